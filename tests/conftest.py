@@ -1,0 +1,26 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def gold():
+    def load(name):
+        return np.load(os.path.join(GOLD, name), allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope='session')
+def dlp():
+    return np.load(os.path.join(ROOT, 'data', 'dlp_scenes.npz'))

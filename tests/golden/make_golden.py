@@ -143,6 +143,14 @@ def flat_rings(rings):
 
 # --------------------------------------------------------------------------- fixtures
 def gold_constants(am, lidar):
+    # capture the table handed to _linear_interpolate inside precompute() (action_mask.py:142)
+    captured = []
+    orig = am._linear_interpolate
+    am._linear_interpolate = lambda x, r=None: (captured.append(np.array(x)), orig(x, r))[1]
+    again = am.precompute()
+    am._linear_interpolate = orig
+    assert np.array_equal(again, am.dist_star)
+    coarse = captured[0]
     theta = np.array([a * math.pi / 120 * 2 for a in range(120)])
     sub = am.dist_star[::7]
     h = hashlib.sha256(np.ascontiguousarray(am.dist_star).tobytes()).hexdigest()
@@ -150,7 +158,7 @@ def gold_constants(am, lidar):
          discrete_actions=np.array(C.discrete_actions, dtype=np.float64),
          vehicle_box=np.array(C.VehicleBox.coords),
          vehicle_boxes=am.vehicle_boxes,
-         dist_star_every7=sub, dist_star_sum=np.array(am.dist_star.sum()),
+         dist_star_coarse=coarse, dist_star_every7=sub, dist_star_sum=np.array(am.dist_star.sum()),
          dist_star_max=np.array(am.dist_star.max()), dist_star_min=np.array(am.dist_star.min()),
          dist_star_sha256=np.array(h),
          dist_star_beam0=am.dist_star[0], dist_star_beam600=am.dist_star[600],
