@@ -93,24 +93,53 @@ def test_quad_overlap_area():
         assert -1e-12 <= ab <= 4.69 * 1.94 + 1e-12
 
 
+def raycast(rings_ego, rng=10.0):
+    """independent parametric ray/segment caster (test-side), ego frame."""
+    out = np.full(120, rng)
+    for i in range(120):
+        th = 2 * math.pi * i / 120
+        dx, dy = math.cos(th), math.sin(th)
+        for r in rings_ego:
+            n = len(r)
+            for k in range(n):
+                (ax, ay), (bx, by) = r[k], r[(k + 1) % n]
+                sx, sy = bx - ax, by - ay
+                den = dx * sy - dy * sx
+                if abs(den) < 1e-14:
+                    continue
+                t = (ax * sy - ay * sx) / den
+                u = (ax * dy - ay * dx) / den
+                if t >= 0 and 0 <= u <= 1:
+                    out[i] = min(out[i], t)
+    return out
+
+
 def test_lidar_ring_cull_and_transform():
-    """ring kept iff its boundary comes within 10 m of the ego origin (lidar_simulator.py:69)."""
+    """ring kept iff its boundary comes within 10 m of the ego origin (lidar_simulator.py:69).
+    Rings are tilted in the ego frame: an edge that is (nearly) axis-aligned THERE is missed by the
+    reference's tolerance-free bbox test -- a faithful quirk covered by the golden lidar fixture."""
     pose = np.array([3.0, -2.0, 0.7])
     c, s = math.cos(0.7), math.sin(0.7)
 
     def world(ego_rect):
         return np.array([(3.0 + c * x - s * y, -2.0 + s * x + c * y) for x, y in ego_rect])
-    near = world(rect(9.0, 0, 2, 2))        # nearest edge at x = 8 -> seen by beam 0 at 8 m
-    far = world(rect(11.5, 0, 2, 2))        # nearest edge at 10.5 -> culled
-    corner = world(rect(8.0, 8.0, 2, 2))    # nearest corner at (7,7): 9.899 < 10 -> kept
+    ego = [rect(9.0, 0, 2, 2, 0.2), rect(12.0, 1.0, 2, 2, 0.4), rect(7.6, 7.6, 2, 2, 0.3), rect(-4, 3, 3, 1, 1.1)]
+    dmin = [min(math.hypot(*p) for p in r) for r in ego]
+    assert dmin[1] > 10.2 and dmin[2] < 9.9        # ring 1 is out of range, ring 2 only by its corner
     hb = O.tables()['hull_base']
-    out = O.lidar_observation(pose, np.stack([near, far, corner]), [4, 4, 4])
-    assert abs(out[0] + hb[0] - 8.0) < 1e-9
-    # beam 16 (48 deg) enters the kept square through its bottom edge y = 7 (beam 15 would graze the
-    # exactly axis-aligned corner (7,7), which the reference's tolerance-free bbox test may miss)
-    assert abs(out[16] + hb[16] - 7 / math.sin(math.radians(48))) < 1e-9
-    out2 = O.lidar_observation(pose, np.stack([far]), [4])
+    out = O.lidar_observation(pose, np.stack([world(r) for r in ego]), [4, 4, 4, 4])
+    want = raycast([ego[0], ego[2], ego[3]])
+    assert np.abs(out + hb - want).max() < 1e-9
+    assert (want < 10).sum() >= 15
+    out2 = O.lidar_observation(pose, np.stack([world(ego[1])]), [4])
     assert np.allclose(out2 + hb, 10.0)
     # a ring wholly containing the vehicle is still seen from inside
-    out3 = O.lidar_observation(pose, np.stack([world(rect(0, 0, 12, 12, 0.2))]), [4])
-    assert ((out3 + hb) < 10.0).all() and ((out3 + hb) >= 6.0 - 1e-9).all()
+    big = rect(0, 0, 12, 12, 0.2)
+    out3 = O.lidar_observation(pose, np.stack([world(big)]), [4])
+    assert np.abs(out3 + hb - raycast([big])).max() < 1e-9
+    assert ((out3 + hb) < 10.0).all()
+    # triangle stored as (v0,v1,v2) with nvert 3
+    tri = np.array([(5.0, -1.0), (6.0, 2.5), (8.0, 0.3)])
+    w = np.vstack([world(tri), world(tri)[2:3]])
+    out4 = O.lidar_observation(pose, w[None], [3])
+    assert np.abs(out4 + hb - raycast([tri])).max() < 1e-9
