@@ -1,0 +1,67 @@
+"""ctypes binding of include/hope_env.h.  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+from .build import lib_path
+
+# mirror of include/hope_env.h
+LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10, 5, 5
+F_OBS_F64, F_ACTION_F64 = 0x1, 0x2
+STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
+ABI_VERSION = 1
+
+EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',
+           'hope_env_set_scenes', 'hope_env_step', 'hope_env_reset_obs', 'hope_env_download_state',
+           'hope_env_upload_state', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
+
+
+class HopeError(RuntimeError):
+    pass
+
+
+class StepOut(C.Structure):
+    _fields_ = [('lidar', C.c_void_p), ('action_mask', C.c_void_p), ('target', C.c_void_p), ('reward', C.c_void_p),
+                ('reward_info', C.c_void_p), ('status', C.c_void_p), ('done', C.c_void_p), ('pose', C.c_void_p),
+                ('rs_word', C.c_void_p), ('rs_lengths', C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen hope_amd/libhope_env.so (built by hope_amd.build.build_extension / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HopeError(f'{path} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    L = C.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise HopeError(f'{path} does not export {name}')
+    L.hope_last_error.restype = C.c_char_p
+    L.hope_env_device_arch.restype = C.c_char_p
+    L.hope_env_device_arch.argtypes = [C.c_void_p]
+    L.hope_env_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_uint32]
+    L.hope_env_destroy.argtypes = [C.c_void_p]
+    L.hope_env_upload_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hope_env_set_scenes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
+    L.hope_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(StepOut), C.c_void_p]
+    L.hope_env_reset_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(StepOut), C.c_void_p]
+    L.hope_env_download_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hope_env_upload_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hope_env_num_scenes.argtypes = [C.c_void_p]
+    L.hope_env_max_obstacles.argtypes = [C.c_void_p]
+    if L.hope_abi_version() != ABI_VERSION:
+        raise HopeError(f'ABI mismatch: library {L.hope_abi_version()} vs binding {ABI_VERSION}')
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load_library().hope_last_error().decode(errors='replace')
+        raise HopeError(f'{what} failed (code {rc}): {msg}')

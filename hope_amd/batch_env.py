@@ -1,0 +1,118 @@
+"""ParkingBatch -- N independent parking scenes stepped on one MI355X through libhope_env.so.
+
+Tensor-in / tensor-out counterpart of `CarParkingWrapper.step` (src/env/env_wrapper.py:73-81) for N >> 1.
+PyTorch is used for device memory and streams only; all arithmetic is in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import tables as T
+from .scenes import pack_scenes
+
+
+class ParkingBatch:
+    def __init__(self, n_scenes, max_obstacles=128, device='cuda:0', obs_dtype=torch.float32,
+                 action_dtype=torch.float32, tables=None):
+        if not torch.cuda.is_available():
+            raise L.HopeError('ParkingBatch needs a HIP device (torch.cuda.is_available() is False); no CPU fallback')
+        self.lib = L.load_library()
+        self.device = torch.device(device)
+        self.n, self.max_obst = int(n_scenes), int(max_obstacles)
+        assert obs_dtype in (torch.float32, torch.float64) and action_dtype in (torch.float32, torch.float64)
+        self.obs_dtype, self.action_dtype = obs_dtype, action_dtype
+        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0)
+        h = C.c_void_p()
+        L.check(self.lib.hope_env_create(C.byref(h), self.n, self.max_obst, self.device.index or 0, flags),
+                'hope_env_create')
+        self.h = h
+        self.arch = self.lib.hope_env_device_arch(self.h).decode()
+        t = T.all_tables() if tables is None else tables
+        self.tables = t
+        ds, hb, ab = (np.ascontiguousarray(t[k], dtype=np.float64) for k in ('dist_star', 'hull_base', 'beam_ab'))
+        assert ds.shape == (1200, 42, 10) and hb.shape == (120,) and ab.shape == (120, 2)
+        L.check(self.lib.hope_env_upload_tables(self.h, ds.ctypes.data, hb.ctypes.data, ab.ctypes.data),
+                'hope_env_upload_tables')
+        n, dev, od = self.n, self.device, obs_dtype
+        self.lidar = torch.zeros((n, L.LIDAR_NUM), dtype=od, device=dev)
+        self.action_mask = torch.zeros((n, L.N_ACTION), dtype=od, device=dev)
+        self.target = torch.zeros((n, L.TARGET_DIM), dtype=od, device=dev)
+        self.reward = torch.zeros(n, dtype=od, device=dev)
+        self.reward_info = torch.zeros((n, 5), dtype=od, device=dev)
+        self.status = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.pose = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        self.rs_word = torch.full((n, 8), -1, dtype=torch.int8, device=dev)
+        self.rs_lengths = torch.zeros((n, L.RS_MAX_SEG), dtype=od, device=dev)
+        self._out = L.StepOut(self.lidar.data_ptr(), self.action_mask.data_ptr(), self.target.data_ptr(),
+                              self.reward.data_ptr(), self.reward_info.data_ptr(), self.status.data_ptr(),
+                              self.done.data_ptr(), self.pose.data_ptr(), self.rs_word.data_ptr(),
+                              self.rs_lengths.data_ptr())
+
+    # -- scenes ------------------------------------------------------------------------------------
+    def set_scenes(self, ids, scenes):
+        """map.reset + vehicle.reset for the listed scene slots (host -> device; synchronous)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        start, dest, bbox, verts, nob, _nv = pack_scenes(scenes, self.max_obst)
+        self.set_scene_arrays(ids, start, dest, bbox, verts, nob)
+
+    def set_scene_arrays(self, ids, start, dest, bbox, verts, n_obst):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (start, dest, bbox, verts)]
+        nob = np.ascontiguousarray(n_obst, dtype=np.int32)
+        assert a[3].shape == (len(ids), self.max_obst, 4, 2)
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.hope_env_set_scenes(self.h, ids.ctypes.data, len(ids), a[0].ctypes.data, a[1].ctypes.data,
+                                             a[2].ctypes.data, a[3].ctypes.data, nob.ctypes.data),
+                'hope_env_set_scenes')
+
+    # -- the hot path ------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset_obs(self, active=None, stages=L.STAGE_ALL):
+        """the action-less step of CarParking.reset (car_parking_base.py:138)."""
+        ap = C.c_void_p(active.data_ptr()) if active is not None else None
+        L.check(self.lib.hope_env_reset_obs(self.h, ap, stages, C.byref(self._out), self._stream()),
+                'hope_env_reset_obs')
+        return self
+
+    def step(self, actions, active=None, stages=L.STAGE_ALL):
+        """actions: [N, 2] (steer, speed) in [-1, 1] on this device."""
+        assert actions.shape == (self.n, 2) and actions.dtype == self.action_dtype and actions.is_contiguous()
+        assert actions.device == self.device
+        ap = C.c_void_p(active.data_ptr()) if active is not None else None
+        L.check(self.lib.hope_env_step(self.h, C.c_void_p(actions.data_ptr()), ap, stages, C.byref(self._out),
+                                       self._stream()), 'hope_env_step')
+        return self
+
+    def obs(self):
+        return {'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
+
+    # -- state -------------------------------------------------------------------------------------
+    def download_state(self):
+        pose, t, acc = np.zeros((self.n, 3)), np.zeros(self.n, np.int32), np.zeros(self.n)
+        L.check(self.lib.hope_env_download_state(self.h, pose.ctypes.data, t.ctypes.data, acc.ctypes.data),
+                'hope_env_download_state')
+        return pose, t, acc
+
+    def upload_state(self, pose=None, t=None, accum=None):
+        p = np.ascontiguousarray(pose, dtype=np.float64) if pose is not None else None
+        tt = np.ascontiguousarray(t, dtype=np.int32) if t is not None else None
+        a = np.ascontiguousarray(accum, dtype=np.float64) if accum is not None else None
+        L.check(self.lib.hope_env_upload_state(self.h, p.ctypes.data if p is not None else None,
+                                               tt.ctypes.data if tt is not None else None,
+                                               a.ctypes.data if a is not None else None), 'hope_env_upload_state')
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.hope_env_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,320 @@
+// hope_env.hip -- host side of the C ABI (include/hope_env.h) + the fused step kernel instantiation.
+// gfx950 only; no CPU fallback: every entry point fails with HOPE_ENODEV/HOPE_EHIP when no device works.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "hope_dev.h"
+#include "hope_env.h"
+#include "hope_internal.h"
+#include "hope_step_kernel.h"
+
+using namespace hope;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(HOPE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+struct hope_env {
+    int n = 0, max_obst = 0, device = 0;
+    uint32_t flags = 0;
+    bool have_tables = false, have_scenes = false;
+    char arch[64] = {0};
+    // device memory
+    double* verts = nullptr;
+    int32_t* n_obst = nullptr;
+    double* scene_c = nullptr;
+    double* state = nullptr;
+    int32_t* tstep = nullptr;
+    double* tab = nullptr;
+    double* pmax = nullptr;
+    double* hull_base = nullptr;
+    double* beam_ab = nullptr;
+    int32_t* rs_count = nullptr;
+    int32_t* rs_list = nullptr;
+    // staging for set_scenes
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// scene upload kernels
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// one thread per uploaded scene: constants, derived dest box, episode state reset
+__global__ void k_set_scene_consts(int n, const int32_t* ids, const double* start, const double* dest,
+                                   const double* bbox, const int32_t* nob, double* scene_c, double* state,
+                                   int32_t* tstep, int32_t* n_obst) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int s = ids[k];
+    double* c = scene_c + (size_t)s * SC_WORDS;
+    for (int i = 0; i < 3; i++) { c[SC_START + i] = start[3 * k + i]; c[SC_DEST + i] = dest[3 * k + i]; }
+    for (int i = 0; i < 4; i++) c[SC_BBOX + i] = bbox[4 * k + i];
+    double sn, ct;
+    sincos(dest[3 * k + 2], &sn, &ct);
+    Box b = make_box(dest[3 * k], dest[3 * k + 1], ct, sn);       // dest.create_box()
+    for (int v = 0; v < 4; v++) { c[SC_DBOX + 2 * v] = b.x[v]; c[SC_DBOX + 2 * v + 1] = b.y[v]; }
+    // Polygon(dest_box).area: GEOS Area::ofRingSigned
+    double sum = 0.0, x0 = b.x[0];
+    for (int i = 1; i < 4; i++) sum += (b.x[i] - x0) * (b.y[i - 1] - b.y[(i + 1) & 3]);
+    c[SC_DAREA] = fabs(sum / 2.0);
+    double dx = dest[3 * k] - start[3 * k], dy = dest[3 * k + 1] - start[3 * k + 1];
+    c[SC_DNORM] = fmax(sqrt(dx * dx + dy * dy), 10.0);            // car_parking_base.py:211
+    for (int i = SC_DNORM + 1; i < SC_WORDS; i++) c[i] = 0.0;
+    double* st = state + (size_t)s * ST_WORDS;
+    st[0] = start[3 * k]; st[1] = start[3 * k + 1]; st[2] = start[3 * k + 2]; st[3] = 0.0;
+    tstep[s] = 0;
+    n_obst[s] = nob[k];
+}
+
+// one block per uploaded scene: copy its obstacle tile
+__global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const double* verts_in, double* verts,
+                                  int max_obst) {
+    int k = blockIdx.x;
+    int s = ids[k];
+    const double2* src = (const double2*)(verts_in + (size_t)k * max_obst * 8);
+    double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
+    int nv = 4 * nob[k];
+    for (int v = threadIdx.x; v < nv; v += blockDim.x) dst[v] = src[v];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* hope_last_error(void) { return g_err.c_str(); }
+int hope_abi_version(void) { return HOPE_ABI_VERSION; }
+
+int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int device_id, uint32_t flags) {
+    if (!out || n_scenes <= 0 || max_obstacles <= 0) return fail(HOPE_EINVAL, "hope_env_create: bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(HOPE_ENODEV, std::string("hope_env_create: no HIP device (") + hipGetErrorString(e) +
+                                     "); libhope_env has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(HOPE_EINVAL, "hope_env_create: device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    size_t lds = step_lds_bytes(max_obstacles);
+    size_t lds_rs = rs_lds_bytes(max_obstacles);
+    if (lds > 160 * 1024 || lds_rs > 160 * 1024)
+        return fail(HOPE_EINVAL, "hope_env_create: max_obstacles too large for the 160 KiB LDS tile");
+    hope_env* h = new (std::nothrow) hope_env();
+    if (!h) return fail(HOPE_ENOMEM, "hope_env_create: host allocation failed");
+    h->n = n_scenes; h->max_obst = max_obstacles; h->device = device_id; h->flags = flags;
+    snprintf(h->arch, sizeof(h->arch), "%s", prop.gcnArchName);
+    size_t N = (size_t)n_scenes;
+#define ALLOC(ptr, bytes)                                                                          \
+    do {                                                                                           \
+        hipError_t e2 = hipMalloc((void**)&(ptr), (bytes));                                        \
+        if (e2 != hipSuccess) {                                                                    \
+            hope_env_destroy(h);                                                                   \
+            return fail(HOPE_ENOMEM, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e2)); \
+        }                                                                                          \
+    } while (0)
+    ALLOC(h->verts, N * max_obstacles * 8 * sizeof(double));
+    ALLOC(h->n_obst, N * sizeof(int32_t));
+    ALLOC(h->scene_c, N * SC_WORDS * sizeof(double));
+    ALLOC(h->state, N * ST_WORDS * sizeof(double));
+    ALLOC(h->tstep, N * sizeof(int32_t));
+    ALLOC(h->tab, (size_t)NL * NITER * NACT * sizeof(double));
+    ALLOC(h->pmax, NL * sizeof(double));
+    ALLOC(h->hull_base, NBEAM * sizeof(double));
+    ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
+    ALLOC(h->rs_count, sizeof(int32_t));
+    ALLOC(h->rs_list, N * sizeof(int32_t));
+#undef ALLOC
+    HIPCHK(hipMemset(h->n_obst, 0, N * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->scene_c, 0, N * SC_WORDS * sizeof(double)));
+    HIPCHK(hipMemset(h->state, 0, N * ST_WORDS * sizeof(double)));
+    HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->rs_count, 0, sizeof(int32_t)));
+    if (lds > 48 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    *out = h;
+    return HOPE_OK;
+}
+
+int hope_env_destroy(hope_env_t* h) {
+    if (!h) return HOPE_OK;
+    hipSetDevice(h->device);
+    void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->stage};
+    for (void* q : ptrs)
+        if (q) hipFree(q);
+    delete h;
+    return HOPE_OK;
+}
+
+int hope_env_num_scenes(const hope_env_t* h) { return h ? h->n : HOPE_EINVAL; }
+int hope_env_max_obstacles(const hope_env_t* h) { return h ? h->max_obst : HOPE_EINVAL; }
+const char* hope_env_device_arch(const hope_env_t* h) { return h ? h->arch : ""; }
+
+int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double* hull_base, const double* beam_ab) {
+    if (!h || !dist_star || !hull_base || !beam_ab) return fail(HOPE_EINVAL, "hope_env_upload_tables: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    // device layout: prefix-max over k (first exceedance of a sequence == first exceedance of its running
+    // max: exact), transposed to [l][k][a] so that lane = action reads coalesced rows.
+    std::vector<double> tab((size_t)NL * NITER * NACT), pmax(NL);
+    for (int l = 0; l < NL; l++) {
+        double pm = -INFINITY;
+        for (int a = 0; a < NACT; a++) {
+            double run = -INFINITY;
+            for (int k = 0; k < NITER; k++) {
+                double v = dist_star[((size_t)l * NACT + a) * NITER + k];
+                run = v > run ? v : run;
+                tab[((size_t)l * NITER + k) * NACT + a] = run;
+            }
+            pm = run > pm ? run : pm;
+        }
+        pmax[l] = pm;
+    }
+    HIPCHK(hipMemcpy(h->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->pmax, pmax.data(), pmax.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->hull_base, hull_base, NBEAM * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->beam_ab, beam_ab, 2 * NBEAM * sizeof(double), hipMemcpyHostToDevice));
+    h->have_tables = true;
+    return HOPE_OK;
+}
+
+int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const double* start, const double* dest,
+                        const double* bbox, const double* verts, const int32_t* n_obst) {
+    if (!h || n < 0 || (n > 0 && (!scene_ids || !start || !dest || !bbox || !n_obst)))
+        return fail(HOPE_EINVAL, "hope_env_set_scenes: null argument");
+    if (n == 0) return HOPE_OK;
+    for (int k = 0; k < n; k++) {
+        if (scene_ids[k] < 0 || scene_ids[k] >= h->n) return fail(HOPE_EINVAL, "hope_env_set_scenes: scene id out of range");
+        if (n_obst[k] < 0 || n_obst[k] > h->max_obst) return fail(HOPE_EINVAL, "hope_env_set_scenes: n_obst exceeds max_obstacles");
+        if (n_obst[k] > 0 && !verts) return fail(HOPE_EINVAL, "hope_env_set_scenes: verts is null");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    size_t tile = (size_t)h->max_obst * 8 * sizeof(double);
+    size_t o_ids = 0, o_nob = o_ids + sizeof(int32_t) * n, o_start = (o_nob + sizeof(int32_t) * n + 15) & ~(size_t)15;
+    size_t o_dest = o_start + 24 * (size_t)n, o_bbox = o_dest + 24 * (size_t)n, o_verts = (o_bbox + 32 * (size_t)n + 15) & ~(size_t)15;
+    size_t need = o_verts + tile * n;
+    if (need > h->stage_bytes) {
+        if (h->stage) hipFree(h->stage);
+        h->stage = nullptr; h->stage_bytes = 0;
+        hipError_t e2 = hipMalloc(&h->stage, need);
+        if (e2 != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc stage: ") + hipGetErrorString(e2));
+        h->stage_bytes = need;
+    }
+    char* sp = (char*)h->stage;
+    HIPCHK(hipMemcpy(sp + o_ids, scene_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_nob, n_obst, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_start, start, 24 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_dest, dest, 24 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_bbox, bbox, 32 * (size_t)n, hipMemcpyHostToDevice));
+    if (verts) HIPCHK(hipMemcpy(sp + o_verts, verts, tile * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_scene_consts, dim3((n + 127) / 128), dim3(128), 0, 0, n, (const int32_t*)(sp + o_ids),
+                       (const double*)(sp + o_start), (const double*)(sp + o_dest), (const double*)(sp + o_bbox),
+                       (const int32_t*)(sp + o_nob), h->scene_c, h->state, h->tstep, h->n_obst);
+    if (verts)
+        hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
+                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), h->verts, h->max_obst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    h->have_scenes = true;
+    return HOPE_OK;
+}
+
+static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages,
+                       const hope_step_out* out, void* stream, int has_action) {
+    if (!h || !out) return fail(HOPE_EINVAL, "hope_env_step: null argument");
+    if (!h->have_tables) return fail(HOPE_ESTATE, "hope_env_step: hope_env_upload_tables has not been called");
+    if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_step: hope_env_set_scenes has not been called");
+    if (has_action && !actions) return fail(HOPE_EINVAL, "hope_env_step: actions is null");
+    if (stages & HOPE_STAGE_RS) stages |= HOPE_STAGE_REWARD;       // the RS gate needs the status
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    StepParams p;
+    p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
+    p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
+    p.actions = actions; p.active = active;
+    p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
+    p.out = *out;
+    p.rs_count = h->rs_count; p.rs_list = h->rs_list;
+    if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, sizeof(int32_t), s));
+    size_t lds = step_lds_bytes(h->max_obst);
+    const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
+    dim3 grid(h->n), block(WAVE);
+    if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
+    else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, s, p);
+    else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, s, p);
+    HIPCHK(hipGetLastError());
+    if ((stages & HOPE_STAGE_RS) && out->rs_word) {
+        RsParams r;
+        r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
+        r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
+        r.rs_count = h->rs_count; r.rs_list = h->rs_list;
+        r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
+        HIPCHK(launch_rs_search(r, s));
+    }
+    return HOPE_OK;
+}
+
+int hope_env_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages,
+                  const hope_step_out* out, void* stream) {
+    return launch_step(h, actions, active, stages, out, stream, 1);
+}
+
+int hope_env_reset_obs(hope_env_t* h, const uint8_t* active, uint32_t stages, const hope_step_out* out, void* stream) {
+    return launch_step(h, nullptr, active, stages & ~HOPE_STAGE_MOTION, out, stream, 0);
+}
+
+int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* accum) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_download_state: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> st((size_t)h->n * ST_WORDS);
+    HIPCHK(hipMemcpy(st.data(), h->state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->n; i++) {
+        if (pose) { pose[3 * i] = st[4 * (size_t)i]; pose[3 * i + 1] = st[4 * (size_t)i + 1]; pose[3 * i + 2] = st[4 * (size_t)i + 2]; }
+        if (accum) accum[i] = st[4 * (size_t)i + 3];
+    }
+    if (t) HIPCHK(hipMemcpy(t, h->tstep, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HOPE_OK;
+}
+
+int hope_env_upload_state(hope_env_t* h, const double* pose, const int32_t* t, const double* accum) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_upload_state: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> st((size_t)h->n * ST_WORDS);
+    HIPCHK(hipMemcpy(st.data(), h->state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->n; i++) {
+        if (pose) { st[4 * (size_t)i] = pose[3 * i]; st[4 * (size_t)i + 1] = pose[3 * i + 1]; st[4 * (size_t)i + 2] = pose[3 * i + 2]; }
+        if (accum) st[4 * (size_t)i + 3] = accum[i];
+    }
+    HIPCHK(hipMemcpy(h->state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (t) HIPCHK(hipMemcpy(h->tstep, t, (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return HOPE_OK;
+}
+
+}  // extern "C"

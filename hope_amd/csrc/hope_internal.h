@@ -1,0 +1,26 @@
+// hope_internal.h -- declarations shared between the translation units of libhope_env.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hope_env.h"
+
+namespace hope {
+
+struct RsParams {
+    int n, max_obst;
+    int obs_f64;
+    const double* verts;      // [n][max_obst][4][2] world frame
+    const int32_t* n_obst;    // [n]
+    const double* scene_c;    // [n][SC_WORDS]
+    const double* state;      // [n][ST_WORDS]
+    const int32_t* rs_count;  // [1]
+    const int32_t* rs_list;   // [n]
+    int8_t* rs_word;          // [n][8]
+    void* rs_lengths;         // real [n][5]
+};
+
+// launches the Reeds-Shepp feasibility kernel over the scenes queued in rs_list (hope_rs.hip)
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream);
+size_t rs_lds_bytes(int max_obst);
+
+}  // namespace hope

@@ -1,0 +1,143 @@
+/*
+ * hope_env.h -- C ABI of libhope_env.so, the MI355X-native batched parking simulator for HOPE.
+ *
+ * The reference (jiamiya/HOPE) has NO FFI / plugin layer: its boundary is the Python class surface
+ * `CarParking` (src/env/car_parking_base.py:39) wrapped by `CarParkingWrapper`
+ * (src/env/env_wrapper.py:58).  This header is therefore the interface a maintainer would bind
+ * with ctypes from a `CarParking` look-alike (INTEGRATION.md shows the stub); each entry point
+ * names the reference method(s) whose work it replaces.
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types: device buffers are `void*` device addresses (e.g.
+ *     tensor.data_ptr()), streams are the raw hipStream_t passed as `void*` (NULL = default stream);
+ *   - every call returns 0 on success or a negative HOPE_E* code; hope_last_error() gives the text.
+ *     Nothing throws across the ABI;
+ *   - one handle per GPU process; a handle is not thread-safe, distinct handles are independent;
+ *   - the library owns the tables, the per-scene obstacle tiles and the per-scene episode state
+ *     (pose, t, accum_arrive_reward); the caller owns every observation/reward buffer;
+ *   - all launches are asynchronous on the caller's stream; no hidden synchronisation except in
+ *     functions documented as host-synchronous (create/destroy/upload/set_scenes/download).
+ *   - the library fails loudly when no HIP device is usable: there is NO CPU fallback.
+ *
+ * Obstacle tile: every obstacle is a ring of 3 or 4 vertices stored in a fixed 4-vertex slot
+ * (64 B, float64 x,y pairs); a triangle repeats its last vertex in slot 3.  The reference's scenes
+ * (data/dlp.data, parking_map_normal.py) contain only 3- and 4-vertex rings.
+ */
+#ifndef HOPE_ENV_H
+#define HOPE_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOPE_ABI_VERSION 1
+
+#define HOPE_LIDAR_NUM 120   /* configs.py:96  */
+#define HOPE_N_ACTION 42     /* configs.py:108-115 */
+#define HOPE_N_ITER 10       /* action_mask.py:9 n_iter */
+#define HOPE_UPSAMPLE 10     /* action_mask.py:18 */
+#define HOPE_TARGET_DIM 5    /* car_parking_base.py:72 */
+#define HOPE_RS_MAX_SEG 5    /* longest Reeds-Shepp word (CCSCC) */
+
+/* error codes */
+#define HOPE_OK 0
+#define HOPE_EINVAL (-1)     /* bad argument                       */
+#define HOPE_ENODEV (-2)     /* no usable HIP device               */
+#define HOPE_ENOMEM (-3)     /* device/host allocation failed      */
+#define HOPE_EHIP (-4)       /* a HIP runtime call failed          */
+#define HOPE_ESTATE (-5)     /* call order violated (e.g. step before tables/scenes) */
+
+/* vehicle.py:13-18 Status */
+#define HOPE_STATUS_CONTINUE 1
+#define HOPE_STATUS_ARRIVED 2
+#define HOPE_STATUS_COLLIDED 3
+#define HOPE_STATUS_OUTBOUND 4
+#define HOPE_STATUS_OUTTIME 5
+
+/* Reeds-Shepp segment types in rs_word[] */
+#define HOPE_RS_NONE (-1)
+#define HOPE_RS_S 0
+#define HOPE_RS_L 1
+#define HOPE_RS_R 2
+
+/* hope_env_create flags */
+#define HOPE_F_OBS_F64 0x1      /* observation/reward buffers are float64 (parity mode); default float32 */
+#define HOPE_F_ACTION_F64 0x2   /* action buffer is float64; default float32 */
+
+/* hope_env_step stage mask */
+#define HOPE_STAGE_MOTION 0x1   /* kinematics + arrival + collision sub-step loop (CarParking.step :255-277) */
+#define HOPE_STAGE_OBS 0x2      /* lidar + action mask + target (CarParking.render :399-407)               */
+#define HOPE_STAGE_REWARD 0x4   /* status + reward (:279-289) + wrapper reward_shaping                     */
+#define HOPE_STAGE_RS 0x8       /* Reeds-Shepp feasibility search (:293-297, find_rs_path :413)           */
+#define HOPE_STAGE_ALL 0xF
+
+typedef struct hope_env hope_env_t;
+
+/* Caller-owned DEVICE buffers filled by hope_env_step / hope_env_reset_obs.  Any pointer may be NULL
+ * (that output is skipped).  "real" = float32, or float64 when the handle has HOPE_F_OBS_F64. */
+typedef struct hope_step_out {
+    void *lidar;        /* real [N][120]  obs['lidar']  (range minus hull range; may be slightly < 0) */
+    void *action_mask;  /* real [N][42]   obs['action_mask'] in {0,.1,..,1} or all .01               */
+    void *target;       /* real [N][5]    obs['target']                                               */
+    void *reward;       /* real [N]       wrapper reward (env_wrapper.py:10-35)                       */
+    void *reward_info;  /* real [N][5]    time_cost, rs_dist, dist, angle, box_union                  */
+    int32_t *status;    /* i32  [N]       HOPE_STATUS_*                                               */
+    uint8_t *done;      /* u8   [N]       status != CONTINUE                                          */
+    double *pose;       /* f64  [N][3]    x, y, heading after the step (always float64)               */
+    int8_t *rs_word;    /* i8   [N][8]    [0..4] segment types (HOPE_RS_*), [5] n_seg, [6] found, [7] 0 */
+    void *rs_lengths;   /* real [N][5]    signed segment lengths in metres (PATH.lengths)             */
+} hope_step_out;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Replaces CarParking.__init__ (car_parking_base.py:48-115) for n_scenes parallel environments.
+ * max_obstacles bounds the obstacle count of any scene (LDS tile = 64 B x max_obstacles per wave). */
+int hope_env_create(hope_env_t **out, int n_scenes, int max_obstacles, int device_id, uint32_t flags);
+int hope_env_destroy(hope_env_t *h);                       /* CarParking.close (:536) */
+const char *hope_last_error(void);
+int hope_abi_version(void);
+
+/* ---- tables: ActionMask.__init__ / LidarSimlator.__init__ products (host pointers, host-sync) -- */
+/* dist_star  [1200][42][10] float64, reference order (action_mask.py:114-143 `precompute`);
+ * hull_base  [120]  range from the rear axle to the hull per beam (lidar_simulator.py:48-53);
+ * beam_ab    [120][2]  (sin theta_i, -cos theta_i) of lidar_simulator.py:86-88. */
+int hope_env_upload_tables(hope_env_t *h, const double *dist_star, const double *hull_base,
+                           const double *beam_ab);
+
+/* ---- scenes: map.reset + vehicle.reset (car_parking_base.py:127-137), host pointers, host-sync -- */
+/* For k in [0,n): scene scene_ids[k] gets start[k][3], dest[k][3] (x,y,heading), bbox[k][4]
+ * (xmin,xmax,ymin,ymax; parking_map_dlp.py:70-73 / parking_map_normal.py:486-489), n_obst[k]
+ * obstacles whose vertices are verts[k][max_obstacles][4][2].  Episode state is reset: pose=start,
+ * t=0, accum_arrive_reward=0.  The caller then runs hope_env_reset_obs (reset's `self.step()`). */
+int hope_env_set_scenes(hope_env_t *h, const int32_t *scene_ids, int n, const double *start,
+                        const double *dest, const double *bbox, const double *verts,
+                        const int32_t *n_obst);
+
+/* ---- the hot path (asynchronous on `stream`) ------------------------------------------------- */
+/* CarParkingWrapper.step(action) (env_wrapper.py:73-81) for all scenes:
+ * actions = DEVICE [N][2] (steer, speed) in [-1,1] (float32, or float64 with HOPE_F_ACTION_F64).
+ * active  = optional DEVICE u8 [N]; scenes with active[i]==0 are left untouched (outputs too). */
+int hope_env_step(hope_env_t *h, const void *actions, const uint8_t *active, uint32_t stages,
+                  const hope_step_out *out, void *stream);
+
+/* The action-less step of CarParking.reset (:138) / CarParkingWrapper.step(None) (:74-75):
+ * t += 1, observation, status, reward; no motion. */
+int hope_env_reset_obs(hope_env_t *h, const uint8_t *active, uint32_t stages, const hope_step_out *out,
+                       void *stream);
+
+/* ---- state access (host-sync; tests, checkpointing) ------------------------------------------ */
+int hope_env_download_state(hope_env_t *h, double *pose /*[N][3]*/, int32_t *t /*[N]*/,
+                            double *accum /*[N]*/);
+int hope_env_upload_state(hope_env_t *h, const double *pose, const int32_t *t, const double *accum);
+
+/* ---- introspection ---------------------------------------------------------------------------- */
+int hope_env_num_scenes(const hope_env_t *h);
+int hope_env_max_obstacles(const hope_env_t *h);
+/* name of the device the handle runs on (e.g. "gfx950"), static storage */
+const char *hope_env_device_arch(const hope_env_t *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOPE_ENV_H */

@@ -1,0 +1,149 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): collision/arrival/status flags and action-mask values bit-exact;
+pose / lidar / target / reward within a stated tolerance -- 1e-9 absolute in float64 observation mode
+(device libm = OCML vs glibc: <= 2 ulp per transcendental, accumulated over 200 Euler micro-steps),
+1e-5 in float32 observation mode.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+TOL64 = 1e-9
+TOL32 = 2e-5
+
+
+def make_pair(n, seed, obs64=True, max_obst=128, level='dlp'):
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import DlpScenePool, pack_scenes
+    from oracle import oracle as O
+    pool = DlpScenePool()
+    rng = np.random.default_rng(seed)
+    scenes = [pool.sample(rng=rng) for _ in range(n)]
+    # half of the scenes start near the destination (tight surroundings, arrival, collisions)
+    for k in range(0, n, 2):
+        s = scenes[k]
+        r, a = rng.uniform(0.0, 6.0), rng.uniform(0, 2 * np.pi)
+        s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.5])
+    env = ParkingBatch(n, max_obst, obs_dtype=torch.float64 if obs64 else torch.float32, action_dtype=torch.float64)
+    assert env.arch.startswith('gfx950'), env.arch
+    env.set_scenes(np.arange(n), scenes)
+    orc = O.BatchOracle(n, max_obst)
+    start, dest, bbox, verts, nob, nvert = pack_scenes(scenes, max_obst)
+    orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+    t = env.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    return env, orc, rng
+
+
+def compare(env, o, tol, stats, with_rs=False):
+    torch.cuda.synchronize()
+    st = env.status.cpu().numpy()
+    stats['status_mismatch'] += int((st != o['status']).sum())
+    stats['mask_mismatch'] += int((np.abs(env.action_mask.double().cpu().numpy() - o['mask']) > 1e-6).any(axis=1).sum())
+    stats['lidar_err'] = max(stats['lidar_err'], float(np.abs(env.lidar.double().cpu().numpy() - o['lidar']).max()))
+    stats['target_err'] = max(stats['target_err'], float(np.abs(env.target.double().cpu().numpy() - o['target']).max()))
+    stats['reward_err'] = max(stats['reward_err'], float(np.abs(env.reward.double().cpu().numpy() - o['reward']).max()))
+    stats['rinfo_err'] = max(stats['rinfo_err'], float(np.abs(env.reward_info.double().cpu().numpy() - o['reward_info']).max()))
+    if with_rs:
+        w = env.rs_word.cpu().numpy()
+        stats['rs_flag_mismatch'] += int((w[:, 6] != o['rs_found']).sum())
+        stats['rs_word_mismatch'] += int((w[:, :5] != o['rs_ctypes']).any(axis=1).sum())
+        stats['rs_len_err'] = max(stats['rs_len_err'], float(np.abs(env.rs_lengths.double().cpu().numpy() - o['rs_lengths']).max()))
+
+
+def new_stats():
+    return dict(status_mismatch=0, mask_mismatch=0, lidar_err=0.0, target_err=0.0, reward_err=0.0, rinfo_err=0.0,
+                pose_err=0.0, rs_flag_mismatch=0, rs_word_mismatch=0, rs_len_err=0.0)
+
+
+def rollout(env, orc, rng, steps, tol, with_rs=False, stages=None):
+    from hope_amd import _lib as L
+    if stages is None:
+        stages = L.STAGE_ALL if with_rs else (L.STAGE_MOTION | L.STAGE_OBS | L.STAGE_REWARD)
+    stats = new_stats()
+    env.reset_obs(stages=stages)
+    compare(env, orc.reset_obs(with_rs=with_rs), tol, stats, with_rs)
+    seen = set()
+    for it in range(steps):
+        act = rng.uniform(-1.2, 1.2, (env.n, 2))
+        if it % 3 == 0:
+            act[:, 1] = np.sign(act[:, 1]) * 1.0          # full speed: more collisions / outbound
+        a = torch.from_numpy(act).to(env.device)
+        env.step(a, stages=stages)
+        o = orc.step(act, with_rs=with_rs)
+        compare(env, o, tol, stats, with_rs)
+        pose, t, acc = env.download_state()
+        stats['pose_err'] = max(stats['pose_err'], float(np.abs(pose - orc.pose).max()))
+        assert np.array_equal(t, orc.t.astype(np.int32))
+        seen |= set(np.unique(o['status']).tolist())
+    stats['seen'] = sorted(seen)
+    return stats
+
+
+def test_library_is_native():
+    from hope_amd import load_library
+    L = load_library()
+    assert L.hope_abi_version() == 1
+
+
+def test_step_parity_f64_dlp():
+    env, orc, rng = make_pair(384, seed=11)
+    s = rollout(env, orc, rng, steps=24, tol=TOL64)
+    print('parity f64:', s)
+    assert s['status_mismatch'] == 0 and s['mask_mismatch'] == 0
+    assert s['pose_err'] < TOL64 and s['lidar_err'] < TOL64 and s['target_err'] < TOL64
+    assert s['reward_err'] < TOL64 and s['rinfo_err'] < TOL64
+    assert {1, 3}.issubset(set(s['seen'])) or {1, 4}.issubset(set(s['seen']))     # episodes do end
+    env.close()
+
+
+def test_step_parity_f32_outputs():
+    env, orc, rng = make_pair(256, seed=12, obs64=False)
+    s = rollout(env, orc, rng, steps=10, tol=TOL32)
+    print('parity f32:', s)
+    assert s['status_mismatch'] == 0 and s['mask_mismatch'] == 0
+    assert s['pose_err'] < TOL64
+    assert s['lidar_err'] < TOL32 and s['target_err'] < TOL32 and s['reward_err'] < TOL32
+    env.close()
+
+
+def test_motion_only_config2():
+    """BASELINE config 2: kinematics + OBB collision only (4096 mixed scenes), flags bit-exact."""
+    from hope_amd import _lib as L
+    env, orc, rng = make_pair(4096, seed=13)
+    stages = L.STAGE_MOTION | L.STAGE_REWARD
+    stats = new_stats()
+    for it in range(6):
+        act = rng.uniform(-1, 1, (env.n, 2))
+        env.step(torch.from_numpy(act).to(env.device), stages=stages)
+        o = orc.step(act, with_rs=False)
+        torch.cuda.synchronize()
+        stats['status_mismatch'] += int((env.status.cpu().numpy() != o['status']).sum())
+        pose, t, acc = env.download_state()
+        stats['pose_err'] = max(stats['pose_err'], float(np.abs(pose - orc.pose).max()))
+        stats['reward_err'] = max(stats['reward_err'], float(np.abs(env.reward.cpu().numpy() - o['reward']).max()))
+    print('config2:', stats)
+    assert stats['status_mismatch'] == 0 and stats['pose_err'] < TOL64 and stats['reward_err'] < TOL64
+    env.close()
+
+
+def test_active_mask_leaves_scenes_untouched():
+    env, orc, rng = make_pair(64, seed=14)
+    env.reset_obs()
+    torch.cuda.synchronize()
+    pose0, t0, _ = env.download_state()
+    lid0 = env.lidar.clone()
+    active = torch.zeros(64, dtype=torch.uint8, device=env.device)
+    active[::2] = 1
+    act = torch.from_numpy(rng.uniform(-1, 1, (64, 2))).to(env.device)
+    env.step(act, active=active)
+    torch.cuda.synchronize()
+    pose1, t1, _ = env.download_state()
+    assert np.array_equal(pose1[1::2], pose0[1::2]) and np.array_equal(t1[1::2], t0[1::2])
+    assert (t1[::2] == t0[::2] + 1).all()
+    assert torch.equal(env.lidar[1::2], lid0[1::2])
+    env.close()
