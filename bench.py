@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- parallel env-steps/s of the HOPE parking-env step hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize,
+MAX over ranks, rank 0 prints ONE JSON line.
+
+A "step" = one pass of the full hot path (CarParkingWrapper.step: kinematics + collision sub-steps,
+lidar, action mask, reward, Reeds-Shepp feasibility search) over a batch of `--scenes` synthetic
+scenes PER GPU (weak scaling; default 65 536 = BASELINE.json's "64k scenes"), followed by the
+episode turnover the reference's loop performs (`reset` of finished episodes: restart + the
+action-less observation step).  Inputs (scene tiles, actions) are resident in HBM when the timed
+region starts.  Independent scenes shard over ranks with no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--scenes', type=int, default=65536, help='scenes per GPU')
+    ap.add_argument('--max-obst', type=int, default=128)
+    ap.add_argument('--mix', default='mixed', choices=['mixed', 'dlp', 'normal'])
+    ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
+    ap.add_argument('--unique', type=int, default=8192, help='distinct generated scenes (tiled to --scenes)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-scenes', type=int, default=192)
+    ap.add_argument('--cpu-steps', type=int, default=12)
+    ap.add_argument('--seed', type=int, default=42)
+    return ap.parse_args()
+
+
+def make_scenes(n_unique, mix, rng):
+    from hope_amd import scenes as S
+    pool = S.DlpScenePool()
+    out = []
+    levels = {'mixed': ['Normal', 'Complex', 'Extrem', 'dlp'], 'dlp': ['dlp'], 'normal': ['Normal', 'Complex', 'Extrem']}[mix]
+    gen = getattr(S, 'generate_scene', None)
+    for k in range(n_unique):
+        lv = levels[k % len(levels)]
+        if lv == 'dlp' or gen is None:
+            out.append(pool.sample(rng=rng))
+        else:
+            out.append(gen(lv, rng))
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})')
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device: the product has no CPU path')
+    dev = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scenes import pack_scenes
+
+    N = args.scenes
+    rng = np.random.default_rng(args.seed + rank)
+    uniq = make_scenes(min(N, args.unique), args.mix, rng)
+    start, dest, bbox, verts, nob, nvert = pack_scenes(uniq, args.max_obst)
+    reps = (N + len(uniq) - 1) // len(uniq)
+    tile = lambda a: np.concatenate([a] * reps, axis=0)[:N]  # noqa: E731
+    stages = {'all': L.STAGE_ALL, 'norss': L.STAGE_MOTION | L.STAGE_OBS | L.STAGE_REWARD,
+              'motion': L.STAGE_MOTION | L.STAGE_REWARD}[args.stages]
+
+    env = ParkingBatch(N, args.max_obst, device=str(dev), obs_dtype=torch.float32, action_dtype=torch.float32,
+                       profile=True)
+    chunk = 8192
+    for a in range(0, N, chunk):
+        b = min(N, a + chunk)
+        sl = slice(a, b)
+        env.set_scene_arrays(np.arange(a, b), tile(start)[sl], tile(dest)[sl], tile(bbox)[sl], tile(verts)[sl],
+                             tile(nob)[sl])
+    n_obst_all = tile(nob)
+    edges = 4.0 * n_obst_all
+    # algorithmic bytes per scene-step = 808 + 16*E (reads 64 + 16E, writes 744)
+    bytes_per_launch = float(np.sum(808.0 + 16.0 * edges))
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + rank)
+    act_bank = [torch.rand((N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
+
+    def one_step(i):
+        env.step(act_bank[i % len(act_bank)], stages=stages)
+        env.restart(env.done)                      # episode turnover: finished scenes start over
+        env.reset_obs(active=env.done, stages=stages)
+
+    env.reset_obs(stages=stages)
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize(dev)
+    env.kernel_ms(reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    step_ms, step_n, rs_ms, rs_n = env.kernel_ms(reset=True)
+    done_frac = float(env.done.float().mean().item())
+    rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    result = None
+    if rank == 0:
+        total_scenes = N * world
+        value = total_scenes * args.steps / elapsed
+        # dominant kernel = the one with the larger accumulated HIP-event time.  step launches include
+        # the (active-masked) reset_obs launches, so average over "full" launches only: args.steps of them
+        # carry the whole batch; the masked ones are counted into the same accumulated time (conservative).
+        k_step = step_ms / max(args.steps, 1)
+        k_rs = rs_ms / max(args.steps, 1)
+        dom, dom_ms = ('k_env_step', k_step) if k_step >= k_rs else ('k_rs_search', k_rs)
+        achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        result = {
+            'metric': 'parallel env steps/sec (full CarParking step incl. obs + RS search)', 'value': value,
+            'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}, random actions U[-1,1]^2, '
+                                   'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
+                       'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
+                       'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': traffic, 'kernel': dom,
+                         'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'k_env_step_ms_per_step': k_step, 'k_rs_search_ms_per_step': k_rs},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result['cpu_baseline'] = cpu_baseline(args, uniq, stages)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(args, uniq, stages):
+    """The CPU oracle (a C port of the reference algorithm) timed on this box's host cores on a bounded
+    sample of the SAME workload: first --cpu-scenes scenes, --cpu-steps steps, single thread (and all
+    cores via OpenMP as an extra figure).  Reported, non-target."""
+    from hope_amd import _lib as L
+    from hope_amd import tables as T
+    from hope_amd.scenes import pack_scenes
+    from oracle import oracle as O
+    n = min(args.cpu_scenes, len(uniq))
+    sample = uniq[:n]
+    start, dest, bbox, verts, nob, nvert = pack_scenes(sample, args.max_obst)
+    t = T.all_tables()
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    with_rs = bool(stages & L.STAGE_RS)
+    rng = np.random.default_rng(args.seed)
+    acts = [rng.uniform(-1, 1, (n, 2)) for _ in range(args.cpu_steps)]
+    res = {}
+    for omp in (False, True):
+        orc = O.BatchOracle(n, args.max_obst, omp=omp)
+        orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+        orc.reset_obs(with_rs=with_rs)
+        t0 = time.perf_counter()
+        for a in acts:
+            o = orc.step(a, with_rs=with_rs)
+            done = o['status'] != 1
+            if done.any():
+                ids = np.nonzero(done)[0]
+                orc.pose[ids] = orc.start[ids]
+                orc.t[ids] = 0
+                orc.accum[ids] = 0
+        dt = time.perf_counter() - t0
+        res[omp] = n * args.cpu_steps / dt
+    cores = os.cpu_count() or 1
+    return {'value': res[False], 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'first {n} scenes of the bench scene set x {args.cpu_steps} steps, same stages/actions, '
+                      'oracle/hope_oracle.c (gcc -O2), 1 thread',
+            'allcore_value': res[True], 'allcore_threads': O.lib(True).orc_num_threads(), 'host_cores': cores}
+
+
+if __name__ == '__main__':
+    main()

@@ -15,7 +15,7 @@ from .scenes import pack_scenes
 
 class ParkingBatch:
     def __init__(self, n_scenes, max_obstacles=128, device='cuda:0', obs_dtype=torch.float32,
-                 action_dtype=torch.float32, tables=None):
+                 action_dtype=torch.float32, tables=None, profile=False):
         if not torch.cuda.is_available():
             raise L.HopeError('ParkingBatch needs a HIP device (torch.cuda.is_available() is False); no CPU fallback')
         self.lib = L.load_library()
@@ -23,7 +23,7 @@ class ParkingBatch:
         self.n, self.max_obst = int(n_scenes), int(max_obstacles)
         assert obs_dtype in (torch.float32, torch.float64) and action_dtype in (torch.float32, torch.float64)
         self.obs_dtype, self.action_dtype = obs_dtype, action_dtype
-        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0)
+        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0) | (L.F_PROFILE if profile else 0)
         h = C.c_void_p()
         L.check(self.lib.hope_env_create(C.byref(h), self.n, self.max_obst, self.device.index or 0, flags),
                 'hope_env_create')
@@ -87,6 +87,19 @@ class ParkingBatch:
         L.check(self.lib.hope_env_step(self.h, C.c_void_p(actions.data_ptr()), ap, stages, C.byref(self._out),
                                        self._stream()), 'hope_env_step')
         return self
+
+    def restart(self, mask):
+        """episodes flagged in mask (u8 [N]) go back to their start pose, t = 0 (same map)."""
+        assert mask.dtype == torch.uint8 and mask.shape == (self.n,) and mask.device == self.device
+        L.check(self.lib.hope_env_restart(self.h, C.c_void_p(mask.data_ptr()), self._stream()), 'hope_env_restart')
+        return self
+
+    def kernel_ms(self, reset=True):
+        """(step_ms, step_launches, rs_ms, rs_launches) from in-library HIP events (profile=True)."""
+        a, b, c, d = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_int64(0)
+        L.check(self.lib.hope_env_kernel_ms(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), int(reset)),
+                'hope_env_kernel_ms')
+        return a.value, b.value, c.value, d.value
 
     def obs(self):
         return {'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}

@@ -48,7 +48,34 @@ struct hope_env {
     // staging for set_scenes
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // HOPE_F_PROFILE: event pairs recorded on the launch stream, drained by hope_env_kernel_ms
+    struct EvPair { hipEvent_t a, b; int kind; };
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> free_events;
+    double ms[2] = {0, 0};
+    int64_t launches[2] = {0, 0};
 };
+
+static hipEvent_t get_event(hope_env* h) {
+    if (!h->free_events.empty()) { hipEvent_t e = h->free_events.back(); h->free_events.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+static int drain_events(hope_env* h) {
+    for (auto& p : h->pending) {
+        float ms = 0;
+        hipError_t e = hipEventSynchronize(p.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.a, p.b);
+        if (e != hipSuccess) return fail(HOPE_EHIP, std::string("event timing: ") + hipGetErrorString(e));
+        h->ms[p.kind] += ms;
+        h->launches[p.kind] += 1;
+        h->free_events.push_back(p.a);
+        h->free_events.push_back(p.b);
+    }
+    h->pending.clear();
+    return HOPE_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // scene upload kernels
@@ -80,6 +107,16 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
     st[0] = start[3 * k]; st[1] = start[3 * k + 1]; st[2] = start[3 * k + 2]; st[3] = 0.0;
     tstep[s] = 0;
     n_obst[s] = nob[k];
+}
+
+// episode restart: pose = start, t = 0, accum = 0 for masked scenes
+__global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, double* state, int32_t* tstep) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !mask[s]) return;
+    const double* c = scene_c + (size_t)s * SC_WORDS;
+    double* st = state + (size_t)s * ST_WORDS;
+    st[0] = c[SC_START]; st[1] = c[SC_START + 1]; st[2] = c[SC_START + 2]; st[3] = 0.0;
+    tstep[s] = 0;
 }
 
 // one block per uploaded scene: copy its obstacle tile
@@ -163,6 +200,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
 int hope_env_destroy(hope_env_t* h) {
     if (!h) return HOPE_OK;
     hipSetDevice(h->device);
+    drain_events(h);
+    for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
                     h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->stage};
     for (void* q : ptrs)
@@ -263,19 +302,59 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     size_t lds = step_lds_bytes(h->max_obst);
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 grid(h->n), block(WAVE);
+    const bool prof = h->flags & HOPE_F_PROFILE;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (prof) {
+        if (h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
+        ea = get_event(h); eb = get_event(h);
+        if (!ea || !eb) return fail(HOPE_EHIP, "hipEventCreate failed");
+        HIPCHK(hipEventRecord(ea, s));
+    }
     if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
     else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, s, p);
     else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, s, p);
     HIPCHK(hipGetLastError());
+    if (prof) { HIPCHK(hipEventRecord(eb, s)); h->pending.push_back({ea, eb, 0}); }
     if ((stages & HOPE_STAGE_RS) && out->rs_word) {
+        if (prof) {
+            ea = get_event(h); eb = get_event(h);
+            if (!ea || !eb) return fail(HOPE_EHIP, "hipEventCreate failed");
+            HIPCHK(hipEventRecord(ea, s));
+        }
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
         r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
         r.rs_count = h->rs_count; r.rs_list = h->rs_list;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
         HIPCHK(launch_rs_search(r, s));
+        if (prof) { HIPCHK(hipEventRecord(eb, s)); h->pending.push_back({ea, eb, 1}); }
     }
+    return HOPE_OK;
+}
+
+int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
+    if (!h || !mask) return fail(HOPE_EINVAL, "hope_env_restart: null argument");
+    if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_restart: hope_env_set_scenes has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_restart, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->n, mask, h->scene_c,
+                       h->state, h->tstep);
+    HIPCHK(hipGetLastError());
+    return HOPE_OK;
+}
+
+int hope_env_kernel_ms(hope_env_t* h, double* step_ms, int64_t* step_launches, double* rs_ms, int64_t* rs_launches,
+                       int reset) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_kernel_ms: null handle");
+    if (!(h->flags & HOPE_F_PROFILE)) return fail(HOPE_ESTATE, "hope_env_kernel_ms: handle was not created with HOPE_F_PROFILE");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = drain_events(h);
+    if (rc) return rc;
+    if (step_ms) *step_ms = h->ms[0];
+    if (step_launches) *step_launches = h->launches[0];
+    if (rs_ms) *rs_ms = h->ms[1];
+    if (rs_launches) *rs_launches = h->launches[1];
+    if (reset) { h->ms[0] = h->ms[1] = 0; h->launches[0] = h->launches[1] = 0; }
     return HOPE_OK;
 }
 

@@ -65,6 +65,7 @@ extern "C" {
 /* hope_env_create flags */
 #define HOPE_F_OBS_F64 0x1      /* observation/reward buffers are float64 (parity mode); default float32 */
 #define HOPE_F_ACTION_F64 0x2   /* action buffer is float64; default float32 */
+#define HOPE_F_PROFILE 0x4      /* record HIP events around every kernel launch (hope_env_kernel_ms) */
 
 /* hope_env_step stage mask */
 #define HOPE_STAGE_MOTION 0x1   /* kinematics + arrival + collision sub-step loop (CarParking.step :255-277) */
@@ -125,6 +126,16 @@ int hope_env_step(hope_env_t *h, const void *actions, const uint8_t *active, uin
  * t += 1, observation, status, reward; no motion. */
 int hope_env_reset_obs(hope_env_t *h, const uint8_t *active, uint32_t stages, const hope_step_out *out,
                        void *stream);
+
+/* vehicle.reset(initial_state) + accumulator reset of CarParking.reset (:128-136) WITHOUT a new map:
+ * scenes with mask[i] != 0 go back to pose = start, t = 0, accum_arrive_reward = 0 (asynchronous).
+ * Follow with hope_env_reset_obs(active = mask) to obtain the first observation. */
+int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
+
+/* With HOPE_F_PROFILE: accumulated HIP-event time (ms) and launch count of the step kernel and of the
+ * Reeds-Shepp kernel since the last call with reset != 0.  Host-synchronous. */
+int hope_env_kernel_ms(hope_env_t *h, double *step_ms, int64_t *step_launches, double *rs_ms,
+                       int64_t *rs_launches, int reset);
 
 /* ---- state access (host-sync; tests, checkpointing) ------------------------------------------ */
 int hope_env_download_state(hope_env_t *h, double *pose /*[N][3]*/, int32_t *t /*[N]*/,
