@@ -33,6 +33,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.  Import it FIRST so that this library
+    # binds to the HIP runtime torch already initialised (one runtime per process); loading in the other
+    # order leaves the process with two runtimes and "no ROCm-capable device" from the second one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise HopeError(f'{path} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '

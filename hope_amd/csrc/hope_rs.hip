@@ -1,11 +1,527 @@
-// hope_rs.hip -- Reeds-Shepp feasibility search kernel (placeholder wiring; real kernel follows)
+// hope_rs.hip -- Reeds-Shepp feasibility search: ONE WAVEFRONT PER ELIGIBLE SCENE.
+//
+// Replaces CarParking.find_rs_path (src/env/car_parking_base.py:413-450) with
+//   rsCurve.calc_all_paths / generate_path / set_path / generate_local_course / interpolate
+//     (src/env/reeds_shepp.py:35-557) and CarParking.is_traj_valid (car_parking_base.py:452-534),
+// for the scenes the step kernel queued (gate :293-294: t > 1, CONTINUE, |pos - dest| < 10).
+//
+// Mapping onto the wave:
+//   1. the 46 word-solver calls of generate_path run one per lane (lanes 0..45);
+//   2. set_path's ORDER-DEPENDENT de-dup (signed length-sum test, :63-66) is replayed sequentially over
+//      the candidates with a cross-lane ballot; L = sum |len|, L >= 1000 dropped (:68-71);
+//   3. lane 0 replays heapdict's array heap (push order = path order, non-strict sift-up, strict
+//      sift-down) to obtain the pop order find_rs_path sees, ties included;
+//   4. for each popped path (stop rule :443) the samples of generate_local_course are produced 64 at a
+//      time: the `pd += d` chain is run in lock-step by all lanes (sequential rounding kept), each
+//      lane interpolates ITS sample, builds the 4 hull edges and tests them against the obstacle tile
+//      in LDS.  A (hull edge, obstacle edge) pair can only be a hit if the two edge bounding boxes
+//      overlap (the reference requires the intersection point inside both), so pairs failing that
+//      exact pre-test skip the two float64 divisions.  The reference's obstacle cull (:482-494) and
+//      its T x 4 x E matrix are result-neutral and are not materialised.
+// Deviation (documented in DESIGN.md): generate_local_course's "pop trailing samples whose local x is
+// exactly 0.0" (:501-505) is not replayed beyond the unused array tail (a measure-zero event).
 #include "hope_dev.h"
 #include "hope_internal.h"
 
 namespace hope {
-size_t rs_lds_bytes(int max_obst) { return (size_t)max_obst * 64 + 4096; }
-hipError_t launch_rs_search(const RsParams& p, hipStream_t stream) {
-    (void)p; (void)stream;
-    return hipSuccess;
+
+namespace {
+
+constexpr double MAXC = 0.3327130214085973;      // math.tan(VALID_STEER[-1]) / WHEEL_BASE  (car_parking_base.py:422)
+constexpr double RS_STEP = 0.1;                  // step_size passed by find_rs_path (:424)
+constexpr double MAX_LENGTH = 1000.0;            // reeds_shepp.py:6
+constexpr int NCAND = 46;
+
+enum { TS = 0, TL = 1, TR = 2 };
+
+__device__ __forceinline__ double py_mod(double v, double w) {   // Python float %
+    double m = fmod(v, w);
+    if (m != 0) { if ((w < 0) != (m < 0)) m += w; } else m = copysign(0.0, w);
+    return m;
 }
+__device__ __forceinline__ double rs_M(double theta) {           // reeds_shepp.py:581-592
+    double phi = py_mod(theta, 2.0 * PI);
+    if (phi < -PI) phi += 2.0 * PI;
+    if (phi > PI) phi -= 2.0 * PI;
+    return phi;
+}
+__device__ __forceinline__ void rs_R(double x, double y, double& r, double& th) { r = hypot(x, y); th = atan2(y, x); }
+__device__ __forceinline__ double pi_2_pi(double t) {            // :561-568
+    while (t > PI) t -= 2.0 * PI;
+    while (t < -PI) t += 2.0 * PI;
+    return t;
+}
+
+__device__ bool rs_SLS(double x, double y, double phi, double& t, double& u, double& v) {   // :133-149
+    phi = rs_M(phi);
+    if (y > 0.0 && 0.0 < phi && phi < PI * 0.99) {
+        double xd = -y / tan(phi) + x;
+        t = xd - tan(phi / 2.0);
+        u = phi;
+        v = sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        return true;
+    } else if (y < 0.0 && 0.0 < phi && phi < PI * 0.99) {
+        double xd = -y / tan(phi) + x;
+        t = xd - tan(phi / 2.0);
+        u = phi;
+        v = -sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        return true;
+    }
+    return false;
+}
+__device__ bool rs_LSL(double x, double y, double phi, double& t, double& u, double& v) {   // :79-87
+    double uu, tt;
+    rs_R(x - sin(phi), y - 1.0 + cos(phi), uu, tt);
+    if (tt >= 0.0) {
+        double vv = rs_M(phi - tt);
+        if (vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+__device__ bool rs_LSR(double x, double y, double phi, double& t, double& u, double& v) {   // :90-103
+    double u1, t1;
+    rs_R(x + sin(phi), y - 1.0 - cos(phi), u1, t1);
+    u1 = u1 * u1;
+    if (u1 >= 4.0) {
+        double uu = sqrt(u1 - 4.0);
+        double theta = atan2(2.0, uu);
+        double tt = rs_M(t1 + theta);
+        double vv = rs_M(tt - phi);
+        if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+__device__ bool rs_LRL(double x, double y, double phi, double& t, double& u, double& v) {   // :106-117
+    double u1, t1;
+    rs_R(x - sin(phi), y - 1.0 + cos(phi), u1, t1);
+    if (u1 <= 4.0) {
+        double uu = -2.0 * asin(0.25 * u1);
+        double tt = rs_M(t1 + 0.5 * uu + PI);
+        double vv = rs_M(phi - tt + uu);
+        if (tt >= 0.0 && uu <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+__device__ void calc_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega) {
+    double delta = rs_M(u - v);                                                             // :228-243
+    double A = sin(u) - sin(delta);
+    double B = cos(u) - cos(delta) - 1.0;
+    double t1 = atan2(eta * A - xi * B, xi * A + eta * B);
+    double t2 = 2.0 * (cos(delta) - cos(v) - cos(u)) + 3.0;
+    if (t2 < 0) tau = rs_M(t1 + PI); else tau = rs_M(t1);
+    omega = rs_M(tau - u + v - phi);
+}
+__device__ bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double& v) { // :246-257
+    double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
+    double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
+    if (rho <= 1.0) {
+        double uu = acos(rho), tt, vv;
+        calc_tauOmega(uu, -uu, xi, eta, phi, tt, vv);
+        if (tt >= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+__device__ bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double& v) { // :260-272
+    double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
+    double rho = (20.0 - xi * xi - eta * eta) / 16.0;
+    if (0.0 <= rho && rho <= 1.0) {
+        double uu = -acos(rho);
+        if (uu >= -0.5 * PI) {
+            double tt, vv;
+            calc_tauOmega(uu, uu, xi, eta, phi, tt, vv);
+            if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+        }
+    }
+    return false;
+}
+__device__ bool rs_LRSR(double x, double y, double phi, double& t, double& u, double& v) {  // :311-323
+    double xi = x + sin(phi), eta = y - 1.0 - cos(phi), rho, theta;
+    rs_R(-eta, xi, rho, theta);
+    if (rho >= 2.0) {
+        double tt = theta, uu = 2.0 - rho, vv = rs_M(tt + 0.5 * PI - phi);
+        if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+__device__ bool rs_LRSL(double x, double y, double phi, double& t, double& u, double& v) {  // :326-339
+    double xi = x - sin(phi), eta = y - 1.0 + cos(phi), rho, theta;
+    rs_R(xi, eta, rho, theta);
+    if (rho >= 2.0) {
+        double r = sqrt(rho * rho - 4.0);
+        double uu = 2.0 - r;
+        double tt = rs_M(theta + atan2(r, -2.0));
+        double vv = rs_M(phi - 0.5 * PI - tt);
+        if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
+    }
+    return false;
+}
+__device__ bool rs_LRSLR(double x, double y, double phi, double& t, double& u, double& v) { // :414-429
+    double xi = x + sin(phi), eta = y - 1.0 - cos(phi), rho, theta;
+    rs_R(xi, eta, rho, theta);
+    if (rho >= 2.0) {
+        double uu = 4.0 - sqrt(rho * rho - 4.0);
+        if (uu <= 0.0) {
+            double tt = rs_M(atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
+            double vv = rs_M(tt - phi);
+            if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
+        }
+    }
+    return false;
+}
+
+// candidate c (0..45) of generate_path in call order: group g, variant q
+//   q=0: f(x, y, phi) ; q=1: f(-x, y, -phi), lengths negated ; q=2: f(x, -y, -phi), L<->R ; q=3: both
+__device__ __forceinline__ void cand_decode(int c, int& g, int& q) {
+    if (c < 2) { g = 0; q = c * 2; }              // SCS (:120-130): SLS(x,y,phi), SLS(x,-y,-phi)
+    else { g = 1 + (c - 2) / 4; q = (c - 2) & 3; }
+}
+// groups: 0 SLS | 1 LSL | 2 LSR | 3 LRL | 4 LRL backwards | 5 LRLRn | 6 LRLRp | 7 LRSL | 8 LRSR |
+//         9 LRSL backwards | 10 LRSR backwards | 11 LRSLR
+__device__ __forceinline__ int pack_types(int a, int b, int c, int d, int e, int n) {
+    return a | (b << 2) | (c << 4) | (d << 6) | (e << 8) | (n << 12);
+}
+__device__ __forceinline__ int mirror_type(int t) { return t == TL ? TR : (t == TR ? TL : t); }
+
+struct Word {
+    double len[5];
+    int code;   // packed types + n
+    int n;
+};
+
+__device__ __forceinline__ int type_of(int code, int i) { return (code >> (2 * i)) & 3; }
+
+// interpolate (:510-537) of arc/line parameter l from origin (ox, oy, oyaw) in the local frame
+__device__ __forceinline__ void interpolate(double l, int m, double ox, double oy, double oyaw, double c_noy,
+                                            double s_noy, double c_oy, double s_oy, double& px, double& py,
+                                            double& pyaw) {
+    if (m == TS) {
+        px = ox + l / MAXC * c_oy;
+        py = oy + l / MAXC * s_oy;
+        pyaw = oyaw;
+    } else {
+        double ldx = sin(l) / MAXC;
+        double ldy = (m == TL) ? (1.0 - cos(l)) / MAXC : (1.0 - cos(l)) / (-MAXC);
+        double gdx = c_noy * ldx + s_noy * ldy;          // cos(-oyaw)*ldx + sin(-oyaw)*ldy
+        double gdy = -s_noy * ldx + c_noy * ldy;
+        px = ox + gdx;
+        py = oy + gdy;
+        pyaw = (m == TL) ? oyaw + l : oyaw - l;
+    }
+}
+
+// is_traj_valid for ONE pose held by this lane: returns true if the pose is out of the map box or any
+// hull edge meets any obstacle edge (line-line intersection inside both edge boxes, no tolerance).
+__device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, double wyaw, const double* tile,
+                                          int n_obst, double xmin, double xmax, double ymin, double ymax) {
+    bool bad = false;
+    double vx[4], vy[4];
+    double hminx = 0, hmaxx = 0, hminy = 0, hmaxy = 0;
+    if (active) {
+        if (wx < xmin || wx > xmax || wy < ymin || wy > ymax) bad = true;      // :462-464
+        double st, ct;
+        sincos(wyaw, &st, &ct);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            vx[k] = ct * car_x(k) - st * car_y(k) + wx;                         // :468-471
+            vy[k] = st * car_x(k) + ct * car_y(k) + wy;
+        }
+        hminx = fmin(fmin(vx[0], vx[1]), fmin(vx[2], vx[3]));
+        hmaxx = fmax(fmax(vx[0], vx[1]), fmax(vx[2], vx[3]));
+        hminy = fmin(fmin(vy[0], vy[1]), fmin(vy[2], vy[3]));
+        hmaxy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
+    }
+    for (int r = 0; r < n_obst; r++) {
+        const double* o = tile + 8 * r;
+        double ox0 = o[0], oy0 = o[1], ox1 = o[2], oy1 = o[3], ox2 = o[4], oy2 = o[5], ox3 = o[6], oy3 = o[7];
+        double ominx = fmin(fmin(ox0, ox1), fmin(ox2, ox3)), omaxx = fmax(fmax(ox0, ox1), fmax(ox2, ox3));
+        double ominy = fmin(fmin(oy0, oy1), fmin(oy2, oy3)), omaxy = fmax(fmax(oy0, oy1), fmax(oy2, oy3));
+        bool near = active && !bad && !(ominx > hmaxx || omaxx < hminx || ominy > hmaxy || omaxy < hminy);
+        if (!__any(near)) continue;
+        if (near) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double x1 = o[2 * j], y1 = o[2 * j + 1], x2 = o[2 * ((j + 1) & 3)], y2 = o[2 * ((j + 1) & 3) + 1];
+                double exmin = fmin(x1, x2), exmax = fmax(x1, x2), eymin = fmin(y1, y2), eymax = fmax(y1, y2);
+                if (exmin > hmaxx || exmax < hminx || eymin > hmaxy || eymax < hminy) continue;
+                double d = y2 - y1, e = x1 - x2, f = y1 * x2 - x1 * y2;                           // :504-506
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int k2 = (k + 1) & 3;
+                    double ax1 = vx[k], ay1 = vy[k], ax2 = vx[k2], ay2 = vy[k2];
+                    double vminx = fmin(ax1, ax2), vmaxx = fmax(ax1, ax2), vminy = fmin(ay1, ay2), vmaxy = fmax(ay1, ay2);
+                    // exact necessary condition for the 8 box tests of :518-526
+                    if (vminx > exmax || vmaxx < exmin || vminy > eymax || vmaxy < eymin) continue;
+                    double a = ay2 - ay1, b = ax1 - ax2, c = ay1 * ax2 - ax1 * ay2;               // :477-479
+                    double det = a * e - b * d;
+                    if (det == 0) continue;
+                    double raw_x = (b * f - c * e) / det;
+                    double raw_y = (c * d - a * f) / det;
+                    bool cx = !(raw_x > exmax) && !(raw_x < exmin) && !(raw_x > vmaxx) && !(raw_x < vminx);
+                    bool cy = !(raw_y > eymax) && !(raw_y < eymin) && !(raw_y > vmaxy) && !(raw_y < vminy);
+                    if (cx && cy) bad = true;
+                }
+            }
+        }
+    }
+    return bad;
+}
+
+// LDS (doubles): tile 8*max_obst | Lm[64] | heap pr[64] | ints: heap id[64], order[64]
+constexpr int RS_LM = 0, RS_PR = 64, RS_WORDS = 128;
+
+__global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= *p.rs_count) return;
+    const int scene = p.rs_list[blockIdx.x];
+    double* tile = lds;
+    double* scr = lds + 8 * p.max_obst;
+    int* hid = (int*)(scr + RS_WORDS);
+    int* order = hid + 64;
+
+    const int n_obst = p.n_obst[scene];
+    {
+        const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
+        double2* dst = (double2*)tile;
+        for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
+    }
+    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+    const double* st = p.state + (size_t)scene * ST_WORDS;
+    const double q0x = st[0], q0y = st[1], q0w = st[2];
+    const double gx = sc[SC_DEST], gy = sc[SC_DEST + 1], gw = sc[SC_DEST + 2];
+    const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
+
+    // ---- generate_path (:540-557): normalise the goal into the start frame ------------------------
+    double X, Y, PHI;
+    {
+        double dx = gx - q0x, dy = gy - q0y;
+        PHI = gw - q0w;
+        double c = cos(q0w), s = sin(q0w);
+        X = (c * dx + s * dy) * MAXC;
+        Y = (-s * dx + c * dy) * MAXC;
+    }
+    Word w;
+    w.n = 0; w.code = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) w.len[i] = 0;
+    bool ok = false;
+    if (lane < NCAND) {
+        int g, q;
+        cand_decode(lane, g, q);
+        double bx = X, by = Y;
+        if (g == 4 || g == 9 || g == 10) {               // "backwards" (:206-207, :376-377)
+            bx = X * cos(PHI) + Y * sin(PHI);
+            by = X * sin(PHI) - Y * cos(PHI);
+        }
+        double sx = (q & 1) ? -bx : bx;
+        double sy = (q & 2) ? -by : by;
+        double sp = (q == 1 || q == 2) ? -PHI : PHI;
+        double t = 0, u = 0, v = 0;
+        switch (g) {
+            case 0: ok = rs_SLS(sx, sy, sp, t, u, v); break;
+            case 1: ok = rs_LSL(sx, sy, sp, t, u, v); break;
+            case 2: ok = rs_LSR(sx, sy, sp, t, u, v); break;
+            case 3: case 4: ok = rs_LRL(sx, sy, sp, t, u, v); break;
+            case 5: ok = rs_LRLRn(sx, sy, sp, t, u, v); break;
+            case 6: ok = rs_LRLRp(sx, sy, sp, t, u, v); break;
+            case 7: case 9: ok = rs_LRSL(sx, sy, sp, t, u, v); break;
+            case 8: case 10: ok = rs_LRSR(sx, sy, sp, t, u, v); break;
+            default: ok = rs_LRSLR(sx, sy, sp, t, u, v); break;
+        }
+        const double hp = 0.5 * PI;
+        int t0 = TL, t1 = TS, t2 = TL, t3 = 0, t4 = 0, n = 3;
+        double l0 = t, l1 = u, l2 = v, l3 = 0, l4 = 0;
+        switch (g) {
+            case 0: t0 = TS; t1 = TL; t2 = TS; break;
+            case 1: t0 = TL; t1 = TS; t2 = TL; break;
+            case 2: t0 = TL; t1 = TS; t2 = TR; break;
+            case 3: t0 = TL; t1 = TR; t2 = TL; break;
+            case 4: t0 = TL; t1 = TR; t2 = TL; l0 = v; l2 = t; break;
+            case 5: n = 4; t0 = TL; t1 = TR; t2 = TL; t3 = TR; l2 = -u; l3 = v; break;
+            case 6: n = 4; t0 = TL; t1 = TR; t2 = TL; t3 = TR; l2 = u; l3 = v; break;
+            case 7: n = 4; t0 = TL; t1 = TR; t2 = TS; t3 = TL; l1 = -hp; l2 = u; l3 = v; break;
+            case 8: n = 4; t0 = TL; t1 = TR; t2 = TS; t3 = TR; l1 = -hp; l2 = u; l3 = v; break;
+            case 9: n = 4; t0 = TL; t1 = TS; t2 = TR; t3 = TL; l0 = v; l1 = u; l2 = -hp; l3 = t; break;
+            case 10: n = 4; t0 = TR; t1 = TS; t2 = TR; t3 = TL; l0 = v; l1 = u; l2 = -hp; l3 = t; break;
+            default: n = 5; t0 = TL; t1 = TR; t2 = TS; t3 = TL; t4 = TR; l1 = -hp; l2 = u; l3 = -hp; l4 = v; break;
+        }
+        if (q & 1) { l0 = -l0; l1 = -l1; l2 = -l2; l3 = -l3; l4 = -l4; }
+        if (q & 2) { t0 = mirror_type(t0); t1 = mirror_type(t1); t2 = mirror_type(t2); t3 = mirror_type(t3); t4 = mirror_type(t4); }
+        if (n < 4) { t3 = 0; l3 = 0; }
+        if (n < 5) { t4 = 0; l4 = 0; }
+        w.n = n;
+        w.code = pack_types(t0, t1, t2, t3, t4, n);
+        w.len[0] = l0; w.len[1] = l1; w.len[2] = l2; w.len[3] = l3; w.len[4] = l4;
+    }
+
+    // ---- set_path (:57-76) replayed in call order ---------------------------------------------------
+    unsigned long long okmask = __ballot(ok);
+    unsigned long long kept = 0;
+    double myL = 0;
+    for (int c = 0; c < NCAND; c++) {
+        if (!((okmask >> c) & 1)) continue;
+        int code_c = __shfl(w.code, c);
+        int n_c = __shfl(w.n, c);
+        double lc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) lc[i] = __shfl(w.len[i], c);
+        bool dup = false;
+        if (((kept >> lane) & 1) && w.code == code_c) {
+            double s = 0;
+            for (int i = 0; i < n_c; i++) s = s + (w.len[i] - lc[i]);      // sum([x - y ...]) (:65)
+            dup = s <= 0.01;
+        }
+        if (__any(dup)) continue;
+        double L = 0;
+        for (int i = 0; i < n_c; i++) L = L + fabs(lc[i]);                  // :68
+        if (L >= MAX_LENGTH) continue;                                      // :70
+        kept |= 1ull << c;
+        if (lane == c) myL = L;
+    }
+    const int n_paths = __popcll(kept);
+    if (n_paths == 0) return;                                               // find_rs_path :427-428
+
+    // ---- path.L / maxc (calc_all_paths :52) and heapdict pop order ----------------------------------
+    const double myLm = myL / MAXC;
+    if ((kept >> lane) & 1) scr[RS_LM + lane] = myLm;
+    wsync();
+    if (lane == 0) {
+        double* pr = scr + RS_PR;
+        int hn = 0;
+        for (int c = 0; c < NCAND; c++) {                 // costQueue[path] = path.L in path order (:432-433)
+            if (!((kept >> c) & 1)) continue;
+            int i = hn++;
+            pr[i] = scr[RS_LM + c]; hid[i] = c;
+            while (i) {                                   // _decrease_key: swap unless parent < child
+                int parent = (i - 1) >> 1;
+                if (pr[parent] < pr[i]) break;
+                double tp = pr[i]; pr[i] = pr[parent]; pr[parent] = tp;
+                int ti = hid[i]; hid[i] = hid[parent]; hid[parent] = ti;
+                i = parent;
+            }
+        }
+        int no = 0;
+        while (hn > 0) {                                  // popitem
+            order[no++] = hid[0];
+            if (hn == 1) { hn = 0; break; }
+            hn--;
+            pr[0] = pr[hn]; hid[0] = hid[hn];
+            int i = 0;
+            for (;;) {                                    // _min_heapify
+                int l = (i << 1) + 1, r = (i + 1) << 1, low;
+                if (l < hn && pr[l] < pr[i]) low = l; else low = i;
+                if (r < hn && pr[r] < pr[low]) low = r;
+                if (low == i) break;
+                double tp = pr[i]; pr[i] = pr[low]; pr[low] = tp;
+                int ti = hid[i]; hid[i] = hid[low]; hid[low] = ti;
+                i = low;
+            }
+        }
+    }
+    wsync();
+
+    // ---- find_rs_path main loop (:436-450) --------------------------------------------------------------
+    const double c_q = cos(-q0w), s_q = sin(-q0w);
+    const double step = RS_STEP * MAXC;                   // step_size * maxc (:44)
+    double min_path_len = -1;
+    int found_c = -1;
+    for (int idx = 1; idx <= n_paths; idx++) {
+        const int pc = order[idx - 1];
+        const double Lm = scr[RS_LM + pc];
+        if (min_path_len < 0) min_path_len = Lm;
+        if (Lm > 1.6 * min_path_len && idx > 2) break;
+        const int code = __shfl(w.code, pc);
+        const int nseg = __shfl(w.n, pc);
+        double len[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) len[i] = __shfl(w.len[i], pc);
+
+        // generate_local_course (:452-507) + world transform (:47-49) + is_traj_valid, 64 samples per pass
+        bool invalid = false;
+        double ox = 0, oy = 0, oyaw = 0;                  // local-frame origin of the current segment
+        double d = len[0] > 0.0 ? step : -step;
+        double pd = d, ll = 0.0;
+        double ex = 0, ey = 0, eyaw = 0;                  // end point of the current segment
+        for (int i = 0; i < nseg && !invalid; i++) {
+            const int m = type_of(code, i);
+            const double l = len[i];
+            d = l > 0.0 ? step : -step;
+            if (i >= 1 && (len[i - 1] * len[i]) > 0) pd = -d - ll; else pd = d - ll;
+            double s_oy, c_oy;
+            sincos(oyaw, &s_oy, &c_oy);
+            const double c_noy = cos(-oyaw), s_noy = sin(-oyaw);
+            for (;;) {
+                // `pd += d` chain: every lane walks it, lane j keeps the value after j additions
+                double mine = pd, t = pd;
+                for (int j = 0; j < WAVE; j++) {
+                    if (lane == j) mine = t;
+                    t = t + d;
+                }
+                const bool in_seg = fabs(mine) <= fabs(l);
+                unsigned long long mk = __ballot(in_seg);
+                const int count = (~mk == 0ull) ? WAVE : (__ffsll((long long)~mk) - 1);
+                const bool active = lane < count;
+                double px = 0, py = 0, pyaw = 0;
+                if (active) interpolate(mine, m, ox, oy, oyaw, c_noy, s_noy, c_oy, s_oy, px, py, pyaw);
+                double wx = c_q * px + s_q * py + q0x;
+                double wy = -s_q * px + c_q * py + q0y;
+                double wyaw = pi_2_pi(pyaw + q0w);
+                bool bad = pose_hits(active, wx, wy, wyaw, tile, n_obst, xmin, xmax, ymin, ymax);
+                if (__any(bad)) { invalid = true; break; }
+                if (count < WAVE) { pd = __shfl(mine, count); break; }
+                pd = t;
+            }
+            if (invalid) break;
+            ll = l - pd - d;                              // "calc remain length" (:494)
+            interpolate(l, m, ox, oy, oyaw, c_noy, s_noy, c_oy, s_oy, ex, ey, eyaw);
+            ox = ex; oy = ey; oyaw = eyaw;
+        }
+        if (!invalid) {
+            // the start pose (index 0, local (0,0,0)) and the final end point (the only segment end
+            // that is not overwritten by the next segment's first sample)
+            double px = lane == 0 ? 0.0 : ex, py = lane == 0 ? 0.0 : ey, pyaw = lane == 0 ? 0.0 : eyaw;
+            double wx = c_q * px + s_q * py + q0x;
+            double wy = -s_q * px + c_q * py + q0y;
+            double wyaw = pi_2_pi(pyaw + q0w);
+            bool bad = pose_hits(lane < 2, wx, wy, wyaw, tile, n_obst, xmin, xmax, ymin, ymax);
+            if (__any(bad)) invalid = true;
+        }
+        if (!invalid) { found_c = pc; break; }
+    }
+    if (found_c < 0) return;
+
+    // ---- output: PATH.ctypes / PATH.lengths (metres) of the first collision-free path ----------------
+    const int code = __shfl(w.code, found_c);
+    const int nseg = __shfl(w.n, found_c);
+    double lenv = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { double v = __shfl(w.len[i], found_c); if (lane == i) lenv = v; }
+    if (lane < 5) {
+        double lm = lane < nseg ? lenv / MAXC : 0.0;      // path.lengths = [l / maxc ...] (:51)
+        if (p.rs_lengths) {
+            if (obs_f64) ((double*)p.rs_lengths)[5 * (size_t)scene + lane] = lm;
+            else ((float*)p.rs_lengths)[5 * (size_t)scene + lane] = (float)lm;
+        }
+        p.rs_word[8 * (size_t)scene + lane] = lane < nseg ? (int8_t)type_of(code, lane) : (int8_t)HOPE_RS_NONE;
+    }
+    if (lane == 5) p.rs_word[8 * (size_t)scene + 5] = (int8_t)nseg;
+    if (lane == 6) p.rs_word[8 * (size_t)scene + 6] = 1;
+}
+
+}  // namespace
+
+size_t rs_lds_bytes(int max_obst) { return (size_t)(8 * max_obst + RS_WORDS) * 8 + 128 * 4; }
+
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream) {
+    size_t lds = rs_lds_bytes(p.max_obst);
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_rs_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_rs_search, dim3(p.n), dim3(WAVE), lds, stream, p, p.obs_f64);
+    return hipGetLastError();
+}
+
 }  // namespace hope

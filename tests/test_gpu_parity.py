@@ -101,6 +101,56 @@ def test_step_parity_f64_dlp():
     env.close()
 
 
+def test_step_parity_with_rs_search():
+    """BASELINE config 3 shape (full step incl. Reeds-Shepp feasibility search), flags + words exact."""
+    env, orc, rng = make_pair(512, seed=21)
+    s = rollout(env, orc, rng, steps=12, tol=TOL64, with_rs=True)
+    print('parity f64 + RS:', s)
+    assert s['status_mismatch'] == 0 and s['mask_mismatch'] == 0
+    assert s['rs_flag_mismatch'] == 0 and s['rs_word_mismatch'] == 0 and s['rs_len_err'] < TOL64
+    assert s['pose_err'] < TOL64 and s['lidar_err'] < TOL64
+    torch.cuda.synchronize()
+    env.close()
+
+
+def test_rs_search_finds_paths_near_goal():
+    """scenes started on the slot axis a few metres out: a feasible RS path must be found for some, and the
+    (flag, word, lengths) must match the oracle exactly / to 1e-9."""
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import DlpScenePool, pack_scenes
+    from oracle import oracle as O
+    n, mo = 256, 128
+    pool = DlpScenePool()
+    rng = np.random.default_rng(5)
+    scenes = []
+    for k in range(n):
+        s = pool.sample(rng=rng)
+        fwd = rng.uniform(3.0, 9.0) * rng.choice([-1, 1])
+        s.start = np.array([s.dest[0] + fwd * np.cos(s.dest[2]) + rng.normal() * 0.2,
+                            s.dest[1] + fwd * np.sin(s.dest[2]) + rng.normal() * 0.2, s.dest[2] + rng.normal() * 0.1])
+        scenes.append(s)
+    env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
+    env.set_scenes(np.arange(n), scenes)
+    orc = O.BatchOracle(n, mo)
+    start, dest, bbox, verts, nob, nvert = pack_scenes(scenes, mo)
+    orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+    t = env.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    env.reset_obs()
+    orc.reset_obs()                      # t = 1: the RS gate needs t > 1
+    act = np.zeros((n, 2))
+    env.step(torch.from_numpy(act).to(env.device))
+    o = orc.step(act)
+    torch.cuda.synchronize()
+    w = env.rs_word.cpu().numpy()
+    assert np.array_equal(w[:, 6], o['rs_found'])
+    assert np.array_equal(w[:, :5], o['rs_ctypes'])
+    assert np.abs(env.rs_lengths.cpu().numpy() - o['rs_lengths']).max() < TOL64
+    print('rs found', int(o['rs_found'].sum()), 'of', n)
+    assert o['rs_found'].sum() >= 10
+    env.close()
+
+
 def test_step_parity_f32_outputs():
     env, orc, rng = make_pair(256, seed=12, obs64=False)
     s = rollout(env, orc, rng, steps=10, tol=TOL32)
