@@ -8,6 +8,7 @@ from .build import lib_path
 LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10, 5, 5
 F_OBS_F64, F_ACTION_F64, F_PROFILE = 0x1, 0x2, 0x4
 STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
+ACTION_PHYSICAL = 0x10
 ABI_VERSION = 1
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',

@@ -202,8 +202,11 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
         // ---- action_rescale (env_wrapper.py:37-50) + KSModel clip (vehicle.py:85-86) -------------
         const AT* act = (const AT*)p.actions;
         double a0 = (double)act[2 * (size_t)scene], a1 = (double)act[2 * (size_t)scene + 1];
-        double steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
-        double speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
+        double steer = a0, speed = a1;
+        if (!(p.stages & HOPE_ACTION_PHYSICAL)) {
+            steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
+            speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
+        }
         speed = clipd(speed, SPEED_LO, SPEED_HI);
         steer = clipd(steer, STEER_LO, STEER_HI);
         const double dh = speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;

@@ -118,3 +118,215 @@ def pack_scenes(scenes, max_obst):
         nvert[k, :s.n_obst] = s.nvert
         nob[k] = s.n_obst
     return start, dest, bbox, verts, nob, nvert
+
+
+# =================================================================================================
+# Normal / Complex / Extrem scene generator (host side)
+#
+# Produces scenes from the same distribution as the reference's rejection samplers
+# `generate_bay_parking_case` / `generate_parallel_parking_case` (src/env/parking_map_normal.py:40-457)
+# and `ParkingMapNormal.reset` (:474-494).  The reference delegates `distance` / `intersects` to
+# shapely; here they are small numpy routines.  A numpy Generator replaces the global RNG.
+# =================================================================================================
+LENGTH = T.WHEEL_BASE + T.FRONT_HANG + T.REAR_HANG
+# configs.py:43-70
+_MIN_LOT_LEN = {'Extrem': LENGTH + 0.6, 'Complex': LENGTH + 0.9, 'Normal': LENGTH * 1.25}
+_MAX_LOT_LEN = {'Extrem': LENGTH + 0.9, 'Complex': LENGTH * 1.25, 'Normal': LENGTH * 1.25 + 0.5}
+_MIN_LOT_WID = {'Complex': T.WIDTH + 0.4, 'Normal': T.WIDTH + 0.85}
+_MAX_LOT_WID = {'Complex': T.WIDTH + 0.85, 'Normal': T.WIDTH + 1.2}
+_PARA_WALL = {'Extrem': 3.5, 'Complex': 4.0, 'Normal': 4.5}
+_BAY_WALL = {'Complex': 6.0, 'Normal': 7.0}
+_N_OBST = {'Extrem': 8, 'Complex': 5, 'Normal': 3}
+_GAP = 0.1                     # MIN_DIST_TO_OBST
+_P_WALL, _N_EXTRA, _P_EXTRA = 0.5, 3, 0.7     # parking_map_normal.py:20-22
+
+
+def _segs(ring):
+    r = np.asarray(ring, dtype=np.float64)
+    return r, np.roll(r, -1, axis=0)
+
+
+def _cross(ax, ay, bx, by):
+    return ax * by - ay * bx
+
+
+def rings_intersect(a, b):
+    """LinearRing.intersects(LinearRing): any boundary segment pair shares a point."""
+    p1, p2 = _segs(a)
+    q1, q2 = _segs(b)
+    P1, P2 = p1[:, None, :], p2[:, None, :]
+    Q1, Q2 = q1[None, :, :], q2[None, :, :]
+    d1 = _cross(P2[..., 0] - P1[..., 0], P2[..., 1] - P1[..., 1], Q1[..., 0] - P1[..., 0], Q1[..., 1] - P1[..., 1])
+    d2 = _cross(P2[..., 0] - P1[..., 0], P2[..., 1] - P1[..., 1], Q2[..., 0] - P1[..., 0], Q2[..., 1] - P1[..., 1])
+    d3 = _cross(Q2[..., 0] - Q1[..., 0], Q2[..., 1] - Q1[..., 1], P1[..., 0] - Q1[..., 0], P1[..., 1] - Q1[..., 1])
+    d4 = _cross(Q2[..., 0] - Q1[..., 0], Q2[..., 1] - Q1[..., 1], P2[..., 0] - Q1[..., 0], P2[..., 1] - Q1[..., 1])
+    box = (np.minimum(P1, P2) <= np.maximum(Q1, Q2)).all(-1) & (np.minimum(Q1, Q2) <= np.maximum(P1, P2)).all(-1)
+    opp = (np.sign(d1) * np.sign(d2) <= 0) & (np.sign(d3) * np.sign(d4) <= 0)
+    return bool((box & opp).any())
+
+
+def _pt_seg(p, a, b):
+    ab = b - a
+    den = (ab * ab).sum(-1)
+    t = np.where(den > 0, ((p - a) * ab).sum(-1) / np.where(den > 0, den, 1), 0.0)
+    t = np.clip(t, 0, 1)
+    c = a + t[..., None] * ab
+    return np.sqrt(((p - c) ** 2).sum(-1))
+
+
+def rings_distance(a, b):
+    """LinearRing.distance(LinearRing): 0 when they meet, else the closest vertex-to-edge gap."""
+    if rings_intersect(a, b):
+        return 0.0
+    p1, p2 = _segs(a)
+    q1, q2 = _segs(b)
+    d_ab = _pt_seg(p1[:, None, :], q1[None], q2[None]).min()
+    d_ba = _pt_seg(q1[:, None, :], p1[None], p2[None]).min()
+    return float(min(d_ab, d_ba))
+
+
+def _clipn(rng, mean, std, lo, hi):
+    return float(np.clip(rng.standard_normal() * std + mean, lo, hi))
+
+
+def _uni(rng, lo, hi):
+    return float(rng.random() * (hi - lo) + lo)
+
+
+def _polar(rng, origin, a0, a1, r0, r1):
+    ang = _clipn(rng, (a0 + a1) / 2, (a1 - a0) / 4, a0, a1)
+    rad = _clipn(rng, (r0 + r1) / 2, (r1 - r0) / 4, r0, r1)
+    return (origin[0] + math.cos(ang) * rad, origin[1] + math.sin(ang) * rad)
+
+
+def _case(level, bay, rng):
+    """one rejection-sampling attempt; returns (start, dest, rings) or None."""
+    half = 15.0 if bay else 18.0
+    if bay:
+        space_hi, space_lo = _MAX_LOT_WID[level] - T.WIDTH, _MIN_LOT_WID[level] - T.WIDTH
+        wall, yaw0, pitch = _BAY_WALL[level], math.pi / 2, T.WIDTH
+        yaw_lo, yaw_hi = math.pi * 5 / 12, math.pi * 7 / 12
+        low_pair = (0, 3)                    # rear-right, rear-left corners touch the back wall
+        n_extra = _N_EXTRA
+    else:
+        space_hi, space_lo = _MAX_LOT_LEN[level] - LENGTH, _MIN_LOT_LEN[level] - LENGTH
+        wall, yaw0, pitch = _PARA_WALL[level], 0.0, LENGTH
+        yaw_lo, yaw_hi = -math.pi / 12, math.pi / 12
+        low_pair = (0, 1)                    # rear-right, front-right
+        n_extra = _N_EXTRA - 1
+    back = np.array([(half, 0.0), (half, -1.0), (-half, -1.0), (-half, 0.0)])
+
+    def slot_pose(x):
+        yaw = _clipn(rng, yaw0, math.pi / 36, yaw_lo, yaw_hi)
+        b = create_box((x, 0.0, yaw))
+        y_min = -min(b[low_pair[0], 1], b[low_pair[1], 1]) + _GAP
+        y = _clipn(rng, y_min + 0.4, 0.2, y_min, y_min + 0.8)
+        return np.array([x, y, yaw])
+
+    dest = slot_pose(0.0)
+    rb, rf, lf, lb = create_box(dest)
+    dest_ring = np.array([rb, rf, lf, lb])
+    ok = True
+    extras = []
+
+    def side(sign, near_a, near_b, d_lo, d_hi):
+        """obstacle next to the slot on side `sign` (-1 left, +1 right): a wall-like quad or a parked car
+        followed by further parked cars (kept with probability .7)."""
+        if rng.random() < _P_WALL:
+            a0, a1 = (math.pi * 11 / 12, math.pi * 13 / 12) if sign < 0 else (-math.pi / 12, math.pi / 12)
+            pa = _polar(rng, near_a, a0, a1, d_lo, d_hi)
+            pb = _polar(rng, near_b, a0, a1, d_lo, d_hi)
+            if sign < 0:
+                return np.array([pa, pb, (-half, 0.0), (-half, pa[1])])
+            return np.array([(half, pa[1]), (half, 0.0), pb, pa])
+        x = sign * (pitch + _uni(rng, d_lo, d_hi))
+        pose = slot_pose(x)
+        first = create_box(pose)
+        for _ in range(n_extra):
+            x += sign * (pitch + _GAP + _uni(rng, d_lo, d_hi))
+            y = pose[1] + _clipn(rng, 0, 0.05, -0.1, 0.1)
+            pose = np.array([x, y, _clipn(rng, yaw0, math.pi / 36, yaw_lo, yaw_hi)])
+            ring = create_box(pose)
+            if rng.random() < _P_EXTRA:
+                extras.append(ring)
+        return first
+
+    if bay:
+        left = side(-1, lf, lb, space_hi / 5 * 1, space_hi / 5 * 4)
+    else:
+        left = side(-1, lb, rb, space_lo / 5 * 1, space_hi / 5 * 4)
+    gap_l = rings_distance(dest_ring, left)
+    d_lo = max(space_lo - gap_l, 0) + _GAP
+    d_hi = max(space_hi - gap_l, 0) + _GAP
+    right = side(+1, rf, rb, d_lo, d_hi) if bay else side(+1, lf, rf, d_lo, d_hi)
+    gap_r = rings_distance(dest_ring, right)
+    if gap_r + gap_l < space_lo or gap_r + gap_l > space_hi or gap_l < _GAP or gap_r < _GAP:
+        ok = False
+    rings = [back, left, right] + extras
+    if any(rings_intersect(r, dest_ring) for r in rings):
+        ok = False
+
+    top = max(float(np.max(r[:, 1])) for r in rings) + _GAP
+    far = []
+    if rng.random() < 0.2:                                   # only a thin wall across the aisle
+        y0 = wall + top + _GAP
+        far = [np.array([(-half, y0), (half, y0), (half, y0 + 0.1), (-half, y0 + 0.1)])]
+    else:
+        zone = np.array([(-half, wall + top), (half, wall + top), (half, wall + top + 8), (-half, wall + top + 8)])
+        for _ in range(_N_OBST[level]):
+            pose = (_uni(rng, -half + 2, half - 2), _uni(rng, wall + top + 2, wall + top + 6), rng.random() * math.pi * 2)
+            ring = create_box(pose) + 0.5 * rng.random((4, 2))
+            if rings_intersect(ring, zone) or any(rings_intersect(ring, o) for o in far):
+                continue
+            far.append(ring)
+    rings = rings + far
+
+    while True:                                              # start pose in the aisle, clear of everything
+        sx = _uni(rng, -half / 2, half / 2)
+        sy = _uni(rng, top + 1, wall + top - 1)
+        syaw = _clipn(rng, 0, math.pi / 6, -math.pi / 2, math.pi / 2)
+        if rng.random() < 0.5:
+            syaw += math.pi
+        sbox = create_box((sx, sy, syaw))
+        if not any(rings_intersect(r, sbox) for r in rings) and not rings_intersect(dest_ring, sbox):
+            break
+    start = np.array([sx, sy, syaw])
+    if not bay and math.cos(syaw) < 0:                       # parallel: face the slot the way the car arrives
+        dest = flip_orientation(dest)
+    if not ok:
+        return None
+    return start, dest, rings
+
+
+def generate_scene(level, rng=None, case_id=None):
+    """ParkingMapNormal.reset (parking_map_normal.py:474-494): bay or parallel case, bbox = +-10 m."""
+    rng = np.random.default_rng() if rng is None else rng
+    if level not in ('Normal', 'Complex', 'Extrem'):
+        raise ValueError(level)
+    bay = (case_id == 0 or (rng.random() > 0.5 and case_id != 1)) and level in ('Normal', 'Complex')
+    while True:
+        got = _case(level, bay, rng)
+        if got is not None:
+            break
+    start, dest, rings = got
+    bbox = np.array([np.floor(min(start[0], dest[0]) - 10), np.ceil(max(start[0], dest[0]) + 10),
+                     np.floor(min(start[1], dest[1]) - 10), np.ceil(max(start[1], dest[1]) + 10)])
+    verts = np.stack(rings)
+    return Scene(start=start, dest=dest, bbox=bbox, verts=verts, nvert=np.full(len(rings), 4, np.int32), level=level,
+                 case_id=0 if bay else 1)
+
+
+class SceneSource:
+    """uniform mix over difficulty levels, as the reference's SceneChoose does before its curriculum kicks
+    in (src/train/train_HOPE_sac.py:23-29)."""
+
+    def __init__(self, levels=('Normal', 'Complex', 'Extrem', 'dlp'), seed=42, dlp_path=DEFAULT_DLP):
+        self.levels = tuple(levels)
+        self.rng = np.random.default_rng(seed)
+        self.pool = DlpScenePool(dlp_path) if 'dlp' in self.levels else None
+
+    def draw(self, level=None):
+        level = self.levels[int(self.rng.integers(len(self.levels)))] if level is None else level
+        if level == 'dlp':
+            return self.pool.sample(rng=self.rng)
+        return generate_scene(level, self.rng)

@@ -73,6 +73,10 @@ extern "C" {
 #define HOPE_STAGE_REWARD 0x4   /* status + reward (:279-289) + wrapper reward_shaping                     */
 #define HOPE_STAGE_RS 0x8       /* Reeds-Shepp feasibility search (:293-297, find_rs_path :413)           */
 #define HOPE_STAGE_ALL 0xF
+/* modifier bit: actions are already physical (steer [rad], speed [m/s]) as CarParking.step receives them
+ * (car_parking_base.py:235); without it they are the wrapper's [-1,1] actions and action_rescale
+ * (env_wrapper.py:37-50) is applied first.  KSModel's own clip (vehicle.py:85-86) always applies. */
+#define HOPE_ACTION_PHYSICAL 0x10
 
 typedef struct hope_env hope_env_t;
 
