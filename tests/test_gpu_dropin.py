@@ -1,0 +1,163 @@
+"""-m gpu: the N = 1 drop-in surface (hope_amd.env.CarParking / CarParkingWrapper) and every Status."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def test_config1_trace_2000_steps():
+    """BASELINE configs[0]: one DLP scene, 2000 wrapper steps with the recorded actions; every step's
+    status / mask (exact), pose (1e-9), lidar (float32 fixture), reward, RS result against the trace."""
+    from hope_amd.env import CarParking, CarParkingWrapper, Status
+    from hope_amd.scenes import Scene
+    g = np.load(os.path.join(GOLD, 'trace_config1.npz'))
+    scene = Scene(start=g['start'], dest=g['dest'], bbox=g['bbox'], verts=g['verts'], nvert=g['nvert'], level='dlp', case_id=0)
+    raw = CarParking(render_mode='rgb_array', fps=100, verbose=False)
+    env = CarParkingWrapper(raw)
+    assert env.observation_shape == {'action_mask': (42,), 'lidar': (120,), 'target': (5,)}
+    assert env.action_space.shape[0] == 2 and env.vehicle.kinetic_model.step_len == 0.05
+    obs = raw.reset_to_scene(scene)
+    assert list(obs.keys()) == ['img', 'lidar', 'target', 'action_mask'] and obs['img'] is None
+    assert np.abs(obs['lidar'] - g['first_lidar']).max() < 1e-9 and np.array_equal(obs['action_mask'], g['first_mask'])
+    bad = dict(status=0, mask=0, rs=0)
+    err = dict(pose=0.0, lidar=0.0, reward=0.0, rslen=0.0, target=0.0)
+    for i in range(len(g['action'])):
+        obs, reward, done, info = env.step(g['action'][i])
+        bad['status'] += int(info['status'].value != int(g['status'][i]))
+        bad['mask'] += int(not np.array_equal(np.round(obs['action_mask'] * 100).astype(np.uint8), g['mask'][i]))
+        pose = np.array(env.vehicle.state.get_pos())
+        err['pose'] = max(err['pose'], np.abs(pose - g['pose'][i]).max())
+        err['lidar'] = max(err['lidar'], np.abs(obs['lidar'].astype(np.float32) - g['lidar'][i]).max())
+        err['target'] = max(err['target'], np.abs(obs['target'] - g['target'][i]).max())
+        err['reward'] = max(err['reward'], abs(reward - g['reward'][i]))
+        p = info['path_to_dest']
+        if (p is not None) != bool(g['rs_found'][i]):
+            bad['rs'] += 1
+        elif p is not None:
+            want = ['SLR'[c] for c in g['rs_ctypes'][i] if c >= 0]
+            bad['rs'] += int(p.ctypes != want)
+            err['rslen'] = max(err['rslen'], np.abs(np.array(p.lengths) - g['rs_lengths'][i][:len(want)]).max())
+        assert done == bool(g['reset'][i])
+        if done:
+            raw.reset_to_scene(scene)
+    print('config1 trace:', bad, err)
+    assert bad == dict(status=0, mask=0, rs=0)
+    assert err['pose'] < 1e-9 and err['lidar'] < 1e-5 and err['reward'] < 1e-9 and err['rslen'] < 1e-9 and err['target'] < 1e-9
+    assert isinstance(info['status'], Status)
+    env.close()
+
+
+def _pair(scene, mo=32):
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import pack_scenes
+    from oracle import oracle as O
+    env = ParkingBatch(1, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
+    env.set_scenes([0], [scene])
+    orc = O.BatchOracle(1, mo)
+    start, dest, bbox, verts, nob, nvert = pack_scenes([scene], mo)
+    orc.set_scenes([0], start, dest, bbox, verts, nvert, nob)
+    t = env.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    return env, orc
+
+
+def _same(env, o):
+    torch.cuda.synchronize()
+    assert int(env.status[0]) == int(o['status'][0])
+    assert np.array_equal(env.action_mask[0].cpu().numpy(), o['mask'][0])
+    assert np.abs(env.lidar[0].cpu().numpy() - o['lidar'][0]).max() < 1e-9
+    assert abs(float(env.reward[0]) - o['reward'][0]) < 1e-9
+    assert np.abs(env.reward_info[0].cpu().numpy() - o['reward_info'][0]).max() < 1e-9
+
+
+def test_every_status_is_reachable_and_matches():
+    from hope_amd.scenes import Scene, create_box
+    wall = np.array([[(6.0, -3.0), (6.3, -3.0), (6.3, 3.0), (6.0, 3.0)]])
+    tri = np.array([[(-8.0, 6.0), (-7.0, 6.5), (-7.5, 7.5), (-7.5, 7.5)]])
+    verts = np.concatenate([wall, tri])
+    nvert = np.array([4, 3], np.int32)
+
+    def mk(start, dest, bbox=(-12., 12., -12., 12.)):
+        return Scene(start=np.array(start, float), dest=np.array(dest, float), bbox=np.array(bbox), verts=verts, nvert=nvert)
+    seen = set()
+    # ARRIVED: roll straight onto a slot 1 m ahead
+    env, orc = _pair(mk((0, 0, 0), (1.0, 0.0, 0.0)))
+    env.reset_obs(); _same(env, orc.reset_obs())
+    for _ in range(3):
+        a = np.array([[0.0, 0.4]])
+        env.step(torch.from_numpy(a).to(env.device)); o = orc.step(a); _same(env, o)
+        seen.add(int(o['status'][0]))
+        if o['status'][0] != 1:
+            break
+    assert 2 in seen
+    env.close()
+    # collision sub-step retreat against the wall, then COLLIDED from a start pose inside the wall line
+    env, orc = _pair(mk((1.5, 0, 0), (-6.0, -6.0, 1.0)))
+    env.reset_obs(); _same(env, orc.reset_obs())
+    for _ in range(4):
+        a = np.array([[0.0, 1.0]])
+        env.step(torch.from_numpy(a).to(env.device)); o = orc.step(a); _same(env, o)
+    assert orc.pose[0, 0] < 6.0 - 3.76 + 1e-6 and o['substeps'][0] < 10       # stopped short of the wall
+    env.close()
+    env, orc = _pair(mk((3.0, 0, 0), (-6.0, -6.0, 1.0)))                       # hull crosses the wall at reset
+    env.reset_obs(); o = orc.reset_obs(); _same(env, o)
+    assert o['status'][0] == 3
+    seen.add(3)
+    env.close()
+    # OUTBOUND: reverse out of a tight map box
+    env, orc = _pair(mk((0, 0, 0), (4.0, 8.0, 1.0), bbox=(-2., 12., -12., 12.)))
+    env.reset_obs(); orc.reset_obs()
+    for _ in range(4):
+        a = np.array([[0.0, -1.0]])
+        env.step(torch.from_numpy(a).to(env.device)); o = orc.step(a); _same(env, o)
+        seen.add(int(o['status'][0]))
+    assert 4 in seen
+    env.close()
+    # OUTTIME: t > 200 (reset makes t = 1)
+    env, orc = _pair(mk((0, 0, 0), (-6.0, 6.0, 1.0)))
+    env.reset_obs(); orc.reset_obs()
+    a = np.zeros((1, 2))
+    at = torch.from_numpy(a).to(env.device)
+    for i in range(201):
+        env.step(at); o = orc.step(a)
+        if i in (0, 198, 199, 200):
+            _same(env, o)
+        seen.add(int(o['status'][0]))
+    assert o['status'][0] == 5 and orc.t[0] == 202
+    env.close()
+    assert seen >= {1, 2, 3, 4, 5}
+
+
+def test_empty_and_full_tiles():
+    """ragged inputs: a scene with no obstacle at all and one with max_obstacles obstacles."""
+    from hope_amd.scenes import Scene
+    empty = Scene(start=np.array([0., 0, 0]), dest=np.array([5., 3, 1.0]), bbox=np.array([-10., 15, -10, 13]),
+                  verts=np.zeros((0, 4, 2)), nvert=np.zeros(0, np.int32))
+    env, orc = _pair(empty)
+    env.reset_obs(); _same(env, orc.reset_obs())
+    a = np.array([[0.3, 0.8]])
+    for _ in range(3):
+        env.step(torch.from_numpy(a).to(env.device)); o = orc.step(a); _same(env, o)
+    torch.cuda.synchronize()
+    assert (env.lidar[0].cpu().numpy() + env.tables['hull_base'] == 10.0).all() and int(env.rs_word[0, 6]) == 1
+    assert int(o['rs_found'][0]) == 1
+    env.close()
+    rng = np.random.default_rng(4)
+    n = 32
+    v = np.zeros((n, 4, 2))
+    for k in range(n):
+        c = np.array([rng.uniform(-9, 9), rng.uniform(3.5, 9)])
+        v[k] = c + np.array([(-.4, -.4), (.4, -.4), (.4, .4), (-.4, .4)]) @ np.array([[np.cos(k), -np.sin(k)], [np.sin(k), np.cos(k)]])
+    full = Scene(start=np.array([0., 0, 0]), dest=np.array([5., -3, 1.0]), bbox=np.array([-10., 15, -13, 10]), verts=v,
+                 nvert=np.full(n, 4, np.int32))
+    env, orc = _pair(full, mo=32)
+    env.reset_obs(); _same(env, orc.reset_obs())
+    for _ in range(4):
+        a = rng.uniform(-1, 1, (1, 2))
+        env.step(torch.from_numpy(a).to(env.device)); _same(env, orc.step(a))
+    env.close()
