@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--max-obst', type=int, default=128)
     ap.add_argument('--mix', default='mixed', choices=['mixed', 'dlp', 'normal'])
     ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
-    ap.add_argument('--unique', type=int, default=8192, help='distinct generated scenes (tiled to --scenes)')
+    ap.add_argument('--unique', type=int, default=2048, help='distinct generated scenes (tiled to --scenes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scenes', type=int, default=192)
     ap.add_argument('--cpu-steps', type=int, default=12)
@@ -194,12 +194,15 @@ def cpu_baseline(args, uniq, stages):
     acts = [rng.uniform(-1, 1, (n, 2)) for _ in range(args.cpu_steps)]
     res = {}
     for omp in (False, True):
-        orc = O.BatchOracle(n, args.max_obst, omp=omp)
-        orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+        rep = 8 if omp else 1                        # the all-core run gets 8x the scenes to keep threads busy
+        nn = n * rep
+        orc = O.BatchOracle(nn, args.max_obst, omp=omp)
+        tl = lambda x: np.concatenate([x] * rep, axis=0)  # noqa: E731
+        orc.set_scenes(np.arange(nn), tl(start), tl(dest), tl(bbox), tl(verts), tl(nvert), tl(nob))
         orc.reset_obs(with_rs=with_rs)
         t0 = time.perf_counter()
         for a in acts:
-            o = orc.step(a, with_rs=with_rs)
+            o = orc.step(tl(a), with_rs=with_rs)
             done = o['status'] != 1
             if done.any():
                 ids = np.nonzero(done)[0]
@@ -207,7 +210,7 @@ def cpu_baseline(args, uniq, stages):
                 orc.t[ids] = 0
                 orc.accum[ids] = 0
         dt = time.perf_counter() - t0
-        res[omp] = n * args.cpu_steps / dt
+        res[omp] = nn * args.cpu_steps / dt
     cores = os.cpu_count() or 1
     return {'value': res[False], 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
             'sample': f'first {n} scenes of the bench scene set x {args.cpu_steps} steps, same stages/actions, '

@@ -40,6 +40,7 @@ enum SceneWord {
     SC_DBOX = 10,     // dest box, 4 x (x, y)
     SC_DAREA = 18,    // |dest box|
     SC_DNORM = 19,    // max(|dest - start|, 10)
+    SC_DCEN = 20,     // dest box centre x, y and cos / sin of the dest heading
     SC_WORDS = 24
 };
 // per-scene episode state (float64 words): x, y, heading, accum_arrive_reward

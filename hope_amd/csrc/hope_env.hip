@@ -102,7 +102,10 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
     c[SC_DAREA] = fabs(sum / 2.0);
     double dx = dest[3 * k] - start[3 * k], dy = dest[3 * k + 1] - start[3 * k + 1];
     c[SC_DNORM] = fmax(sqrt(dx * dx + dy * dy), 10.0);            // car_parking_base.py:211
-    for (int i = SC_DNORM + 1; i < SC_WORDS; i++) c[i] = 0.0;
+    c[SC_DCEN] = 0.5 * (b.x[0] + b.x[2]);
+    c[SC_DCEN + 1] = 0.5 * (b.y[0] + b.y[2]);
+    c[SC_DCEN + 2] = ct;
+    c[SC_DCEN + 3] = sn;
     double* st = state + (size_t)s * ST_WORDS;
     st[0] = start[3 * k]; st[1] = start[3 * k + 1]; st[2] = start[3 * k + 2]; st[3] = 0.0;
     tstep[s] = 0;

@@ -39,9 +39,10 @@ struct StepParams {
     int32_t* rs_list;         // [n]
 };
 
-// LDS per wave (doubles): tile 8*max_obst | tx[200] ty[200] | hb[10] cb[10] sb[10] | sh[64] | x[121]+pad | dest box[8] | keep ints
-constexpr int LDS_TX = 0, LDS_TY = 200, LDS_HB = 400, LDS_CB = 410, LDS_SB = 420, LDS_SH = 432, LDS_X = 496,
-              LDS_DBOX = 624, LDS_KEEP = 632, LDS_SCRATCH_WORDS = 632;
+// LDS per wave (doubles): tile 8*max_obst | tx[200] ty[200] (the heading chain hs[201] aliases ty.. first) |
+//   hb[10] cb[10] sb[10] px[10] py[10] | sh[64] | x[121]+pad | dest box[8] | w2[10] | ints: near / keep list
+constexpr int LDS_TX = 0, LDS_TY = 200, LDS_HB = 402, LDS_CB = 412, LDS_SB = 422, LDS_PX = 432, LDS_PY = 442,
+              LDS_SH = 452, LDS_X = 516, LDS_DBOX = 640, LDS_W2 = 648, LDS_KEEP = 658, LDS_SCRATCH_WORDS = 658;
 __host__ __device__ inline size_t step_lds_bytes(int max_obst) {
     return (size_t)(8 * max_obst + LDS_SCRATCH_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4;
 }
@@ -107,8 +108,48 @@ __device__ __forceinline__ double overlap_area(const Box& box, const double* dbo
     return __shfl(area, 0);
 }
 
+// Exact necessary condition for |hull ∩ dest| / |dest| > 0.95 (car_parking_base.py:164-170) that avoids the
+// polygon clip: hull ∩ dest lies inside the hull AND inside the slab spanned by dest's projection on each hull
+// axis, so area <= width x (overlap length along the long axis) and <= length x (overlap along the short axis).
+// If either overlap is below 94 % of the hull extent the ratio is < 0.95 whatever the rounding.
+__device__ __forceinline__ bool arrival_possible(double x, double y, double ct, double sn, double dcx, double dcy,
+                                                 double cd, double sd) {
+    const double mid = 0.5 * (CAR_XF + CAR_XR), hl = 0.5 * (CAR_XF - CAR_XR), hw = CAR_YH;
+    double dx = dcx - (x + ct * mid), dy = dcy - (y + sn * mid);
+    double cphi = fabs(ct * cd + sn * sd), sphi = fabs(ct * sd - sn * cd);
+    double p = dx * ct + dy * sn, q = dy * ct - dx * sn;
+    double hB = hl * cphi + hw * sphi, wB = hl * sphi + hw * cphi;
+    double lov = fmin(hl, p + hB) - fmax(-hl, p - hB);
+    double wov = fmin(hw, q + wB) - fmax(-hw, q - wB);
+    return lov >= 0.94 * 2 * hl && wov >= 0.94 * 2 * hw;
+}
+
+// Obstacles that can touch the hull during this step: the hull stays inside the disc of radius `reach`
+// about the step's start position (rear axle travels <= 1.25 m, hull radius about the axle 3.883 m).
+// Compacts their indices into list[]; exact (bounding boxes only, never drops a candidate).
+__device__ __forceinline__ int build_near_list(const double* tile, int n_obst, double x0, double y0, double reach,
+                                               int* list, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < n_obst; base += WAVE) {
+        int o = base + lane;
+        bool near = false;
+        if (o < n_obst) {
+            const double* v = tile + 8 * o;
+            double mnx = fmin(fmin(v[0], v[2]), fmin(v[4], v[6])), mxx = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+            double mny = fmin(fmin(v[1], v[3]), fmin(v[5], v[7])), mxy = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+            near = !(mnx > x0 + reach || mxx < x0 - reach || mny > y0 + reach || mxy < y0 - reach);
+        }
+        unsigned long long m = __ballot(near);
+        if (near) list[cnt + __popcll(m & ((1ull << lane) - 1))] = o;
+        cnt += __popcll(m);
+    }
+    return cnt;
+}
+
 // _detect_collision (car_parking_base.py:153-158): any hull edge x any obstacle edge share a point.
-__device__ __forceinline__ bool detect_collision(const Box& b, const double* tile, int n_slots, int lane) {
+// Edges are taken from the obstacles in list[0..n_list).
+__device__ __forceinline__ bool detect_collision(const Box& b, const double* tile, const int* list, int n_list, int lane) {
+    const int n_slots = 4 * n_list;
     double hminx = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3]));
     double hmaxx = fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3]));
     double hminy = fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3]));
@@ -117,8 +158,9 @@ __device__ __forceinline__ bool detect_collision(const Box& b, const double* til
         int e = base + lane;
         bool hit = false;
         if (e < n_slots) {
-            int e2 = (e & ~3) | ((e + 1) & 3);
-            double x1 = tile[2 * e], y1 = tile[2 * e + 1], x2 = tile[2 * e2], y2 = tile[2 * e2 + 1];
+            const double* v = tile + 8 * list[e >> 2];
+            int j = e & 3, j2 = (e + 1) & 3;
+            double x1 = v[2 * j], y1 = v[2 * j + 1], x2 = v[2 * j2], y2 = v[2 * j2 + 1];
             // envelope of the obstacle edge vs envelope of the hull: necessary for any segment pair
             if (!(fmin(x1, x2) > hmaxx || fmax(x1, x2) < hminx || fmin(y1, y2) > hmaxy || fmax(y1, y2) < hminy)) {
 #pragma unroll
@@ -142,6 +184,21 @@ __device__ __forceinline__ double origin_seg_dist(double ax, double ay, double b
     if (r >= 1.0) return sqrt(bx * bx + by * by);
     double s = ((ay - 0.0) * (bx - ax) - (ax - 0.0) * (by - ay)) / len2;
     return fabs(s) * sqrt(len2);
+}
+
+// Exact-safe necessary conditions for beam (a, b) = (sin th, -cos th) to register a hit on edge (x1,y1)-(x2,y2):
+//  * the reference accepts a hit only if the intersection of the beam LINE with the edge LINE lies inside the
+//    edge's box, i.e. on the segment, so the end points lie on opposite sides of (or on) the beam line; both
+//    clearly on one side (signed distance beyond 1e-9 m, ~1e4 x the rounding of raw_x / raw_y) -> no hit;
+//  * a point of the segment that is on the beam line has a forward coordinate t between the end points'; if both
+//    are < -1e-6 the point is behind the sensor and raw_x or raw_y violates the +-1e-8 quadrant test (:120-124).
+__device__ __forceinline__ bool beam_may_hit(double a, double b, double x1, double y1, double x2, double y2) {
+    double s1 = a * x1 + b * y1, s2 = a * x2 + b * y2;
+    const double eps = 1e-9, back = -1e-6;
+    if ((s1 > eps && s2 > eps) || (s1 < -eps && s2 < -eps)) return false;
+    double t1 = a * y1 - b * x1, t2 = a * y2 - b * x2;
+    if (t1 < back && t2 < back) return false;
+    return true;
 }
 
 // one (beam, edge) pair of _fast_calc_lidar_obs (lidar_simulator.py:98-133); returns range or +inf
@@ -194,11 +251,18 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
     bool arrive = false;
     bool known_free = false;     // final pose already passed _detect_collision in the sub-step loop
     bool have_ua = false;        // overlap area of the final pose already computed
-    double ua = 0.0, ua_prev = 0.0;
+    double ua = 0.0;
     double ct = 0, sn = 0;       // cos/sin of the final heading
     bool have_cs = false;
+    const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
+    int* nlist = keep;           // near-obstacle list (motion/status); the lidar reuses the words as keep flags
+    const bool moving = (p.stages & HOPE_STAGE_MOTION) && p.has_action;
+    // hull radius about the rear axle 3.883 m (+ 1.25 m of travel at |v| <= 2.5 m/s over 0.5 s) + slack
+    const int n_near = build_near_list(tile, n_obst, x, y, moving ? 5.2 : 3.9, nlist, lane);
+    if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
+    wsync();
 
-    if ((p.stages & HOPE_STAGE_MOTION) && p.has_action) {
+    if (moving) {
         // ---- action_rescale (env_wrapper.py:37-50) + KSModel clip (vehicle.py:85-86) -------------
         const AT* act = (const AT*)p.actions;
         double a0 = (double)act[2 * (size_t)scene], a1 = (double)act[2 * (size_t)scene + 1];
@@ -211,20 +275,21 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
         steer = clipd(steer, STEER_LO, STEER_HI);
         const double dh = speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
 
-        // ---- heading chain: h_{m+1} = h_m + dh (sequential rounding, vehicle.py:92-93).  Every lane
-        // runs the 200-add chain; lane l captures h_m for m = l, l+64, l+128, l+192. -----------------
-        double hj = h, hm0 = 0, hm1 = 0, hm2 = 0, hm3 = 0;
-        for (int m = 0; m < NUM_STEP * MINI_ITER; m++) {
-            int r = m >> 6, i = m & 63;
-            if (lane == i) {
-                if (r == 0) hm0 = hj; else if (r == 1) hm1 = hj; else if (r == 2) hm2 = hj; else hm3 = hj;
-            }
-            hj = hj + dh;
-            if ((m + 1) % MINI_ITER == 0 && lane == 0) scr[LDS_HB + (m + 1) / MINI_ITER - 1] = hj;
+        // ---- heading chain h_{m+1} = h_m + dh (sequential rounding, vehicle.py:92-93): ONE lane walks the
+        // 200 additions and leaves every partial sum in LDS; the other lanes pick theirs up afterwards. ----
+        double* hs = scr + LDS_TY;                         // hs[0..200], consumed before ty is written
+        if (lane == 0) {
+            double hj = h;
+            for (int m = 0; m < NUM_STEP * MINI_ITER; m++) { hs[m] = hj; hj = hj + dh; }
+            hs[NUM_STEP * MINI_ITER] = hj;
         }
         wsync();
-        // lanes 8..17 of round 3 evaluate the ten sub-step boundary headings instead (m = 200..209 unused)
-        if (lane >= 8 && lane < 18) hm3 = scr[LDS_HB + lane - 8];
+        // lane l evaluates micro-steps l, l+64, l+128, (l+192 for l < 8); lanes 8..17 the ten sub-step
+        // boundary headings h_{20(k+1)}
+        const double hm0 = hs[lane], hm1 = hs[64 + lane], hm2 = hs[128 + lane];
+        double hm3 = 0;
+        if (lane < 8) hm3 = hs[192 + lane]; else if (lane < 18) hm3 = hs[MINI_ITER * (lane - 7)];
+        wsync();
         // ---- per-micro-step displacement terms speed*cos(h)*step_len/mini_iter (vehicle.py:90-91) ----
         {
             double s_, c_;
@@ -243,41 +308,51 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
                     scr[LDS_TX + 192 + lane] = speed * c_ * STEP_LENGTH / MINI_ITER;
                     scr[LDS_TY + 192 + lane] = speed * s_ * STEP_LENGTH / MINI_ITER;
                 } else {
+                    scr[LDS_HB + lane - 8] = hm3;
                     scr[LDS_CB + lane - 8] = c_;
                     scr[LDS_SB + lane - 8] = s_;
                 }
             }
         }
         wsync();
+        // ---- x += ..., y += ... in micro-step order: lane 0 sums x, lane 1 sums y; the pose after each of
+        // the ten sub-steps is kept (it does not depend on the collision outcome, only where we stop does)
+        if (lane < 2) {
+            double acc = lane == 0 ? x : y;
+            const double* term = scr + (lane == 0 ? LDS_TX : LDS_TY);
+            double* dst = scr + (lane == 0 ? LDS_PX : LDS_PY);
+            for (int k = 0; k < NUM_STEP; k++) {
+#pragma unroll
+                for (int j = 0; j < MINI_ITER; j++) acc += term[k * MINI_ITER + j];
+                dst[k] = acc;
+            }
+        }
+        wsync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------
-        bool cur_free = false;      // pose at loop entry not checked in this step
         for (int k = 0; k < NUM_STEP; k++) {
             const double px = x, py = y, ph = h;          // prev_info
-            const bool prev_free = cur_free;
-            ua_prev = ua;
-            const bool prev_have_ua = have_ua;
-            for (int j = 0; j < MINI_ITER; j++) {         // x += ...; y += ... in micro-step order
-                x += scr[LDS_TX + k * MINI_ITER + j];
-                y += scr[LDS_TY + k * MINI_ITER + j];
-            }
+            const bool prev_free = known_free;
+            x = scr[LDS_PX + k];
+            y = scr[LDS_PY + k];
             h = scr[LDS_HB + k];
             ct = scr[LDS_CB + k];
             sn = scr[LDS_SB + k];
             have_cs = true;
+            have_ua = false;
             Box box = make_box(x, y, ct, sn);
-            ua = overlap_area(box, dbox, scr + LDS_SH, lane);
-            have_ua = true;
-            if (ua / dest_area > 0.95) { arrive = true; break; }        // _check_arrived :164-170
-            if (detect_collision(box, tile, n_slots, lane)) {            // retreat :264-271
+            if (arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {           // _check_arrived :164-170
+                ua = overlap_area(box, dbox, scr + LDS_SH, lane);
+                have_ua = true;
+                if (ua / dest_area > 0.95) { arrive = true; break; }
+            }
+            if (detect_collision(box, tile, nlist, n_near, lane)) {              // retreat :264-271
                 x = px; y = py; h = ph;
                 known_free = prev_free;
-                ua = ua_prev;
-                have_ua = prev_have_ua;
+                have_ua = false;
                 have_cs = false;
                 break;
             }
-            cur_free = true;
             known_free = true;
         }
     }
@@ -292,12 +367,18 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
         if (arrive) status = HOPE_STATUS_ARRIVED;
         else {
             const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
-            bool coll = known_free ? false : detect_collision(box, tile, n_slots, lane);
+            bool coll = known_free ? false : detect_collision(box, tile, nlist, n_near, lane);
             if (coll) status = HOPE_STATUS_COLLIDED;
             else if (x > xmax || x < xmin || y > ymax || y < ymin) status = HOPE_STATUS_OUTBOUND;
             else {
-                if (!have_ua) { ua = overlap_area(box, dbox, scr + LDS_SH, lane); have_ua = true; }
-                if (ua / dest_area > 0.95) status = HOPE_STATUS_ARRIVED;
+                bool arrived = false;
+                if (have_ua) arrived = ua / dest_area > 0.95;
+                else if (arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {
+                    ua = overlap_area(box, dbox, scr + LDS_SH, lane);
+                    have_ua = true;
+                    arrived = ua / dest_area > 0.95;
+                }
+                if (arrived) status = HOPE_STATUS_ARRIVED;
                 else if (t > TOLERANT_TIME) status = HOPE_STATUS_OUTTIME;
             }
         }
@@ -404,23 +485,60 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
         if (e < n_slots && (e & 3) == 0) keep[e >> 2] = dd < LIDAR_RANGE;
     }
     wsync();
-    // beams: lane l owns beams l and l+64
+    // beams: lane l owns beams l and l+64.  Two passes (SIMT pays for the union of lanes, and every edge is
+    // crossed by SOME beam, so the two float64 divisions of a pair must not sit in the lane-per-beam loop):
+    //  pass 1 (cheap): per kept edge each lane tests its beams with exact-safe necessary conditions and
+    //          appends the surviving (beam, edge) pairs to an LDS queue;
+    //  pass 2 (dense): the queue is drained 64 pairs at a time through the full reference arithmetic and an
+    //          LDS atomic-min per beam (non-negative doubles order like their bit patterns).
     const int i0 = lane, i1 = lane + 64;
     const bool has1 = i1 < NBEAM;
     const double a0 = p.beam_ab[2 * i0], b0 = p.beam_ab[2 * i0 + 1];
     const double a1 = has1 ? p.beam_ab[2 * i1] : 0.0, b1 = has1 ? p.beam_ab[2 * i1 + 1] : 0.0;
-    double best0 = INFINITY, best1 = INFINITY;
+    unsigned long long* best = (unsigned long long*)(scr + LDS_TX);          // [128] (tx/ty are dead by now)
+    int* queue = (int*)(scr + LDS_TX + 128);                                 // [LQ]
+    constexpr int LQ = 384;
+    best[lane] = 0x7ff0000000000000ull;                                      // +inf
+    best[lane + 64] = 0x7ff0000000000000ull;
+    wsync();
+    int qn = 0;
+    auto drain = [&]() {
+        wsync();
+        for (int q0 = 0; q0 < qn; q0 += WAVE) {
+            int q = q0 + lane;
+            if (q < qn) {
+                int pr = queue[q];
+                int bi = pr & 127, e = pr >> 7;
+                int e2 = (e & ~3) | ((e + 1) & 3);
+                double x1 = tile[2 * e], y1 = tile[2 * e + 1], x2 = tile[2 * e2], y2 = tile[2 * e2 + 1];
+                double d = y2 - y1, ee = x1 - x2, f = y1 * x2 - x1 * y2;
+                double r = beam_edge(bi, p.beam_ab[2 * bi], p.beam_ab[2 * bi + 1], x1, y1, x2, y2, d, ee, f);
+                if (r < INFINITY) atomicMin(&best[bi], (unsigned long long)__double_as_longlong(r));
+            }
+        }
+        wsync();
+        qn = 0;
+    };
     for (int r = 0; r < n_obst; r++) {
-        if (!keep[r]) continue;
+        if (!keep[r] || (p.stages & 0x1000)) continue;       // 0x1000: internal profiling switch (tools/stage_times.py)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             int e = 4 * r + j, e2 = 4 * r + ((j + 1) & 3);
             double x1 = tile[2 * e], y1 = tile[2 * e + 1], x2 = tile[2 * e2], y2 = tile[2 * e2 + 1];
-            double d = y2 - y1, ee = x1 - x2, f = y1 * x2 - x1 * y2;
-            best0 = fmin(best0, beam_edge(i0, a0, b0, x1, y1, x2, y2, d, ee, f));
-            if (has1) best1 = fmin(best1, beam_edge(i1, a1, b1, x1, y1, x2, y2, d, ee, f));
+            bool c0 = beam_may_hit(a0, b0, x1, y1, x2, y2);
+            bool c1 = has1 && beam_may_hit(a1, b1, x1, y1, x2, y2);
+            unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+            const unsigned long long lt = (1ull << lane) - 1;
+            if (c0) queue[qn + __popcll(m0 & lt)] = (e << 7) | i0;
+            qn += __popcll(m0);
+            if (c1) queue[qn + __popcll(m1 & lt)] = (e << 7) | i1;
+            qn += __popcll(m1);
         }
+        if (qn > LQ - 4 * 2 * WAVE) drain();                                  // room for one more ring
     }
+    if (qn > 0) drain();
+    const double best0 = __longlong_as_double((long long)best[i0]);
+    const double best1 = has1 ? __longlong_as_double((long long)best[i1]) : INFINITY;
     const double base0 = p.hull_base[i0], base1 = has1 ? p.hull_base[i1] : 0.0;
     const double lid0 = clipd(best0, 0, LIDAR_RANGE) - base0;      // get_observation :46
     const double lid1 = clipd(best1, 0, LIDAR_RANGE) - base1;
@@ -429,7 +547,7 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
         lo[i0] = (OT)lid0;
         if (has1) lo[i1] = (OT)lid1;
     }
-    if (!p.out.action_mask) return;
+    if (!p.out.action_mask || (p.stages & 0x2000)) return;    // 0x2000: internal profiling switch
 
     // ---- action mask (action_mask.py:166-196) ----------------------------------------------------------
     double* xs = scr + LDS_X;                                     // lidar_obs = clip(raw,0,10) + base (:170)
@@ -438,29 +556,85 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
     wsync();
     if (lane == 0) xs[NBEAM] = xs[0];                             // circular (:158)
     wsync();
-    int mstep = NITER;                                            // lane a: min over beams of first-exceed index
-    for (int r = 0; r < (NL + WAVE - 1) / WAVE; r++) {
-        int l = r * WAVE + lane;
-        double dl = 0;
-        bool act = false;
-        if (l < NL) {
-            int i = l / UPS, j = l % UPS;
-            double w2 = (double)j / UPS, w1 = 1 - w2;
-            dl = xs[i] * w1 + xs[i + 1] * w2;                     // _linear_interpolate (:161-162)
-            act = dl < p.pmax[l];
-        }
-        unsigned long long m = __ballot(act);
-        while (m) {
-            int bpos = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int ll = r * WAVE + bpos;
-            double d_ll = __shfl(dl, bpos);
-            if (lane < NACT) {
-                const double* row = p.tab + (size_t)ll * NITER * NACT + lane;
-                int cnt = 0;
+    // step_len[a] = min over the 1200 upsampled beams l of cnt(l,a) = #{k : tab[l][k][a] <= d_l} (tab is prefix-maxed
+    // over k, so the count IS the first-exceed index of :176-177).
+    //
+    // Coarse decision.  Fine beam l = 10i + j carries d_l = x_i*w1 + x_{i+1}*w2 and the fine table is the SAME
+    // interpolation of the coarse table (:142,:161-162), hence for every l of interval i
+    //     tab[l][k][a] <= w1*tab[10i][k][a] + w2*tab[10i+10][k][a]   (up to ~1e-15 rounding),
+    // and at the coarse beams themselves (w1 = 1, w2 = 0: exact) cnt(10i,a) = #{k : tab[10i][k][a] <= x_i}.
+    // With  m    = min_i #{k : tab[10i][k][a] <= x_i}          (exact counts at the 120 coarse beams: upper bound)
+    //       mlow = min_i #{k : tab[10i][k][a] <= x_i - 1e-9}    (=> every fine beam has cnt >= mlow: lower bound)
+    // the answer lies in [mlow, m].  They differ only if some table entry is within 1e-9 of x_i (e.g. the
+    // structural tie of the straight arcs when an obstacle touches the hull side); then, and only then, the
+    // full 1200-beam evaluation below runs.  120 row probes instead of up to 1200 x 10 rows.
+    int mstep = NITER, mlow = NITER;
+    {
+        // lane-parallel activity test (one lane per coarse beam), then only the active rows are visited,
+        // four at a time so that their probes are in flight together
+        const bool c0 = xs[i0] - 1e-9 < p.pmax[UPS * i0];
+        const bool c1 = has1 && xs[i1] - 1e-9 < p.pmax[UPS * i1];
+        unsigned long long am[2] = {__ballot(c0), __ballot(c1)};
 #pragma unroll
-                for (int k = 0; k < NITER; k++) cnt += (row[k * NACT] <= d_ll) ? 1 : 0;
-                mstep = min(mstep, cnt);
+        for (int half = 0; half < 2; half++) {
+            unsigned long long m = am[half];
+            while (m) {
+                int ib[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    if (m) { ib[g] = 64 * half + __ffsll((long long)m) - 1; m &= m - 1; }
+                    else ib[g] = ib[0];                           // duplicate: min() is idempotent
+                }
+                if (lane < NACT) {
+                    const double* row[4];
+                    double xv[4], v[4], vl[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        xv[g] = xs[ib[g]];
+                        row[g] = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + lane;
+                        v[g] = mstep > 0 ? row[g][(mstep - 1) * NACT] : 0.0;
+                        vl[g] = mlow > 0 ? row[g][(mlow - 1) * NACT] : 0.0;
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        if (mstep > 0 && v[g] > xv[g]) {
+                            int c = mstep;
+                            while (c > 0 && row[g][(c - 1) * NACT] > xv[g]) c--;
+                            mstep = c;
+                        }
+                        if (mlow > 0 && vl[g] > xv[g] - 1e-9) {
+                            int c = mlow;
+                            while (c > 0 && row[g][(c - 1) * NACT] > xv[g] - 1e-9) c--;
+                            mlow = c;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (__any(mlow != mstep)) {
+        // ---- exact fall-back over all 1200 beams (rare) ---------------------------------------------------
+        for (int r = 0; r < (NL + WAVE - 1) / WAVE; r++) {
+            int l = r * WAVE + lane;
+            double dl = 0;
+            bool act = false;
+            if (l < NL) {
+                int i = l / UPS, j = l % UPS;
+                double w2 = scr[LDS_W2 + j], w1 = 1 - w2;
+                dl = xs[i] * w1 + xs[i + 1] * w2;                 // _linear_interpolate (:161-162)
+                act = dl < p.pmax[l];
+            }
+            unsigned long long m = __ballot(act);
+            while (m) {
+                int bpos = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                double d_ll = __shfl(dl, bpos);
+                if (lane < NACT) {
+                    const double* row = p.tab + (size_t)(r * WAVE + bpos) * NITER * NACT + lane;
+                    int c = mstep;
+                    while (c > 0 && row[(c - 1) * NACT] > d_ll) c--;
+                    mstep = c;
+                }
             }
         }
     }

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-stage cost of the step kernel: times hope_env_step with different stage masks / scene mixes using the
+in-library HIP events.  Usage: python tools/stage_times.py [--scenes 32768]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--scenes', type=int, default=32768)
+    ap.add_argument('--steps', type=int, default=8)
+    args = ap.parse_args()
+    import torch
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scenes import SceneSource, pack_scenes
+    N = args.scenes
+    for mix in (('dlp',), ('Normal', 'Complex', 'Extrem')):
+        src = SceneSource(levels=mix, seed=3)
+        uniq = [src.draw() for _ in range(512)]
+        start, dest, bbox, verts, nob, nvert = pack_scenes(uniq, 128)
+        reps = N // len(uniq)
+        tile = lambda a: np.concatenate([a] * reps, axis=0)  # noqa: E731
+        env = ParkingBatch(N, 128, profile=True)
+        for a in range(0, N, 8192):
+            sl = slice(a, a + 8192)
+            env.set_scene_arrays(np.arange(a, a + 8192), tile(start)[sl], tile(dest)[sl], tile(bbox)[sl], tile(verts)[sl], tile(nob)[sl])
+        g = torch.Generator(device=env.device); g.manual_seed(0)
+        acts = [torch.rand((N, 2), generator=g, device=env.device) * 2 - 1 for _ in range(4)]
+        for name, st in (('motion', L.STAGE_MOTION), ('motion+reward', L.STAGE_MOTION | L.STAGE_REWARD),
+                         ('obs only(no motion)', L.STAGE_OBS), ('motion+obs+reward', L.STAGE_MOTION | L.STAGE_OBS | L.STAGE_REWARD),
+                         ('all', L.STAGE_ALL), ('obs -mask', L.STAGE_OBS | 0x2000), ('obs -beams', L.STAGE_OBS | 0x1000),
+                         ('obs -beams -mask', L.STAGE_OBS | 0x3000)):
+            env.reset_obs(stages=L.STAGE_ALL)
+            for i in range(3):
+                env.step(acts[i % 4], stages=st)
+            torch.cuda.synchronize()
+            env.kernel_ms(reset=True)
+            for i in range(args.steps):
+                env.step(acts[i % 4], stages=st)
+            torch.cuda.synchronize()
+            sm, sn, rm, rn = env.kernel_ms(reset=True)
+            print(f'{"/".join(mix):24s} {name:22s} step {sm/sn*1e3:8.1f} us  rs {rm/max(rn,1)*1e3:8.1f} us   '
+                  f'({N/(sm/sn+rm/max(rn,1))/1e3:.1f} M scene-steps/s)', flush=True)
+        env.close()
+
+
+if __name__ == '__main__':
+    main()
