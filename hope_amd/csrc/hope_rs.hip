@@ -209,13 +209,17 @@ __device__ __forceinline__ void interpolate(double l, int m, double ox, double o
     }
 }
 
-// is_traj_valid for ONE pose held by this lane: returns true if the pose is out of the map box or any
-// hull edge meets any obstacle edge (line-line intersection inside both edge boxes, no tolerance).
+// is_traj_valid for the (up to 64) poses held one per lane: returns true on a lane whose pose is out of the
+// map box or whose hull meets an obstacle edge (line-line intersection inside both edge boxes, no tolerance).
+// Obstacles are culled per call: the union box of the active lanes' hulls is wave-reduced, one lane per
+// obstacle compares its precomputed box (obb, in LDS) with it, and only the survivors (cand[], usually 0-3)
+// are visited.  A pair whose boxes do not overlap cannot pass the reference's box tests, so this is exact.
 __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, double wyaw, const double* tile,
-                                          int n_obst, double xmin, double xmax, double ymin, double ymax) {
+                                          const double* obb, int* cand, int n_obst, double xmin, double xmax,
+                                          double ymin, double ymax, int lane) {
     bool bad = false;
     double vx[4], vy[4];
-    double hminx = 0, hmaxx = 0, hminy = 0, hmaxy = 0;
+    double hminx = INFINITY, hmaxx = -INFINITY, hminy = INFINITY, hmaxy = -INFINITY;
     if (active) {
         if (wx < xmin || wx > xmax || wy < ymin || wy > ymax) bad = true;      // :462-464
         double st, ct;
@@ -230,12 +234,35 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         hminy = fmin(fmin(vy[0], vy[1]), fmin(vy[2], vy[3]));
         hmaxy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
     }
-    for (int r = 0; r < n_obst; r++) {
+    if (__any(bad)) return bad;
+    // union box of the chunk
+    double uminx = hminx, umaxx = hmaxx, uminy = hminy, umaxy = hmaxy;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uminx = fmin(uminx, __shfl_xor(uminx, off));
+        umaxx = fmax(umaxx, __shfl_xor(umaxx, off));
+        uminy = fmin(uminy, __shfl_xor(uminy, off));
+        umaxy = fmax(umaxy, __shfl_xor(umaxy, off));
+    }
+    int nc = 0;
+    for (int base = 0; base < n_obst; base += WAVE) {
+        int o = base + lane;
+        bool near = false;
+        if (o < n_obst) {
+            const double* bb = obb + 4 * o;
+            near = !(bb[0] > umaxx || bb[1] < uminx || bb[2] > umaxy || bb[3] < uminy);
+        }
+        unsigned long long m = __ballot(near);
+        if (near) cand[nc + __popcll(m & ((1ull << lane) - 1))] = o;
+        nc += __popcll(m);
+    }
+    if (nc == 0) return false;
+    wsync();
+    for (int ci = 0; ci < nc; ci++) {
+        const int r = cand[ci];
         const double* o = tile + 8 * r;
-        double ox0 = o[0], oy0 = o[1], ox1 = o[2], oy1 = o[3], ox2 = o[4], oy2 = o[5], ox3 = o[6], oy3 = o[7];
-        double ominx = fmin(fmin(ox0, ox1), fmin(ox2, ox3)), omaxx = fmax(fmax(ox0, ox1), fmax(ox2, ox3));
-        double ominy = fmin(fmin(oy0, oy1), fmin(oy2, oy3)), omaxy = fmax(fmax(oy0, oy1), fmax(oy2, oy3));
-        bool near = active && !bad && !(ominx > hmaxx || omaxx < hminx || ominy > hmaxy || omaxy < hminy);
+        const double* bb = obb + 4 * r;
+        bool near = active && !(bb[0] > hmaxx || bb[1] < hminx || bb[2] > hmaxy || bb[3] < hminy);
         if (!__any(near)) continue;
         if (near) {
 #pragma unroll
@@ -263,10 +290,11 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
             }
         }
     }
+    wsync();
     return bad;
 }
 
-// LDS (doubles): tile 8*max_obst | Lm[64] | heap pr[64] | ints: heap id[64], order[64]
+// LDS (doubles): tile 8*max_obst | obstacle boxes 4*max_obst | Lm[64] | heap pr[64] | ints: heap id[64], order[64], cand[max_obst]
 constexpr int RS_LM = 0, RS_PR = 64, RS_WORDS = 128;
 
 __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
@@ -275,15 +303,24 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
     if ((int)blockIdx.x >= *p.rs_count) return;
     const int scene = p.rs_list[blockIdx.x];
     double* tile = lds;
-    double* scr = lds + 8 * p.max_obst;
+    double* obb = lds + 8 * p.max_obst;
+    double* scr = lds + 12 * p.max_obst;
     int* hid = (int*)(scr + RS_WORDS);
     int* order = hid + 64;
+    int* cand = order + 64;
 
     const int n_obst = p.n_obst[scene];
     {
         const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
         double2* dst = (double2*)tile;
         for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
+        for (int o = lane; o < n_obst; o += WAVE) {           // obstacle boxes (xmin, xmax, ymin, ymax) from HBM copy
+            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
+            obb[4 * o] = fmin(fmin(v[0], v[2]), fmin(v[4], v[6]));
+            obb[4 * o + 1] = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+            obb[4 * o + 2] = fmin(fmin(v[1], v[3]), fmin(v[5], v[7]));
+            obb[4 * o + 3] = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+        }
     }
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double* st = p.state + (size_t)scene * ST_WORDS;
@@ -466,7 +503,7 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
                 double wx = c_q * px + s_q * py + q0x;
                 double wy = -s_q * px + c_q * py + q0y;
                 double wyaw = pi_2_pi(pyaw + q0w);
-                bool bad = pose_hits(active, wx, wy, wyaw, tile, n_obst, xmin, xmax, ymin, ymax);
+                bool bad = pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane);
                 if (__any(bad)) { invalid = true; break; }
                 if (count < WAVE) { pd = __shfl(mine, count); break; }
                 pd = t;
@@ -483,7 +520,7 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
             double wx = c_q * px + s_q * py + q0x;
             double wy = -s_q * px + c_q * py + q0y;
             double wyaw = pi_2_pi(pyaw + q0w);
-            bool bad = pose_hits(lane < 2, wx, wy, wyaw, tile, n_obst, xmin, xmax, ymin, ymax);
+            bool bad = pose_hits(lane < 2, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane);
             if (__any(bad)) invalid = true;
         }
         if (!invalid) { found_c = pc; break; }
@@ -510,7 +547,7 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
 
 }  // namespace
 
-size_t rs_lds_bytes(int max_obst) { return (size_t)(8 * max_obst + RS_WORDS) * 8 + 128 * 4; }
+size_t rs_lds_bytes(int max_obst) { return (size_t)(12 * max_obst + RS_WORDS) * 8 + (size_t)(128 + ((max_obst + 3) & ~3)) * 4; }
 
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream) {
     size_t lds = rs_lds_bytes(p.max_obst);
