@@ -45,6 +45,8 @@ struct hope_env {
     double* beam_ab = nullptr;
     int32_t* rs_count = nullptr;
     int32_t* rs_list = nullptr;
+    void* rs_words = nullptr;
+    int32_t* rs_nwords = nullptr;
     // staging for set_scenes
     void* stage = nullptr;
     size_t stage_bytes = 0;
@@ -183,6 +185,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
     ALLOC(h->rs_count, sizeof(int32_t));
     ALLOC(h->rs_list, N * sizeof(int32_t));
+    ALLOC(h->rs_words, N * rs_words_bytes_per_scene());
+    ALLOC(h->rs_nwords, N * sizeof(int32_t));
 #undef ALLOC
     HIPCHK(hipMemset(h->n_obst, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->scene_c, 0, N * SC_WORDS * sizeof(double)));
@@ -206,7 +210,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->stage};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_words, h->rs_nwords, h->stage};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -329,6 +333,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
         r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
         r.rs_count = h->rs_count; r.rs_list = h->rs_list;
+        r.rs_words = (RsWord*)h->rs_words; r.rs_nwords = h->rs_nwords;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
         HIPCHK(launch_rs_search(r, s));
         if (prof) { HIPCHK(hipEventRecord(eb, s)); h->pending.push_back({ea, eb, 1}); }

@@ -6,6 +6,15 @@
 
 namespace hope {
 
+// One Reeds-Shepp word as the validation kernel reads it (64 B)
+struct RsWord {
+    double len[5];   // normalised (curvature-1) signed lengths
+    double Lm;       // path.L / maxc  [m]
+    int code;        // packed segment types + count
+    int n;
+};
+constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generate_path
+
 struct RsParams {
     int n, max_obst;
     int obs_f64;
@@ -15,6 +24,8 @@ struct RsParams {
     const double* state;      // [n][ST_WORDS]
     const int32_t* rs_count;  // [1]
     const int32_t* rs_list;   // [n]
+    RsWord* rs_words;         // [n][RS_WORDS_PER_SCENE] ordered (pop order) words of the queued scenes
+    int32_t* rs_nwords;       // [n]
     int8_t* rs_word;          // [n][8]
     void* rs_lengths;         // real [n][5]
 };
@@ -22,5 +33,6 @@ struct RsParams {
 // launches the Reeds-Shepp feasibility kernel over the scenes queued in rs_list (hope_rs.hip)
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream);
 size_t rs_lds_bytes(int max_obst);
+size_t rs_words_bytes_per_scene();
 
 }  // namespace hope

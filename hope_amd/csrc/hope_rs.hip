@@ -181,13 +181,6 @@ __device__ __forceinline__ int pack_types(int a, int b, int c, int d, int e, int
     return a | (b << 2) | (c << 4) | (d << 6) | (e << 8) | (n << 12);
 }
 __device__ __forceinline__ int mirror_type(int t) { return t == TL ? TR : (t == TR ? TL : t); }
-
-struct Word {
-    double len[5];
-    int code;   // packed types + n
-    int n;
-};
-
 __device__ __forceinline__ int type_of(int code, int i) { return (code >> (2 * i)) & 3; }
 
 // interpolate (:510-537) of arc/line parameter l from origin (ox, oy, oyaw) in the local frame
@@ -294,39 +287,26 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
     return bad;
 }
 
-// LDS (doubles): tile 8*max_obst | obstacle boxes 4*max_obst | Lm[64] | heap pr[64] | ints: heap id[64], order[64], cand[max_obst]
-constexpr int RS_LM = 0, RS_PR = 64, RS_WORDS = 128;
+// ================================================================================================
+// Kernel A: generate_path + set_path + heapdict order  ->  ordered word list per queued scene
+// ================================================================================================
+// The 46 solver calls run one per lane.  Instead of twelve divergent solver bodies, the lanes share the
+// expensive steps: one sincos(phi'), one (hypot, atan2) of the solver's polar argument, one asin/acos,
+// one second atan2, then short per-family tails -- the arithmetic of each solver is unchanged.
+constexpr int RSA_LM = 0, RSA_PR = 64, RSA_WORDS = 128;     // LDS doubles, then ints hid[64], order[64]
 
-__global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
+    __shared__ double scr[RSA_WORDS];
+    __shared__ int hid[64];
+    __shared__ int order[64];
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= *p.rs_count) return;
-    const int scene = p.rs_list[blockIdx.x];
-    double* tile = lds;
-    double* obb = lds + 8 * p.max_obst;
-    double* scr = lds + 12 * p.max_obst;
-    int* hid = (int*)(scr + RS_WORDS);
-    int* order = hid + 64;
-    int* cand = order + 64;
-
-    const int n_obst = p.n_obst[scene];
-    {
-        const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
-        double2* dst = (double2*)tile;
-        for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
-        for (int o = lane; o < n_obst; o += WAVE) {           // obstacle boxes (xmin, xmax, ymin, ymax) from HBM copy
-            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
-            obb[4 * o] = fmin(fmin(v[0], v[2]), fmin(v[4], v[6]));
-            obb[4 * o + 1] = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
-            obb[4 * o + 2] = fmin(fmin(v[1], v[3]), fmin(v[5], v[7]));
-            obb[4 * o + 3] = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
-        }
-    }
+    const int slot = blockIdx.x;
+    if (slot >= *p.rs_count) return;
+    const int scene = p.rs_list[slot];
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double* st = p.state + (size_t)scene * ST_WORDS;
     const double q0x = st[0], q0y = st[1], q0w = st[2];
     const double gx = sc[SC_DEST], gy = sc[SC_DEST + 1], gw = sc[SC_DEST + 2];
-    const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
 
     // ---- generate_path (:540-557): normalise the goal into the start frame ------------------------
     double X, Y, PHI;
@@ -337,10 +317,8 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
         X = (c * dx + s * dy) * MAXC;
         Y = (-s * dx + c * dy) * MAXC;
     }
-    Word w;
-    w.n = 0; w.code = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) w.len[i] = 0;
+    double l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0;
+    int code = 0, wn = 0;
     bool ok = false;
     if (lane < NCAND) {
         int g, q;
@@ -350,45 +328,110 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
             bx = X * cos(PHI) + Y * sin(PHI);
             by = X * sin(PHI) - Y * cos(PHI);
         }
-        double sx = (q & 1) ? -bx : bx;
-        double sy = (q & 2) ? -by : by;
-        double sp = (q == 1 || q == 2) ? -PHI : PHI;
+        const double sx = (q & 1) ? -bx : bx;
+        const double sy = (q & 2) ? -by : by;
+        const double sp = (q == 1 || q == 2) ? -PHI : PHI;
         double t = 0, u = 0, v = 0;
-        switch (g) {
-            case 0: ok = rs_SLS(sx, sy, sp, t, u, v); break;
-            case 1: ok = rs_LSL(sx, sy, sp, t, u, v); break;
-            case 2: ok = rs_LSR(sx, sy, sp, t, u, v); break;
-            case 3: case 4: ok = rs_LRL(sx, sy, sp, t, u, v); break;
-            case 5: ok = rs_LRLRn(sx, sy, sp, t, u, v); break;
-            case 6: ok = rs_LRLRp(sx, sy, sp, t, u, v); break;
-            case 7: case 9: ok = rs_LRSL(sx, sy, sp, t, u, v); break;
-            case 8: case 10: ok = rs_LRSR(sx, sy, sp, t, u, v); break;
-            default: ok = rs_LRSLR(sx, sy, sp, t, u, v); break;
+        if (g == 0) {
+            ok = rs_SLS(sx, sy, sp, t, u, v);
+        } else {
+            double s_, c_;
+            sincos(sp, &s_, &c_);
+            const bool plus = (g == 2 || g == 5 || g == 6 || g == 8 || g == 10 || g == 11);
+            const double xi = plus ? sx + s_ : sx - s_;
+            const double eta = plus ? sy - 1.0 - c_ : sy - 1.0 + c_;
+            const bool isLRLR = (g == 5 || g == 6);
+            const bool isLRSR = (g == 8 || g == 10);
+            double r = 0, th = 0;
+            if (!isLRLR) {                                // R(.,.) (:571-578); LRSR uses R(-eta, xi) (:314)
+                double ra = isLRSR ? -eta : xi, rb = isLRSR ? xi : eta;
+                r = hypot(ra, rb);
+                th = atan2(rb, ra);
+            }
+            bool alive = true, needC = false;
+            double cy = 0, cx = 1, vv = 0, t2 = 0;
+            if (g == 1) {                                 // LSL :79-87
+                t = th; u = r; alive = t >= 0.0;
+            } else if (g == 2) {                          // LSR :90-103
+                double u1 = r * r;
+                alive = u1 >= 4.0;
+                if (alive) { u = sqrt(u1 - 4.0); cy = 2.0; cx = u; needC = true; }
+            } else if (g == 3 || g == 4) {                // LRL :106-117
+                alive = r <= 4.0;
+                if (alive) u = -2.0 * asin(0.25 * r);
+            } else if (isLRSR) {                          // LRSR :311-323
+                alive = r >= 2.0;
+                if (alive) { t = th; u = 2.0 - r; v = rs_M(t + 0.5 * PI - sp); }
+            } else if (g == 7 || g == 9) {                // LRSL :326-339
+                alive = r >= 2.0;
+                if (alive) { double rr = sqrt(r * r - 4.0); u = 2.0 - rr; cy = rr; cx = -2.0; needC = true; }
+            } else if (g == 11) {                         // LRSLR :414-429
+                alive = r >= 2.0;
+                if (alive) {
+                    u = 4.0 - sqrt(r * r - 4.0);
+                    alive = u <= 0.0;
+                    if (alive) { cy = (4.0 - u) * xi - 2.0 * eta; cx = -2.0 * xi + (u - 4.0) * eta; needC = true; }
+                }
+            } else {                                      // LRLRn :246-257 / LRLRp :260-272 + calc_tauOmega :228-243
+                if (g == 5) {
+                    double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
+                    alive = rho <= 1.0;
+                    if (alive) { u = acos(rho); vv = -u; }
+                } else {
+                    double rho = (20.0 - xi * xi - eta * eta) / 16.0;
+                    alive = 0.0 <= rho && rho <= 1.0;
+                    if (alive) { u = -acos(rho); alive = u >= -0.5 * PI; vv = u; }
+                }
+                if (alive) {
+                    double delta = rs_M(u - vv);
+                    double su, cu, sd, cd;
+                    sincos(u, &su, &cu);
+                    sincos(delta, &sd, &cd);
+                    double A = su - sd;
+                    double B = cu - cd - 1.0;
+                    cy = eta * A - xi * B; cx = xi * A + eta * B; needC = true;
+                    t2 = 2.0 * (cd - cos(vv) - cu) + 3.0;
+                }
+            }
+            double th2 = 0;
+            if (alive && needC) th2 = atan2(cy, cx);
+            if (alive) {
+                if (g == 1) { v = rs_M(sp - t); ok = v >= 0.0; }
+                else if (g == 2) { t = rs_M(th + th2); v = rs_M(t - sp); ok = t >= 0.0 && v >= 0.0; }
+                else if (g == 3 || g == 4) { t = rs_M(th + 0.5 * u + PI); v = rs_M(sp - t + u); ok = t >= 0.0 && u <= 0.0; }
+                else if (isLRSR) { ok = t >= 0.0 && u <= 0.0 && v <= 0.0; }
+                else if (g == 7 || g == 9) { t = rs_M(th + th2); v = rs_M(sp - 0.5 * PI - t); ok = t >= 0.0 && u <= 0.0 && v <= 0.0; }
+                else if (g == 11) { t = rs_M(th2); v = rs_M(t - sp); ok = t >= 0.0 && v >= 0.0; }
+                else {
+                    t = t2 < 0 ? rs_M(th2 + PI) : rs_M(th2);
+                    v = rs_M(t - u + vv - sp);
+                    ok = (g == 5) ? (t >= 0.0 && v <= 0.0) : (t >= 0.0 && v >= 0.0);
+                }
+            }
         }
         const double hp = 0.5 * PI;
-        int t0 = TL, t1 = TS, t2 = TL, t3 = 0, t4 = 0, n = 3;
-        double l0 = t, l1 = u, l2 = v, l3 = 0, l4 = 0;
+        int t0 = TL, t1 = TS, t2_ = TL, t3 = 0, t4 = 0, n = 3;
+        l0 = t; l1 = u; l2 = v;
         switch (g) {
-            case 0: t0 = TS; t1 = TL; t2 = TS; break;
-            case 1: t0 = TL; t1 = TS; t2 = TL; break;
-            case 2: t0 = TL; t1 = TS; t2 = TR; break;
-            case 3: t0 = TL; t1 = TR; t2 = TL; break;
-            case 4: t0 = TL; t1 = TR; t2 = TL; l0 = v; l2 = t; break;
-            case 5: n = 4; t0 = TL; t1 = TR; t2 = TL; t3 = TR; l2 = -u; l3 = v; break;
-            case 6: n = 4; t0 = TL; t1 = TR; t2 = TL; t3 = TR; l2 = u; l3 = v; break;
-            case 7: n = 4; t0 = TL; t1 = TR; t2 = TS; t3 = TL; l1 = -hp; l2 = u; l3 = v; break;
-            case 8: n = 4; t0 = TL; t1 = TR; t2 = TS; t3 = TR; l1 = -hp; l2 = u; l3 = v; break;
-            case 9: n = 4; t0 = TL; t1 = TS; t2 = TR; t3 = TL; l0 = v; l1 = u; l2 = -hp; l3 = t; break;
-            case 10: n = 4; t0 = TR; t1 = TS; t2 = TR; t3 = TL; l0 = v; l1 = u; l2 = -hp; l3 = t; break;
-            default: n = 5; t0 = TL; t1 = TR; t2 = TS; t3 = TL; t4 = TR; l1 = -hp; l2 = u; l3 = -hp; l4 = v; break;
+            case 0: t0 = TS; t1 = TL; t2_ = TS; break;
+            case 1: t0 = TL; t1 = TS; t2_ = TL; break;
+            case 2: t0 = TL; t1 = TS; t2_ = TR; break;
+            case 3: t0 = TL; t1 = TR; t2_ = TL; break;
+            case 4: t0 = TL; t1 = TR; t2_ = TL; l0 = v; l2 = t; break;
+            case 5: n = 4; t0 = TL; t1 = TR; t2_ = TL; t3 = TR; l2 = -u; l3 = v; break;
+            case 6: n = 4; t0 = TL; t1 = TR; t2_ = TL; t3 = TR; l2 = u; l3 = v; break;
+            case 7: n = 4; t0 = TL; t1 = TR; t2_ = TS; t3 = TL; l1 = -hp; l2 = u; l3 = v; break;
+            case 8: n = 4; t0 = TL; t1 = TR; t2_ = TS; t3 = TR; l1 = -hp; l2 = u; l3 = v; break;
+            case 9: n = 4; t0 = TL; t1 = TS; t2_ = TR; t3 = TL; l0 = v; l1 = u; l2 = -hp; l3 = t; break;
+            case 10: n = 4; t0 = TR; t1 = TS; t2_ = TR; t3 = TL; l0 = v; l1 = u; l2 = -hp; l3 = t; break;
+            default: n = 5; t0 = TL; t1 = TR; t2_ = TS; t3 = TL; t4 = TR; l1 = -hp; l2 = u; l3 = -hp; l4 = v; break;
         }
         if (q & 1) { l0 = -l0; l1 = -l1; l2 = -l2; l3 = -l3; l4 = -l4; }
-        if (q & 2) { t0 = mirror_type(t0); t1 = mirror_type(t1); t2 = mirror_type(t2); t3 = mirror_type(t3); t4 = mirror_type(t4); }
+        if (q & 2) { t0 = mirror_type(t0); t1 = mirror_type(t1); t2_ = mirror_type(t2_); t3 = mirror_type(t3); t4 = mirror_type(t4); }
         if (n < 4) { t3 = 0; l3 = 0; }
         if (n < 5) { t4 = 0; l4 = 0; }
-        w.n = n;
-        w.code = pack_types(t0, t1, t2, t3, t4, n);
-        w.len[0] = l0; w.len[1] = l1; w.len[2] = l2; w.len[3] = l3; w.len[4] = l4;
+        wn = n;
+        code = pack_types(t0, t1, t2_, t3, t4, n);
     }
 
     // ---- set_path (:57-76) replayed in call order ---------------------------------------------------
@@ -397,38 +440,41 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
     double myL = 0;
     for (int c = 0; c < NCAND; c++) {
         if (!((okmask >> c) & 1)) continue;
-        int code_c = __shfl(w.code, c);
-        int n_c = __shfl(w.n, c);
-        double lc[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) lc[i] = __shfl(w.len[i], c);
+        const int code_c = __shfl(code, c);
+        const int n_c = __shfl(wn, c);
+        const double c0 = __shfl(l0, c), c1 = __shfl(l1, c), c2 = __shfl(l2, c), c3 = __shfl(l3, c), c4 = __shfl(l4, c);
         bool dup = false;
-        if (((kept >> lane) & 1) && w.code == code_c) {
-            double s = 0;
-            for (int i = 0; i < n_c; i++) s = s + (w.len[i] - lc[i]);      // sum([x - y ...]) (:65)
+        if (((kept >> lane) & 1) && code == code_c) {
+            double s = 0;                                  // sum([x - y ...]) left to right (:65)
+            s = s + (l0 - c0); s = s + (l1 - c1); s = s + (l2 - c2);
+            if (n_c > 3) s = s + (l3 - c3);
+            if (n_c > 4) s = s + (l4 - c4);
             dup = s <= 0.01;
         }
         if (__any(dup)) continue;
         double L = 0;
-        for (int i = 0; i < n_c; i++) L = L + fabs(lc[i]);                  // :68
-        if (L >= MAX_LENGTH) continue;                                      // :70
+        L = L + fabs(c0); L = L + fabs(c1); L = L + fabs(c2);
+        if (n_c > 3) L = L + fabs(c3);
+        if (n_c > 4) L = L + fabs(c4);
+        if (L >= MAX_LENGTH) continue;                     // :70
         kept |= 1ull << c;
         if (lane == c) myL = L;
     }
     const int n_paths = __popcll(kept);
-    if (n_paths == 0) return;                                               // find_rs_path :427-428
+    if (lane == 0) p.rs_nwords[slot] = n_paths;
+    if (n_paths == 0) return;                              // find_rs_path :427-428
 
     // ---- path.L / maxc (calc_all_paths :52) and heapdict pop order ----------------------------------
     const double myLm = myL / MAXC;
-    if ((kept >> lane) & 1) scr[RS_LM + lane] = myLm;
-    wsync();
+    if ((kept >> lane) & 1) scr[RSA_LM + lane] = myLm;
+    __syncthreads();
     if (lane == 0) {
-        double* pr = scr + RS_PR;
+        double* pr = scr + RSA_PR;
         int hn = 0;
         for (int c = 0; c < NCAND; c++) {                 // costQueue[path] = path.L in path order (:432-433)
             if (!((kept >> c) & 1)) continue;
             int i = hn++;
-            pr[i] = scr[RS_LM + c]; hid[i] = c;
+            pr[i] = scr[RSA_LM + c]; hid[i] = c;
             while (i) {                                   // _decrease_key: swap unless parent < child
                 int parent = (i - 1) >> 1;
                 if (pr[parent] < pr[i]) break;
@@ -439,7 +485,7 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
         }
         int no = 0;
         while (hn > 0) {                                  // popitem
-            order[no++] = hid[0];
+            order[hid[0]] = no++;
             if (hn == 1) { hn = 0; break; }
             hn--;
             pr[0] = pr[hn]; hid[0] = hid[hn];
@@ -455,30 +501,94 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
             }
         }
     }
-    wsync();
+    __syncthreads();
+    if ((kept >> lane) & 1) {                             // lane c writes its word at its pop rank
+        RsWord* w = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE + order[lane];
+        w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
+        w->Lm = myLm; w->code = code; w->n = wn;
+    }
+}
 
-    // ---- find_rs_path main loop (:436-450) --------------------------------------------------------------
+// ================================================================================================
+// Kernel B: find_rs_path's main loop (:436-450) over the ordered words
+// ================================================================================================
+// LDS (doubles): tile 8*M | obstacle boxes 4*M | segment params 5 x 8 | sample queue pd[128] | ints: seg[128], cand[M]
+constexpr int RSB_SEG = 0, RSB_QPD = 40, RSB_WORDS = 168;
+constexpr int RSB_QCAP = 128;
+
+__global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;
+    if (slot >= *p.rs_count) return;
+    const int n_paths = p.rs_nwords[slot];
+    if (n_paths == 0) return;
+    const int scene = p.rs_list[slot];
+    double* tile = lds;
+    double* obb = lds + 8 * p.max_obst;
+    double* scr = lds + 12 * p.max_obst;
+    double* segp = scr + RSB_SEG;
+    double* qpd = scr + RSB_QPD;
+    int* qseg = (int*)(scr + RSB_WORDS);
+    int* cand = qseg + RSB_QCAP;
+
+    const int n_obst = p.n_obst[scene];
+    {
+        const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
+        double2* dst = (double2*)tile;
+        for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
+        for (int o = lane; o < n_obst; o += WAVE) {           // obstacle boxes (xmin, xmax, ymin, ymax)
+            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
+            obb[4 * o] = fmin(fmin(v[0], v[2]), fmin(v[4], v[6]));
+            obb[4 * o + 1] = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+            obb[4 * o + 2] = fmin(fmin(v[1], v[3]), fmin(v[5], v[7]));
+            obb[4 * o + 3] = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+        }
+    }
+    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+    const double* st = p.state + (size_t)scene * ST_WORDS;
+    const double q0x = st[0], q0y = st[1], q0w = st[2];
+    const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
     const double c_q = cos(-q0w), s_q = sin(-q0w);
     const double step = RS_STEP * MAXC;                   // step_size * maxc (:44)
+    wsync();
+
+    // one full collision pass over the first k queued samples (k <= 64)
+    auto run_batch = [&](int k) -> bool {
+        const bool active = lane < k;
+        double px = 0, py = 0, pyaw = 0;
+        if (active) {
+            const double pd = qpd[lane];
+            const double* sp_ = segp + 8 * qseg[lane];
+            const int m = (int)sp_[7];
+            interpolate(pd, m, sp_[0], sp_[1], sp_[2], sp_[5], sp_[6], sp_[3], sp_[4], px, py, pyaw);
+        }
+        const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
+        const double wy = -s_q * px + c_q * py + q0y;
+        const double wyaw = pi_2_pi(pyaw + q0w);
+        return __any(pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane));
+    };
+
+    const RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
     double min_path_len = -1;
-    int found_c = -1;
+    int found = -1;
     for (int idx = 1; idx <= n_paths; idx++) {
-        const int pc = order[idx - 1];
-        const double Lm = scr[RS_LM + pc];
+        const RsWord* W = words + (idx - 1);
+        const double Lm = W->Lm;
         if (min_path_len < 0) min_path_len = Lm;
-        if (Lm > 1.6 * min_path_len && idx > 2) break;
-        const int code = __shfl(w.code, pc);
-        const int nseg = __shfl(w.n, pc);
+        if (Lm > 1.6 * min_path_len && idx > 2) break;    // :443
+        const int code = W->code, nseg = W->n;
         double len[5];
 #pragma unroll
-        for (int i = 0; i < 5; i++) len[i] = __shfl(w.len[i], pc);
+        for (int i = 0; i < 5; i++) len[i] = W->len[i];
 
-        // generate_local_course (:452-507) + world transform (:47-49) + is_traj_valid, 64 samples per pass
+        // generate_local_course (:452-507).  Samples are queued as (pd, segment) and collision-tested 64 at a
+        // time, so short segments share a pass.  Sample 0 (the start pose, local (0,0,0)) = segment 0 at pd = 0.
         bool invalid = false;
-        double ox = 0, oy = 0, oyaw = 0;                  // local-frame origin of the current segment
+        int nq = 0;
+        double ox = 0, oy = 0, oyaw = 0;
         double d = len[0] > 0.0 ? step : -step;
         double pd = d, ll = 0.0;
-        double ex = 0, ey = 0, eyaw = 0;                  // end point of the current segment
         for (int i = 0; i < nseg && !invalid; i++) {
             const int m = type_of(code, i);
             const double l = len[i];
@@ -487,54 +597,84 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
             double s_oy, c_oy;
             sincos(oyaw, &s_oy, &c_oy);
             const double c_noy = cos(-oyaw), s_noy = sin(-oyaw);
+            wsync();
+            if (lane == 0) {
+                double* sp_ = segp + 8 * i;
+                sp_[0] = ox; sp_[1] = oy; sp_[2] = oyaw; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_noy; sp_[6] = s_noy;
+                sp_[7] = (double)m;
+                if (i == 0) { qpd[0] = 0.0; qseg[0] = 0; }
+            }
+            if (i == 0) nq = 1;
             for (;;) {
-                // `pd += d` chain: every lane walks it, lane j keeps the value after j additions
-                double mine = pd, t = pd;
-                for (int j = 0; j < WAVE; j++) {
-                    if (lane == j) mine = t;
-                    t = t + d;
+                // `pd += d` chain (sequential rounding kept): every lane walks it, lane j keeps the value after
+                // j additions; the walk stops at the first block of 8 whose last value already left the segment
+                double mine = pd, t = pd, last = pd;
+                int ncap = 0;
+                for (int j0 = 0; j0 < WAVE; j0 += 8) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        if (lane == j0 + jj) mine = t;
+                        last = t;
+                        t = t + d;
+                    }
+                    ncap = j0 + 8;
+                    if (__any(fabs(last) > fabs(l))) break;
                 }
-                const bool in_seg = fabs(mine) <= fabs(l);
-                unsigned long long mk = __ballot(in_seg);
-                const int count = (~mk == 0ull) ? WAVE : (__ffsll((long long)~mk) - 1);
-                const bool active = lane < count;
-                double px = 0, py = 0, pyaw = 0;
-                if (active) interpolate(mine, m, ox, oy, oyaw, c_noy, s_noy, c_oy, s_oy, px, py, pyaw);
-                double wx = c_q * px + s_q * py + q0x;
-                double wy = -s_q * px + c_q * py + q0y;
-                double wyaw = pi_2_pi(pyaw + q0w);
-                bool bad = pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane);
-                if (__any(bad)) { invalid = true; break; }
-                if (count < WAVE) { pd = __shfl(mine, count); break; }
-                pd = t;
+                const bool in_seg = lane < ncap && fabs(mine) <= fabs(l);
+                const unsigned long long valid = (ncap == WAVE) ? ~0ull : ((1ull << ncap) - 1);
+                const unsigned long long fail = ~__ballot(in_seg) & valid;
+                const int count = fail ? (__ffsll((long long)fail) - 1) : ncap;
+                wsync();
+                if (lane < count) { qpd[nq + lane] = mine; qseg[nq + lane] = i; }
+                nq += count;
+                wsync();
+                if (nq >= WAVE) {
+                    if (run_batch(WAVE)) { invalid = true; break; }
+                    const int rest = nq - WAVE;               // < 64: shift the remainder to the front
+                    double tp = 0; int ts = 0;
+                    if (lane < rest) { tp = qpd[WAVE + lane]; ts = qseg[WAVE + lane]; }
+                    wsync();
+                    if (lane < rest) { qpd[lane] = tp; qseg[lane] = ts; }
+                    nq = rest;
+                    wsync();
+                }
+                if (count < ncap || fail) { pd = __shfl(mine, count); break; }   // first value outside the segment
+                pd = t;                                       // all 64 inside: keep walking
             }
             if (invalid) break;
             ll = l - pd - d;                              // "calc remain length" (:494)
+            double ex, ey, eyaw;
             interpolate(l, m, ox, oy, oyaw, c_noy, s_noy, c_oy, s_oy, ex, ey, eyaw);
             ox = ex; oy = ey; oyaw = eyaw;
+            if (i == nseg - 1) {                          // the final end point is the only segment end kept
+                wsync();
+                if (lane == 0) { qpd[nq] = l; qseg[nq] = i; }
+                nq += 1;
+                wsync();
+            }
         }
         if (!invalid) {
-            // the start pose (index 0, local (0,0,0)) and the final end point (the only segment end
-            // that is not overwritten by the next segment's first sample)
-            double px = lane == 0 ? 0.0 : ex, py = lane == 0 ? 0.0 : ey, pyaw = lane == 0 ? 0.0 : eyaw;
-            double wx = c_q * px + s_q * py + q0x;
-            double wy = -s_q * px + c_q * py + q0y;
-            double wyaw = pi_2_pi(pyaw + q0w);
-            bool bad = pose_hits(lane < 2, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane);
-            if (__any(bad)) invalid = true;
+            while (nq > 0 && !invalid) {
+                const int k = nq < WAVE ? nq : WAVE;
+                if (run_batch(k)) { invalid = true; break; }
+                const int rest = nq - k;
+                double tp = 0; int ts = 0;
+                if (lane < rest) { tp = qpd[k + lane]; ts = qseg[k + lane]; }
+                wsync();
+                if (lane < rest) { qpd[lane] = tp; qseg[lane] = ts; }
+                nq = rest;
+                wsync();
+            }
         }
-        if (!invalid) { found_c = pc; break; }
+        if (!invalid) { found = idx - 1; break; }
     }
-    if (found_c < 0) return;
+    if (found < 0) return;
 
     // ---- output: PATH.ctypes / PATH.lengths (metres) of the first collision-free path ----------------
-    const int code = __shfl(w.code, found_c);
-    const int nseg = __shfl(w.n, found_c);
-    double lenv = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) { double v = __shfl(w.len[i], found_c); if (lane == i) lenv = v; }
+    const RsWord* W = words + found;
+    const int code = W->code, nseg = W->n;
     if (lane < 5) {
-        double lm = lane < nseg ? lenv / MAXC : 0.0;      // path.lengths = [l / maxc ...] (:51)
+        double lm = lane < nseg ? W->len[lane] / MAXC : 0.0;      // path.lengths = [l / maxc ...] (:51)
         if (p.rs_lengths) {
             if (obs_f64) ((double*)p.rs_lengths)[5 * (size_t)scene + lane] = lm;
             else ((float*)p.rs_lengths)[5 * (size_t)scene + lane] = (float)lm;
@@ -547,17 +687,21 @@ __global__ __launch_bounds__(64) void k_rs_search(RsParams p, int obs_f64) {
 
 }  // namespace
 
-size_t rs_lds_bytes(int max_obst) { return (size_t)(12 * max_obst + RS_WORDS) * 8 + (size_t)(128 + ((max_obst + 3) & ~3)) * 4; }
+size_t rs_lds_bytes(int max_obst) {
+    return (size_t)(12 * max_obst + RSB_WORDS) * 8 + (size_t)(RSB_QCAP + ((max_obst + 3) & ~3)) * 4;
+}
+size_t rs_words_bytes_per_scene() { return sizeof(RsWord) * RS_WORDS_PER_SCENE; }
 
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream) {
     size_t lds = rs_lds_bytes(p.max_obst);
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_rs_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_rs_search, dim3(p.n), dim3(WAVE), lds, stream, p, p.obs_f64);
+    hipLaunchKernelGGL(k_rs_words, dim3(p.n), dim3(WAVE), 0, stream, p);
+    hipLaunchKernelGGL(k_rs_validate, dim3(p.n), dim3(WAVE), lds, stream, p, p.obs_f64);
     return hipGetLastError();
 }
 
