@@ -306,7 +306,6 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     p.out = *out;
     p.rs_count = h->rs_count; p.rs_list = h->rs_list;
     if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, sizeof(int32_t), s));
-    size_t lds = step_lds_bytes(h->max_obst);
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 grid(h->n), block(WAVE);
     const bool prof = h->flags & HOPE_F_PROFILE;
@@ -317,10 +316,19 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         if (!ea || !eb) return fail(HOPE_EHIP, "hipEventCreate failed");
         HIPCHK(hipEventRecord(ea, s));
     }
-    if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
-    else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, s, p);
-    else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, s, p);
+    // one launch per tile class: scenes with few obstacles get a small LDS tile and therefore more resident
+    // waves; a wave whose scene belongs to the other class exits at once
+    const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
+    for (int c = 0; c < n_cls; c++) {
+        p.cls_lo = (c == 0) ? -1 : SMALL_TILE;
+        p.cls_hi = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
+        p.tile_cap = p.cls_hi;
+        size_t lds = step_lds_bytes(p.tile_cap);
+        if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
+        else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, s, p);
+        else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, s, p);
+    }
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(eb, s)); h->pending.push_back({ea, eb, 0}); }
     if ((stages & HOPE_STAGE_RS) && out->rs_word) {

@@ -584,27 +584,62 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
 
         // generate_local_course (:452-507).  Samples are queued as (pd, segment) and collision-tested 64 at a
         // time, so short segments share a pass.  Sample 0 (the start pose, local (0,0,0)) = segment 0 at pd = 0.
+        //
+        // Segment origins first.  The origin headings are plain sums (oyaw_{i+1} = oyaw_i +- l_i), so every
+        // sine/cosine the path needs -- of the five origin headings and of the five segment lengths (for the
+        // segment end points, interpolate(ind, l, ...) :497-498) -- comes from ONE lane-parallel sincos
+        // (lanes 0-4: headings, lanes 5-9: lengths); cos(-x) = cos x and sin(-x) = -sin x give :522-523.
         bool invalid = false;
-        int nq = 0;
-        double ox = 0, oy = 0, oyaw = 0;
+        {
+            double hy[5];
+            hy[0] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = type_of(code, i);
+                hy[i + 1] = (m == TL) ? hy[i] + len[i] : ((m == TR) ? hy[i] - len[i] : hy[i]);
+            }
+            double arg = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (lane == i) arg = hy[i];
+                if (lane == 5 + i) arg = len[i];
+            }
+            double sv, cv;
+            sincos(arg, &sv, &cv);
+            double ox = 0, oy = 0;
+            wsync();
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (i < nseg) {
+                    const int m = type_of(code, i);
+                    const double c_oy = __shfl(cv, i), s_oy = __shfl(sv, i);
+                    const double sl = __shfl(sv, 5 + i), cl = __shfl(cv, 5 + i);
+                    if (lane == 0) {
+                        double* sp_ = segp + 8 * i;
+                        sp_[0] = ox; sp_[1] = oy; sp_[2] = hy[i]; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_oy; sp_[6] = -s_oy;
+                        sp_[7] = (double)m;
+                    }
+                    const double l = len[i];
+                    if (m == TS) {                                   // interpolate(l) = next origin (:512-513)
+                        ox = ox + l / MAXC * c_oy;
+                        oy = oy + l / MAXC * s_oy;
+                    } else {
+                        const double ldx = sl / MAXC;
+                        const double ldy = (m == TL) ? (1.0 - cl) / MAXC : (1.0 - cl) / (-MAXC);
+                        ox = ox + (c_oy * ldx + (-s_oy) * ldy);
+                        oy = oy + (s_oy * ldx + c_oy * ldy);
+                    }
+                }
+            }
+            if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
+        }
+        int nq = 1;
         double d = len[0] > 0.0 ? step : -step;
         double pd = d, ll = 0.0;
         for (int i = 0; i < nseg && !invalid; i++) {
-            const int m = type_of(code, i);
             const double l = len[i];
             d = l > 0.0 ? step : -step;
             if (i >= 1 && (len[i - 1] * len[i]) > 0) pd = -d - ll; else pd = d - ll;
-            double s_oy, c_oy;
-            sincos(oyaw, &s_oy, &c_oy);
-            const double c_noy = cos(-oyaw), s_noy = sin(-oyaw);
-            wsync();
-            if (lane == 0) {
-                double* sp_ = segp + 8 * i;
-                sp_[0] = ox; sp_[1] = oy; sp_[2] = oyaw; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_noy; sp_[6] = s_noy;
-                sp_[7] = (double)m;
-                if (i == 0) { qpd[0] = 0.0; qseg[0] = 0; }
-            }
-            if (i == 0) nq = 1;
             for (;;) {
                 // `pd += d` chain (sequential rounding kept): every lane walks it, lane j keeps the value after
                 // j additions; the walk stops at the first block of 8 whose last value already left the segment
@@ -638,14 +673,11 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
                     nq = rest;
                     wsync();
                 }
-                if (count < ncap || fail) { pd = __shfl(mine, count); break; }   // first value outside the segment
+                if (fail) { pd = __shfl(mine, count); break; }   // first value outside the segment
                 pd = t;                                       // all 64 inside: keep walking
             }
             if (invalid) break;
             ll = l - pd - d;                              // "calc remain length" (:494)
-            double ex, ey, eyaw;
-            interpolate(l, m, ox, oy, oyaw, c_noy, s_noy, c_oy, s_oy, ex, ey, eyaw);
-            ox = ex; oy = ey; oyaw = eyaw;
             if (i == nseg - 1) {                          // the final end point is the only segment end kept
                 wsync();
                 if (lane == 0) { qpd[nq] = l; qseg[nq] = i; }

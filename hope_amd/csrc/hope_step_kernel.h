@@ -20,7 +20,9 @@
 namespace hope {
 
 struct StepParams {
-    int n, max_obst;
+    int n, max_obst;          // max_obst = HBM tile stride (obstacle slots per scene)
+    int tile_cap;             // LDS tile capacity of THIS launch (obstacles)
+    int cls_lo, cls_hi;       // this launch serves scenes with cls_lo < n_obst <= cls_hi
     uint32_t stages;
     int has_action;
     const double* verts;      // [n][max_obst][4][2]
@@ -39,13 +41,18 @@ struct StepParams {
     int32_t* rs_list;         // [n]
 };
 
-// LDS per wave (doubles): tile 8*max_obst | tx[200] ty[200] (the heading chain hs[201] aliases ty.. first) |
-//   hb[10] cb[10] sb[10] px[10] py[10] | sh[64] | x[121]+pad | dest box[8] | w2[10] | ints: near / keep list
-constexpr int LDS_TX = 0, LDS_TY = 200, LDS_HB = 402, LDS_CB = 412, LDS_SB = 422, LDS_PX = 432, LDS_PY = 442,
-              LDS_SH = 452, LDS_X = 516, LDS_DBOX = 640, LDS_W2 = 648, LDS_KEEP = 658, LDS_SCRATCH_WORDS = 658;
-__host__ __device__ inline size_t step_lds_bytes(int max_obst) {
-    return (size_t)(8 * max_obst + LDS_SCRATCH_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4;
+// LDS per wave (doubles): tile 8*tile_cap | region A [402] | hb[10] cb[10] sb[10] px[10] py[10] | dest box[8] |
+//   w2[10] | ints: near / keep list.  Region A is reused by the phases in turn:
+//     kinematics: tx[200] ty[200] (the heading chain hs[201] aliases ty.. first)
+//     arrival   : sh[64]  Sutherland-Hodgman scratch (tx/ty are dead once px/py exist)
+//     lidar     : best[128] u64 + queue[384] i32
+//     mask      : x[121]
+constexpr int LDS_TX = 0, LDS_TY = 200, LDS_SH = 0, LDS_X = 0, LDS_HB = 402, LDS_CB = 412, LDS_SB = 422, LDS_PX = 432,
+              LDS_PY = 442, LDS_DBOX = 452, LDS_W2 = 460, LDS_KEEP = 470, LDS_SCRATCH_WORDS = 470;
+__host__ __device__ inline size_t step_lds_bytes(int tile_cap) {
+    return (size_t)(8 * tile_cap + LDS_SCRATCH_WORDS) * 8 + (size_t)((tile_cap + 3) & ~3) * 4;
 }
+constexpr int SMALL_TILE = 32;   // scenes with <= 32 obstacles run in a launch with a 2 KB tile (higher occupancy)
 
 // GEOS Area::ofRingSigned over an open vertex list (ring closed implicitly); lane-0 code, LDS arrays
 __device__ __forceinline__ double ring_area_signed_lds(const double* px, const double* py, int n) {
@@ -218,20 +225,22 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 }
 
 template <typename OT, typename AT>
-__global__ __launch_bounds__(64) void k_env_step(StepParams p) {
+__global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int scene = blockIdx.x;
     if (scene >= p.n) return;
     if (p.active && !p.active[scene]) return;
 
+    const int n_obst = p.n_obst[scene];
+    if (n_obst <= p.cls_lo || n_obst > p.cls_hi) return;          // served by the launch of the other tile class
+
     double* tile = lds;
-    double* scr = lds + 8 * p.max_obst;
+    double* scr = lds + 8 * p.tile_cap;
     int* keep = (int*)(scr + LDS_KEEP);
 
     // ---- stage the scene: constants (192 B), state (32 B), obstacle tile (64 B x n_obst) ---------
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
-    const int n_obst = p.n_obst[scene];
     const int n_slots = 4 * n_obst;
     {
         const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
@@ -550,6 +559,7 @@ __global__ __launch_bounds__(64) void k_env_step(StepParams p) {
     if (!p.out.action_mask || (p.stages & 0x2000)) return;    // 0x2000: internal profiling switch
 
     // ---- action mask (action_mask.py:166-196) ----------------------------------------------------------
+    wsync();                                                      // region A: best[]/queue[] are dead from here
     double* xs = scr + LDS_X;                                     // lidar_obs = clip(raw,0,10) + base (:170)
     xs[i0] = clipd(lid0, 0, 10) + base0;
     if (has1) xs[i1] = clipd(lid1, 0, 10) + base1;
