@@ -521,29 +521,60 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 int e2 = (e & ~3) | ((e + 1) & 3);
                 double x1 = tile[2 * e], y1 = tile[2 * e + 1], x2 = tile[2 * e2], y2 = tile[2 * e2 + 1];
                 double d = y2 - y1, ee = x1 - x2, f = y1 * x2 - x1 * y2;
-                double r = beam_edge(bi, p.beam_ab[2 * bi], p.beam_ab[2 * bi + 1], x1, y1, x2, y2, d, ee, f);
+                const double ba = p.beam_ab[2 * bi], bb = p.beam_ab[2 * bi + 1];
+                double r = INFINITY;
+                if (beam_may_hit(ba, bb, x1, y1, x2, y2)) r = beam_edge(bi, ba, bb, x1, y1, x2, y2, d, ee, f);
                 if (r < INFINITY) atomicMin(&best[bi], (unsigned long long)__double_as_longlong(r));
             }
         }
         wsync();
         qn = 0;
     };
-    for (int r = 0; r < n_obst; r++) {
-        if (!keep[r] || (p.stages & 0x1000)) continue;       // 0x1000: internal profiling switch (tools/stage_times.py)
+    // pass 1, one lane per edge slot: the beams that can see an edge are those inside the angle it subtends at
+    // the sensor (a segment not through the origin subtends < pi).  The range is taken from float32 atan2 with
+    // a 2e-3 rad margin on both sides (beam pitch 5.2e-2 rad), so it is a superset of the reference's hits;
+    // pass 2 applies the exact tests.  An edge whose span is ill-defined (passes within ~1e-2 rad of the origin
+    // direction flip) is paired with all 120 beams.
+    {
+        const float PITCH = 6.283185307179586f / NBEAM, MARGIN = 2e-3f;
+        for (int base = 0; base < n_slots && !(p.stages & 0x1000); base += WAVE) {   // 0x1000: profiling switch
+            const int e = base + lane;
+            int lo = 0, cnt = 0;
+            if (e < n_slots && keep[e >> 2]) {
+                const int e2 = (e & ~3) | ((e + 1) & 3);
+                const float x1 = (float)tile[2 * e], y1 = (float)tile[2 * e + 1];
+                const float x2 = (float)tile[2 * e2], y2 = (float)tile[2 * e2 + 1];
+                const float t1 = atan2f(y1, x1), t2 = atan2f(y2, x2);
+                float dth = t2 - t1;
+                if (dth > 3.14159265f) dth -= 6.28318531f;
+                if (dth <= -3.14159265f) dth += 6.28318531f;
+                const float span = fabsf(dth);
+                if (span > 3.13f || !(span == span)) { lo = 0; cnt = NBEAM; }
+                else {
+                    float ts = dth >= 0 ? t1 : t2;                  // start of the arc, counter-clockwise
+                    if (ts < 0) ts += 6.28318531f;
+                    const int ilo = (int)floorf((ts - MARGIN) / PITCH);
+                    const int ihi = (int)ceilf((ts + span + MARGIN) / PITCH);
+                    cnt = ihi - ilo + 1;
+                    if (cnt > NBEAM) cnt = NBEAM;
+                    lo = ((ilo % NBEAM) + NBEAM) % NBEAM;
+                }
+            }
+            int kmax = cnt;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int e = 4 * r + j, e2 = 4 * r + ((j + 1) & 3);
-            double x1 = tile[2 * e], y1 = tile[2 * e + 1], x2 = tile[2 * e2], y2 = tile[2 * e2 + 1];
-            bool c0 = beam_may_hit(a0, b0, x1, y1, x2, y2);
-            bool c1 = has1 && beam_may_hit(a1, b1, x1, y1, x2, y2);
-            unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
-            const unsigned long long lt = (1ull << lane) - 1;
-            if (c0) queue[qn + __popcll(m0 & lt)] = (e << 7) | i0;
-            qn += __popcll(m0);
-            if (c1) queue[qn + __popcll(m1 & lt)] = (e << 7) | i1;
-            qn += __popcll(m1);
+            for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+            for (int k = 0; k < kmax; k++) {
+                const bool c = k < cnt;
+                const unsigned long long m = __ballot(c);
+                if (c) {
+                    int bi = lo + k;
+                    if (bi >= NBEAM) bi -= NBEAM;
+                    queue[qn + __popcll(m & ((1ull << lane) - 1))] = (e << 7) | bi;
+                }
+                qn += __popcll(m);
+                if (qn > LQ - WAVE) drain();
+            }
         }
-        if (qn > LQ - 4 * 2 * WAVE) drain();                                  // room for one more ring
     }
     if (qn > 0) drain();
     const double best0 = __longlong_as_double((long long)best[i0]);

@@ -18,11 +18,16 @@ TOL32 = 2e-5
 
 def make_pair(n, seed, obs64=True, max_obst=128, level='dlp'):
     from hope_amd import ParkingBatch
-    from hope_amd.scenes import DlpScenePool, pack_scenes
+    from hope_amd.scenes import DlpScenePool, SceneSource, pack_scenes
     from oracle import oracle as O
-    pool = DlpScenePool()
     rng = np.random.default_rng(seed)
-    scenes = [pool.sample(rng=rng) for _ in range(n)]
+    if level == 'dlp':
+        pool = DlpScenePool()
+        scenes = [pool.sample(rng=rng) for _ in range(n)]
+    else:
+        src = SceneSource(levels=('Normal', 'Complex', 'Extrem', 'dlp') if level == 'mixed' else ('Normal', 'Complex', 'Extrem'),
+                          seed=seed)
+        scenes = [src.draw() for _ in range(n)]
     # half of the scenes start near the destination (tight surroundings, arrival, collisions)
     for k in range(0, n, 2):
         s = scenes[k]
@@ -148,6 +153,54 @@ def test_rs_search_finds_paths_near_goal():
     assert np.abs(env.rs_lengths.cpu().numpy() - o['rs_lengths']).max() < TOL64
     print('rs found', int(o['rs_found'].sum()), 'of', n)
     assert o['rs_found'].sum() >= 10
+    env.close()
+
+
+def test_step_parity_generated_levels_with_rs():
+    """Normal / Complex / Extrem scenes from hope_amd.scenes.generate_scene (axis-aligned walls: the
+    tolerance-free box tests of the lidar and of is_traj_valid are at their most fragile here) + DLP,
+    small and large tile classes in one batch; full step incl. the RS search."""
+    env, orc, rng = make_pair(768, seed=31, level='mixed')
+    s = rollout(env, orc, rng, steps=16, tol=TOL64, with_rs=True)
+    print('parity mixed levels + RS:', s)
+    assert s['status_mismatch'] == 0 and s['mask_mismatch'] == 0
+    assert s['rs_flag_mismatch'] == 0 and s['rs_word_mismatch'] == 0 and s['rs_len_err'] < TOL64
+    assert s['pose_err'] < TOL64 and s['lidar_err'] < TOL64 and s['reward_err'] < TOL64
+    env.close()
+
+
+def test_restart_and_profile_api():
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scenes import SceneSource
+    src = SceneSource(seed=3)
+    n = 96
+    env = ParkingBatch(n, 128, profile=True)
+    scenes = [src.draw() for _ in range(n)]
+    env.set_scenes(np.arange(n), scenes)
+    env.reset_obs()
+    g = torch.Generator(device=env.device); g.manual_seed(1)
+    for _ in range(5):
+        env.step(torch.rand((n, 2), generator=g, device=env.device) * 2 - 1)
+    torch.cuda.synchronize()
+    pose, t, acc = env.download_state()
+    assert (t == 6).all()
+    mask = torch.zeros(n, dtype=torch.uint8, device=env.device)
+    mask[::3] = 1
+    env.restart(mask)
+    env.reset_obs(active=mask)
+    torch.cuda.synchronize()
+    pose2, t2, acc2 = env.download_state()
+    start = np.array([s.start for s in scenes])
+    assert np.array_equal(pose2[::3], start[::3]) and (t2[::3] == 1).all() and (acc2[::3] >= 0).all()
+    assert np.array_equal(pose2[1::3], pose[1::3]) and (t2[1::3] == 6).all()
+    sm, sn, rm, rn = env.kernel_ms()
+    assert sn == 7 and rn == 7 and sm > 0 and rm > 0          # 1 reset_obs + 5 steps + 1 masked reset_obs
+    sm2, sn2, _, _ = env.kernel_ms()
+    assert sn2 == 0 and sm2 == 0
+    # state upload round trip
+    env.upload_state(pose=pose, t=t, accum=acc)
+    p3, t3, a3 = env.download_state()
+    assert np.array_equal(p3, pose) and np.array_equal(t3, t) and np.array_equal(a3, acc)
     env.close()
 
 
