@@ -127,7 +127,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    step_ms, step_n, rs_ms, rs_n = env.kernel_ms(reset=True)
+    kstats = env.kernel_ms(reset=True)
     done_frac = float(env.done.float().mean().item())
     rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
     if dist is not None:
@@ -139,13 +139,17 @@ def main():
     if rank == 0:
         total_scenes = N * world
         value = total_scenes * args.steps / elapsed
-        # dominant kernel = the one with the larger accumulated HIP-event time.  step launches include
-        # the (active-masked) reset_obs launches, so average over "full" launches only: args.steps of them
-        # carry the whole batch; the masked ones are counted into the same accumulated time (conservative).
-        k_step = step_ms / max(args.steps, 1)
-        k_rs = rs_ms / max(args.steps, 1)
-        dom, dom_ms = ('k_env_step', k_step) if k_step >= k_rs else ('k_rs_search', k_rs)
-        achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # Per-kernel HIP-event statistics recorded by the library around EVERY launch on the launch stream.
+        # Dominant kernel = largest accumulated time.  `kernel_ms` is its AVERAGE LAUNCH duration (directly
+        # comparable with rocprofv3's AverageNs for that kernel: k_env_step is launched once per tile class for the
+        # step and once per class for the active-masked reset observation, i.e. 4 launches per bench step);
+        # `algorithmic bytes per launch` is averaged over the same launches, so achieved = bytes/launch / kernel_ms.
+        per_step = {k: v[0] / max(args.steps, 1) for k, v in kstats.items()}
+        dom = max(per_step, key=per_step.get)
+        dom_total_ms, dom_launches = kstats[dom]
+        dom_ms = dom_total_ms / max(dom_launches, 1)
+        bytes_avg_launch = bytes_per_launch * args.steps / max(dom_launches, 1)
+        achieved = bytes_avg_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         if os.path.exists(pmc):
@@ -164,8 +168,10 @@ def main():
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'kernel': dom,
-                         'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'k_env_step_ms_per_step': k_step, 'k_rs_search_ms_per_step': k_rs},
+                         'kernel_ms': dom_ms, 'kernel_launches': dom_launches,
+                         'algorithmic_bytes_per_launch': bytes_avg_launch,
+                         'algorithmic_bytes_per_bench_step': bytes_per_launch,
+                         'ms_per_bench_step_by_kernel': per_step},
         }
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(args, uniq, stages)

@@ -9,6 +9,7 @@ LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10,
 F_OBS_F64, F_ACTION_F64, F_PROFILE = 0x1, 0x2, 0x4
 STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 ACTION_PHYSICAL = 0x10
+KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate')
 ABI_VERSION = 1
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',
@@ -62,8 +63,7 @@ def load_library():
     L.hope_env_download_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hope_env_upload_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hope_env_restart.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.hope_env_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
-                                     C.POINTER(C.c_int64), C.c_int]
+    L.hope_env_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.hope_env_num_scenes.argtypes = [C.c_void_p]
     L.hope_env_max_obstacles.argtypes = [C.c_void_p]
     if L.hope_abi_version() != ABI_VERSION:

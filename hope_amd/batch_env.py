@@ -95,11 +95,11 @@ class ParkingBatch:
         return self
 
     def kernel_ms(self, reset=True):
-        """(step_ms, step_launches, rs_ms, rs_launches) from in-library HIP events (profile=True)."""
-        a, b, c, d = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_int64(0)
-        L.check(self.lib.hope_env_kernel_ms(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), int(reset)),
-                'hope_env_kernel_ms')
-        return a.value, b.value, c.value, d.value
+        """{kernel name: (accumulated ms, launches)} from the library's per-launch HIP events (profile=True)."""
+        ms = np.zeros(len(L.KERNELS))
+        cnt = np.zeros(len(L.KERNELS), np.int64)
+        L.check(self.lib.hope_env_kernel_ms(self.h, ms.ctypes.data, cnt.ctypes.data, int(reset)), 'hope_env_kernel_ms')
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(L.KERNELS)}
 
     def obs(self):
         return {'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}

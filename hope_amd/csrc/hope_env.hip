@@ -45,6 +45,7 @@ struct hope_env {
     double* beam_ab = nullptr;
     int32_t* rs_count = nullptr;
     int32_t* rs_list = nullptr;
+    double* kin = nullptr;
     void* rs_words = nullptr;
     int32_t* rs_nwords = nullptr;
     // staging for set_scenes
@@ -54,8 +55,8 @@ struct hope_env {
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[2] = {0, 0};
-    int64_t launches[2] = {0, 0};
+    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0};
+    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0};
 };
 
 static hipEvent_t get_event(hope_env* h) {
@@ -64,6 +65,23 @@ static hipEvent_t get_event(hope_env* h) {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+struct EventTimer : LaunchTimer {
+    hope_env* h;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind = 0;
+    bool failed = false;
+    explicit EventTimer(hope_env* h_) : h(h_) {}
+    void begin(int k, hipStream_t s) override {
+        kind = k;
+        a = get_event(h); b = get_event(h);
+        if (!a || !b || hipEventRecord(a, s) != hipSuccess) failed = true;
+    }
+    void end(hipStream_t s) override {
+        if (failed || hipEventRecord(b, s) != hipSuccess) { failed = true; return; }
+        h->pending.push_back({a, b, kind});
+    }
+};
+
 static int drain_events(hope_env* h) {
     for (auto& p : h->pending) {
         float ms = 0;
@@ -185,6 +203,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
     ALLOC(h->rs_count, sizeof(int32_t));
     ALLOC(h->rs_list, N * sizeof(int32_t));
+    ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
     ALLOC(h->rs_words, N * rs_words_bytes_per_scene());
     ALLOC(h->rs_nwords, N * sizeof(int32_t));
 #undef ALLOC
@@ -210,7 +229,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_words, h->rs_nwords, h->stage};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->rs_words, h->rs_nwords, h->stage};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -301,7 +320,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     StepParams p;
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
     p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
-    p.actions = actions; p.active = active;
+    p.actions = actions; p.active = active; p.kin = h->kin;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
     p.rs_count = h->rs_count; p.rs_list = h->rs_list;
@@ -309,12 +328,15 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 grid(h->n), block(WAVE);
     const bool prof = h->flags & HOPE_F_PROFILE;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    if (prof) {
-        if (h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
-        ea = get_event(h); eb = get_event(h);
-        if (!ea || !eb) return fail(HOPE_EHIP, "hipEventCreate failed");
-        HIPCHK(hipEventRecord(ea, s));
+    if (prof && h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
+    EventTimer timer(h);
+    LaunchTimer* tm = prof ? &timer : nullptr;
+    if ((stages & HOPE_STAGE_MOTION) && has_action) {
+        dim3 kg((h->n + WAVE - 1) / WAVE);
+        if (tm) tm->begin(HOPE_K_KINEMATICS, s);
+        if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
+        else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
+        if (tm) tm->end(s);
     }
     // one launch per tile class: scenes with few obstacles get a small LDS tile and therefore more resident
     // waves; a wave whose scene belongs to the other class exits at once
@@ -324,28 +346,25 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         p.cls_hi = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.tile_cap = p.cls_hi;
         size_t lds = step_lds_bytes(p.tile_cap);
+        if (tm) tm->begin(HOPE_K_STEP, s);
         if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
         else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, s, p);
         else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, s, p);
+        if (tm) tm->end(s);
     }
     HIPCHK(hipGetLastError());
-    if (prof) { HIPCHK(hipEventRecord(eb, s)); h->pending.push_back({ea, eb, 0}); }
     if ((stages & HOPE_STAGE_RS) && out->rs_word) {
-        if (prof) {
-            ea = get_event(h); eb = get_event(h);
-            if (!ea || !eb) return fail(HOPE_EHIP, "hipEventCreate failed");
-            HIPCHK(hipEventRecord(ea, s));
-        }
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
+        r.tile_cap = h->max_obst; r.cls_lo = -1; r.cls_hi = h->max_obst;
         r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
         r.rs_count = h->rs_count; r.rs_list = h->rs_list;
         r.rs_words = (RsWord*)h->rs_words; r.rs_nwords = h->rs_nwords;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
-        HIPCHK(launch_rs_search(r, s));
-        if (prof) { HIPCHK(hipEventRecord(eb, s)); h->pending.push_back({ea, eb, 1}); }
+        HIPCHK(launch_rs_search(r, s, tm));
     }
+    if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
     return HOPE_OK;
 }
 
@@ -359,28 +378,18 @@ int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
     return HOPE_OK;
 }
 
-int hope_env_kernel_ms(hope_env_t* h, double* step_ms, int64_t* step_launches, double* rs_ms, int64_t* rs_launches,
-                       int reset) {
+int hope_env_kernel_ms(hope_env_t* h, double* ms, int64_t* launches, int reset) {
     if (!h) return fail(HOPE_EINVAL, "hope_env_kernel_ms: null handle");
     if (!(h->flags & HOPE_F_PROFILE)) return fail(HOPE_ESTATE, "hope_env_kernel_ms: handle was not created with HOPE_F_PROFILE");
     HIPCHK(hipSetDevice(h->device));
     int rc = drain_events(h);
     if (rc) return rc;
-    if (step_ms) *step_ms = h->ms[0];
-    if (step_launches) *step_launches = h->launches[0];
-    if (rs_ms) *rs_ms = h->ms[1];
-    if (rs_launches) *rs_launches = h->launches[1];
-    if (reset) { h->ms[0] = h->ms[1] = 0; h->launches[0] = h->launches[1] = 0; }
+    for (int k = 0; k < HOPE_N_KERNELS; k++) {
+        if (ms) ms[k] = h->ms[k];
+        if (launches) launches[k] = h->launches[k];
+        if (reset) { h->ms[k] = 0; h->launches[k] = 0; }
+    }
     return HOPE_OK;
-}
-
-int hope_env_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages,
-                  const hope_step_out* out, void* stream) {
-    return launch_step(h, actions, active, stages, out, stream, 1);
-}
-
-int hope_env_reset_obs(hope_env_t* h, const uint8_t* active, uint32_t stages, const hope_step_out* out, void* stream) {
-    return launch_step(h, nullptr, active, stages & ~HOPE_STAGE_MOTION, out, stream, 0);
 }
 
 int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* accum) {

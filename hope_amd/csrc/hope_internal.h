@@ -17,6 +17,7 @@ constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generat
 
 struct RsParams {
     int n, max_obst;
+    int tile_cap, cls_lo, cls_hi;   // LDS tile capacity / obstacle-count class served by this launch
     int obs_f64;
     const double* verts;      // [n][max_obst][4][2] world frame
     const int32_t* n_obst;    // [n]
@@ -30,8 +31,13 @@ struct RsParams {
     void* rs_lengths;         // real [n][5]
 };
 
-// launches the Reeds-Shepp feasibility kernel over the scenes queued in rs_list (hope_rs.hip)
-hipError_t launch_rs_search(const RsParams& p, hipStream_t stream);
+// optional per-launch profiling hook: begin(kind) / end() bracket ONE kernel launch
+struct LaunchTimer {
+    virtual void begin(int kind, hipStream_t s) = 0;
+    virtual void end(hipStream_t s) = 0;
+};
+// launches the Reeds-Shepp feasibility kernels over the scenes queued in rs_list (hope_rs.hip)
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);
 size_t rs_lds_bytes(int max_obst);
 size_t rs_words_bytes_per_scene();
 

@@ -20,6 +20,8 @@
 //      its T x 4 x E matrix are result-neutral and are not materialised.
 // Deviation (documented in DESIGN.md): generate_local_course's "pop trailing samples whose local x is
 // exactly 0.0" (:501-505) is not replayed beyond the unused array tail (a measure-zero event).
+#include <stdlib.h>
+
 #include "hope_dev.h"
 #include "hope_internal.h"
 
@@ -512,27 +514,29 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 // ================================================================================================
 // Kernel B: find_rs_path's main loop (:436-450) over the ordered words
 // ================================================================================================
-// LDS (doubles): tile 8*M | obstacle boxes 4*M | segment params 5 x 8 | sample queue pd[128] | ints: seg[128], cand[M]
-constexpr int RSB_SEG = 0, RSB_QPD = 40, RSB_WORDS = 168;
-constexpr int RSB_QCAP = 128;
+// LDS (doubles): tile 8*M | obstacle boxes 4*M | segment params 5 x 8 | sample queue pd[512] | ints: cand[M] | bytes: seg[512]
+constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_WORDS = 562;
+constexpr int RSB_QCAP = 512;
 
-__global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
+__global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
     if (slot >= *p.rs_count) return;
+    if (obs_f64 & 0x400) return;                          // profiling switch: words kernel only
     const int n_paths = p.rs_nwords[slot];
     if (n_paths == 0) return;
     const int scene = p.rs_list[slot];
+    const int n_obst = p.n_obst[scene];
+    if (n_obst <= p.cls_lo || n_obst > p.cls_hi) return;          // served by the launch of the other tile class
     double* tile = lds;
-    double* obb = lds + 8 * p.max_obst;
-    double* scr = lds + 12 * p.max_obst;
+    double* obb = lds + 8 * p.tile_cap;
+    double* scr = lds + 12 * p.tile_cap;
     double* segp = scr + RSB_SEG;
     double* qpd = scr + RSB_QPD;
-    int* qseg = (int*)(scr + RSB_WORDS);
-    int* cand = qseg + RSB_QCAP;
+    int* cand = (int*)(scr + RSB_WORDS);
+    unsigned char* qseg = (unsigned char*)(cand + ((p.tile_cap + 3) & ~3));
 
-    const int n_obst = p.n_obst[scene];
     {
         const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
         double2* dst = (double2*)tile;
@@ -553,22 +557,6 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
     const double step = RS_STEP * MAXC;                   // step_size * maxc (:44)
     wsync();
 
-    // one full collision pass over the first k queued samples (k <= 64)
-    auto run_batch = [&](int k) -> bool {
-        const bool active = lane < k;
-        double px = 0, py = 0, pyaw = 0;
-        if (active) {
-            const double pd = qpd[lane];
-            const double* sp_ = segp + 8 * qseg[lane];
-            const int m = (int)sp_[7];
-            interpolate(pd, m, sp_[0], sp_[1], sp_[2], sp_[5], sp_[6], sp_[3], sp_[4], px, py, pyaw);
-        }
-        const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
-        const double wy = -s_q * px + c_q * py + q0y;
-        const double wyaw = pi_2_pi(pyaw + q0w);
-        return __any(pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane));
-    };
-
     const RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
     double min_path_len = -1;
     int found = -1;
@@ -577,6 +565,7 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
         const double Lm = W->Lm;
         if (min_path_len < 0) min_path_len = Lm;
         if (Lm > 1.6 * min_path_len && idx > 2) break;    // :443
+        if ((obs_f64 & 0x200) && idx > 1) break;          // profiling switch: first path only
         const int code = W->code, nseg = W->n;
         double len[5];
 #pragma unroll
@@ -615,9 +604,9 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
                     const double c_oy = __shfl(cv, i), s_oy = __shfl(sv, i);
                     const double sl = __shfl(sv, 5 + i), cl = __shfl(cv, 5 + i);
                     if (lane == 0) {
-                        double* sp_ = segp + 8 * i;
+                        double* sp_ = segp + RSB_SEGW * i;
                         sp_[0] = ox; sp_[1] = oy; sp_[2] = hy[i]; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_oy; sp_[6] = -s_oy;
-                        sp_[7] = (double)m;
+                        sp_[7] = (double)m; sp_[8] = len[i];
                     }
                     const double l = len[i];
                     if (m == TS) {                                   // interpolate(l) = next origin (:512-513)
@@ -634,13 +623,28 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
             if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
         }
         int nq = 1;
-        double d = len[0] > 0.0 ? step : -step;
-        double pd = d, ll = 0.0;
-        for (int i = 0; i < nseg && !invalid; i++) {
-            const double l = len[i];
-            d = l > 0.0 ? step : -step;
-            if (i >= 1 && (len[i - 1] * len[i]) > 0) pd = -d - ll; else pd = d - ll;
-            for (;;) {
+        wsync();
+        // Resumable sample generator + ONE window test site.  Samples are appended to the queue until it cannot
+        // take another chunk (or the path ends); then the window is tested coarse-to-fine: a path is invalid as
+        // soon as ANY of its samples is bad, whatever the order they are looked at, and a path that crosses an
+        // obstacle has long runs of bad samples -- so every 8th queued sample goes first (one pass for up to 512
+        // samples) and only clean windows pay for the other seven eighths.  Exact: all of them are real samples
+        // of generate_local_course.
+        // window size: generate <= 130 samples, test them, continue (measured best of 66/130/258/512: larger windows
+        // lose the early exit on invalid paths, smaller ones pay more partially filled passes)
+        const int win = (obs_f64 >> 12) ? (obs_f64 >> 12) : 130;
+        int i = 0;
+        bool seg_open = false, finished = false;
+        double pd = 0, ll = 0.0, lprev = 0.0, d = 0, l = 0;
+        while (!invalid && (!finished || nq > 0)) {
+            while (!finished && nq + WAVE + 1 <= win) {
+                if (!seg_open) {
+                    l = segp[RSB_SEGW * i + 8];               // len[i]
+                    d = l > 0.0 ? step : -step;
+                    if (i >= 1 && (lprev * l) > 0) pd = -d - ll; else pd = d - ll;
+                    lprev = l;
+                    seg_open = true;
+                }
                 // `pd += d` chain (sequential rounding kept): every lane walks it, lane j keeps the value after
                 // j additions; the walk stops at the first block of 8 whose last value already left the segment
                 double mine = pd, t = pd, last = pd;
@@ -659,44 +663,45 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
                 const unsigned long long valid = (ncap == WAVE) ? ~0ull : ((1ull << ncap) - 1);
                 const unsigned long long fail = ~__ballot(in_seg) & valid;
                 const int count = fail ? (__ffsll((long long)fail) - 1) : ncap;
-                wsync();
-                if (lane < count) { qpd[nq + lane] = mine; qseg[nq + lane] = i; }
+                if (lane < count) { qpd[nq + lane] = mine; qseg[nq + lane] = (unsigned char)i; }
                 nq += count;
-                wsync();
-                if (nq >= WAVE) {
-                    if (run_batch(WAVE)) { invalid = true; break; }
-                    const int rest = nq - WAVE;               // < 64: shift the remainder to the front
-                    double tp = 0; int ts = 0;
-                    if (lane < rest) { tp = qpd[WAVE + lane]; ts = qseg[WAVE + lane]; }
-                    wsync();
-                    if (lane < rest) { qpd[lane] = tp; qseg[lane] = ts; }
-                    nq = rest;
-                    wsync();
+                if (fail) {                                   // first value outside the segment: segment done
+                    pd = __shfl(mine, count);
+                    ll = l - pd - d;                          // "calc remain length" (:494)
+                    seg_open = false;
+                    if (i == nseg - 1) {                      // the final end point is the only segment end kept
+                        if (lane == 0) { qpd[nq] = l; qseg[nq] = (unsigned char)i; }
+                        nq += 1;
+                        finished = true;
+                    }
+                    i++;
+                } else pd = t;                                // all 64 inside: keep walking
+            }
+            wsync();
+            const int n = nq;
+            const int n_rest = n - (n + 7) / 8;
+            for (int rnd = 0; rnd == 0 || (rnd - 1) * WAVE < n_rest; rnd++) {
+                int idx;
+                if (rnd == 0) idx = (8 * lane < n) ? 8 * lane : -1;
+                else { const int r = (rnd - 1) * WAVE + lane; idx = r < n_rest ? r + r / 7 + 1 : -1; }
+                const bool active = idx >= 0;
+                double px = 0, py = 0, pyaw = 0;
+                if (active) {
+                    const double spd = qpd[idx];
+                    const double* sp_ = segp + RSB_SEGW * (int)qseg[idx];
+                    const int m = (int)sp_[7];
+                    interpolate(spd, m, sp_[0], sp_[1], sp_[2], sp_[5], sp_[6], sp_[3], sp_[4], px, py, pyaw);
                 }
-                if (fail) { pd = __shfl(mine, count); break; }   // first value outside the segment
-                pd = t;                                       // all 64 inside: keep walking
+                const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
+                const double wy = -s_q * px + c_q * py + q0y;
+                const double wyaw = pi_2_pi(pyaw + q0w);
+                if (!(obs_f64 & 0x100) && __any(pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane))) {
+                    invalid = true;
+                    break;
+                }
             }
-            if (invalid) break;
-            ll = l - pd - d;                              // "calc remain length" (:494)
-            if (i == nseg - 1) {                          // the final end point is the only segment end kept
-                wsync();
-                if (lane == 0) { qpd[nq] = l; qseg[nq] = i; }
-                nq += 1;
-                wsync();
-            }
-        }
-        if (!invalid) {
-            while (nq > 0 && !invalid) {
-                const int k = nq < WAVE ? nq : WAVE;
-                if (run_batch(k)) { invalid = true; break; }
-                const int rest = nq - k;
-                double tp = 0; int ts = 0;
-                if (lane < rest) { tp = qpd[k + lane]; ts = qseg[k + lane]; }
-                wsync();
-                if (lane < rest) { qpd[lane] = tp; qseg[lane] = ts; }
-                nq = rest;
-                wsync();
-            }
+            nq = 0;
+            wsync();
         }
         if (!invalid) { found = idx - 1; break; }
     }
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
     if (lane < 5) {
         double lm = lane < nseg ? W->len[lane] / MAXC : 0.0;      // path.lengths = [l / maxc ...] (:51)
         if (p.rs_lengths) {
-            if (obs_f64) ((double*)p.rs_lengths)[5 * (size_t)scene + lane] = lm;
+            if (obs_f64 & 1) ((double*)p.rs_lengths)[5 * (size_t)scene + lane] = lm;
             else ((float*)p.rs_lengths)[5 * (size_t)scene + lane] = (float)lm;
         }
         p.rs_word[8 * (size_t)scene + lane] = lane < nseg ? (int8_t)type_of(code, lane) : (int8_t)HOPE_RS_NONE;
@@ -720,20 +725,35 @@ __global__ __launch_bounds__(64) void k_rs_validate(RsParams p, int obs_f64) {
 }  // namespace
 
 size_t rs_lds_bytes(int max_obst) {
-    return (size_t)(12 * max_obst + RSB_WORDS) * 8 + (size_t)(RSB_QCAP + ((max_obst + 3) & ~3)) * 4;
+    return (size_t)(12 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP;
 }
 size_t rs_words_bytes_per_scene() { return sizeof(RsWord) * RS_WORDS_PER_SCENE; }
 
-hipError_t launch_rs_search(const RsParams& p, hipStream_t stream) {
-    size_t lds = rs_lds_bytes(p.max_obst);
+hipError_t launch_rs_search(const RsParams& p0, hipStream_t stream, LaunchTimer* timer) {
+    RsParams p = p0;
+    size_t lds_full = rs_lds_bytes(p.max_obst);
     static bool attr_done = false;
-    if (lds > 48 * 1024 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds_full > 48 * 1024 && !attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    p.tile_cap = p.max_obst; p.cls_lo = -1; p.cls_hi = p.max_obst;
+    if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
     hipLaunchKernelGGL(k_rs_words, dim3(p.n), dim3(WAVE), 0, stream, p);
-    hipLaunchKernelGGL(k_rs_validate, dim3(p.n), dim3(WAVE), lds, stream, p, p.obs_f64);
+    if (timer) timer->end(stream);
+    // one validation launch per tile class (small LDS tile -> more resident waves), as for the step kernel
+    constexpr int SMALL = 32;
+    const int n_cls = p.max_obst > SMALL ? 2 : 1;
+    for (int c = 0; c < n_cls; c++) {
+        p.cls_lo = (c == 0) ? -1 : SMALL;
+        p.cls_hi = (c == 0 && n_cls == 2) ? SMALL : p.max_obst;
+        p.tile_cap = p.cls_hi;
+        static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
+        if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
+        hipLaunchKernelGGL(k_rs_validate, dim3(p.n), dim3(WAVE), rs_lds_bytes(p.tile_cap), stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+        if (timer) timer->end(stream);
+    }
     return hipGetLastError();
 }
 

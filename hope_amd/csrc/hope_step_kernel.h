@@ -31,6 +31,7 @@ struct StepParams {
     double* state;            // [n][ST_WORDS]
     int32_t* tstep;           // [n]
     const void* actions;      // [n][2]
+    double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
     const uint8_t* active;    // [n] or null
     const double* tab;        // prefix-max mask table [NL][NITER][NACT]
     const double* pmax;       // [NL] max over (a,k) of tab
@@ -41,14 +42,14 @@ struct StepParams {
     int32_t* rs_list;         // [n]
 };
 
-// LDS per wave (doubles): tile 8*tile_cap | region A [402] | hb[10] cb[10] sb[10] px[10] py[10] | dest box[8] |
+// LDS per wave (doubles): tile 8*tile_cap | region A [320] | hb[10] cb[10] sb[10] px[10] py[10] | dest box[8] |
 //   w2[10] | ints: near / keep list.  Region A is reused by the phases in turn:
-//     kinematics: tx[200] ty[200] (the heading chain hs[201] aliases ty.. first)
-//     arrival   : sh[64]  Sutherland-Hodgman scratch (tx/ty are dead once px/py exist)
+//     arrival   : sh[64]  Sutherland-Hodgman scratch
 //     lidar     : best[128] u64 + queue[384] i32
 //     mask      : x[121]
-constexpr int LDS_TX = 0, LDS_TY = 200, LDS_SH = 0, LDS_X = 0, LDS_HB = 402, LDS_CB = 412, LDS_SB = 422, LDS_PX = 432,
-              LDS_PY = 442, LDS_DBOX = 452, LDS_W2 = 460, LDS_KEEP = 470, LDS_SCRATCH_WORDS = 470;
+constexpr int LDS_TX = 0, LDS_SH = 0, LDS_X = 0, LDS_HB = 320, LDS_CB = 330, LDS_SB = 340, LDS_PX = 350,
+              LDS_PY = 360, LDS_DBOX = 370, LDS_W2 = 378, LDS_KEEP = 388, LDS_SCRATCH_WORDS = 388;
+constexpr int KIN_WORDS = 50;
 __host__ __device__ inline size_t step_lds_bytes(int tile_cap) {
     return (size_t)(8 * tile_cap + LDS_SCRATCH_WORDS) * 8 + (size_t)((tile_cap + 3) & ~3) * 4;
 }
@@ -224,6 +225,46 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
     return ok ? sqrt(raw_x * raw_x + raw_y * raw_y) : INFINITY;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_kinematics: ONE THREAD PER SCENE.  action_rescale (env_wrapper.py:37-50), KSModel clip (vehicle.py:85-86) and
+// the 10 x 20 explicit-Euler micro-steps (vehicle.py:88-93) are a strictly sequential float64 recurrence per
+// scene (h += dh and x += v cos h dt/20 accumulate rounding step by step) with no cross-lane work, so it is run
+// thread-per-scene with coalesced loads over the scene batch; the wave-per-scene step kernel then only consumes
+// the ten sub-step poses.  Writes kin[scene][50] = h[10], cos h[10], sin h[10], x[10], y[10].
+// ------------------------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, const void* actions, const uint8_t* active,
+                                                  uint32_t stages, double* kin) {
+    const int scene = blockIdx.x * WAVE + threadIdx.x;
+    if (scene >= n) return;
+    if (active && !active[scene]) return;
+    const double* st = state + (size_t)scene * ST_WORDS;
+    double x = st[0], y = st[1], h = st[2];
+    const AT* act = (const AT*)actions;
+    const double a0 = (double)act[2 * (size_t)scene], a1 = (double)act[2 * (size_t)scene + 1];
+    double steer = a0, speed = a1;
+    if (!(stages & HOPE_ACTION_PHYSICAL)) {
+        steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
+        speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
+    }
+    speed = clipd(speed, SPEED_LO, SPEED_HI);
+    steer = clipd(steer, STEER_LO, STEER_HI);
+    const double dh = speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
+    double* out = kin + (size_t)scene * KIN_WORDS;
+    for (int k = 0; k < NUM_STEP; k++) {
+        for (int j = 0; j < MINI_ITER; j++) {
+            double s_, c_;
+            sincos(h, &s_, &c_);
+            x += speed * c_ * STEP_LENGTH / MINI_ITER;
+            y += speed * s_ * STEP_LENGTH / MINI_ITER;
+            h += dh;
+        }
+        double sb, cb;
+        sincos(h, &sb, &cb);
+        out[k] = h; out[10 + k] = cb; out[20 + k] = sb; out[30 + k] = x; out[40 + k] = y;
+    }
+}
+
 template <typename OT, typename AT>
 __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -272,70 +313,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     wsync();
 
     if (moving) {
-        // ---- action_rescale (env_wrapper.py:37-50) + KSModel clip (vehicle.py:85-86) -------------
-        const AT* act = (const AT*)p.actions;
-        double a0 = (double)act[2 * (size_t)scene], a1 = (double)act[2 * (size_t)scene + 1];
-        double steer = a0, speed = a1;
-        if (!(p.stages & HOPE_ACTION_PHYSICAL)) {
-            steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
-            speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
-        }
-        speed = clipd(speed, SPEED_LO, SPEED_HI);
-        steer = clipd(steer, STEER_LO, STEER_HI);
-        const double dh = speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
-
-        // ---- heading chain h_{m+1} = h_m + dh (sequential rounding, vehicle.py:92-93): ONE lane walks the
-        // 200 additions and leaves every partial sum in LDS; the other lanes pick theirs up afterwards. ----
-        double* hs = scr + LDS_TY;                         // hs[0..200], consumed before ty is written
-        if (lane == 0) {
-            double hj = h;
-            for (int m = 0; m < NUM_STEP * MINI_ITER; m++) { hs[m] = hj; hj = hj + dh; }
-            hs[NUM_STEP * MINI_ITER] = hj;
-        }
-        wsync();
-        // lane l evaluates micro-steps l, l+64, l+128, (l+192 for l < 8); lanes 8..17 the ten sub-step
-        // boundary headings h_{20(k+1)}
-        const double hm0 = hs[lane], hm1 = hs[64 + lane], hm2 = hs[128 + lane];
-        double hm3 = 0;
-        if (lane < 8) hm3 = hs[192 + lane]; else if (lane < 18) hm3 = hs[MINI_ITER * (lane - 7)];
-        wsync();
-        // ---- per-micro-step displacement terms speed*cos(h)*step_len/mini_iter (vehicle.py:90-91) ----
-        {
-            double s_, c_;
-            sincos(hm0, &s_, &c_);
-            scr[LDS_TX + lane] = speed * c_ * STEP_LENGTH / MINI_ITER;
-            scr[LDS_TY + lane] = speed * s_ * STEP_LENGTH / MINI_ITER;
-            sincos(hm1, &s_, &c_);
-            scr[LDS_TX + 64 + lane] = speed * c_ * STEP_LENGTH / MINI_ITER;
-            scr[LDS_TY + 64 + lane] = speed * s_ * STEP_LENGTH / MINI_ITER;
-            sincos(hm2, &s_, &c_);
-            scr[LDS_TX + 128 + lane] = speed * c_ * STEP_LENGTH / MINI_ITER;
-            scr[LDS_TY + 128 + lane] = speed * s_ * STEP_LENGTH / MINI_ITER;
-            if (lane < 18) {
-                sincos(hm3, &s_, &c_);
-                if (lane < 8) {
-                    scr[LDS_TX + 192 + lane] = speed * c_ * STEP_LENGTH / MINI_ITER;
-                    scr[LDS_TY + 192 + lane] = speed * s_ * STEP_LENGTH / MINI_ITER;
-                } else {
-                    scr[LDS_HB + lane - 8] = hm3;
-                    scr[LDS_CB + lane - 8] = c_;
-                    scr[LDS_SB + lane - 8] = s_;
-                }
-            }
-        }
-        wsync();
-        // ---- x += ..., y += ... in micro-step order: lane 0 sums x, lane 1 sums y; the pose after each of
-        // the ten sub-steps is kept (it does not depend on the collision outcome, only where we stop does)
-        if (lane < 2) {
-            double acc = lane == 0 ? x : y;
-            const double* term = scr + (lane == 0 ? LDS_TX : LDS_TY);
-            double* dst = scr + (lane == 0 ? LDS_PX : LDS_PY);
-            for (int k = 0; k < NUM_STEP; k++) {
-#pragma unroll
-                for (int j = 0; j < MINI_ITER; j++) acc += term[k * MINI_ITER + j];
-                dst[k] = acc;
-            }
-        }
+        // the ten sub-step poses (x, y, heading, cos, sin) were produced by k_kinematics (one THREAD per scene):
+        // they do not depend on the collision outcome, only where we stop does
+        if (lane < KIN_WORDS) scr[LDS_HB + lane] = p.kin[(size_t)scene * KIN_WORDS + lane];
         wsync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------

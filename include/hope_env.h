@@ -136,10 +136,16 @@ int hope_env_reset_obs(hope_env_t *h, const uint8_t *active, uint32_t stages, co
  * Follow with hope_env_reset_obs(active = mask) to obtain the first observation. */
 int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
 
-/* With HOPE_F_PROFILE: accumulated HIP-event time (ms) and launch count of the step kernel and of the
- * Reeds-Shepp kernel since the last call with reset != 0.  Host-synchronous. */
-int hope_env_kernel_ms(hope_env_t *h, double *step_ms, int64_t *step_launches, double *rs_ms,
-                       int64_t *rs_launches, int reset);
+/* With HOPE_F_PROFILE every kernel launch is bracketed by its own HIP event pair on the launch stream.
+ * Returns the accumulated time (ms) and launch count per kernel since the last call with reset != 0:
+ * arrays of HOPE_N_KERNELS entries indexed by HOPE_K_*.  Host-synchronous. */
+#define HOPE_K_KINEMATICS 0    /* k_kinematics   (thread per scene)                         */
+#define HOPE_K_STEP 1          /* k_env_step     (wave per scene; one launch per tile class) */
+#define HOPE_K_RS_WORDS 2      /* k_rs_words     (wave per queued scene)                     */
+#define HOPE_K_RS_VALIDATE 3   /* k_rs_validate  (wave per queued scene; per tile class)     */
+#define HOPE_N_KERNELS 4
+int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
+                       int reset);
 
 /* ---- state access (host-sync; tests, checkpointing) ------------------------------------------ */
 int hope_env_download_state(hope_env_t *h, double *pose /*[N][3]*/, int32_t *t /*[N]*/,

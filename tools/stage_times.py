@@ -43,9 +43,11 @@ def main():
             for i in range(args.steps):
                 env.step(acts[i % 4], stages=st)
             torch.cuda.synchronize()
-            sm, sn, rm, rn = env.kernel_ms(reset=True)
-            print(f'{"/".join(mix):24s} {name:22s} step {sm/sn*1e3:8.1f} us  rs {rm/max(rn,1)*1e3:8.1f} us   '
-                  f'({N/(sm/sn+rm/max(rn,1))/1e3:.1f} M scene-steps/s)', flush=True)
+            km = env.kernel_ms(reset=True)
+            per = {k: v[0] / args.steps * 1e3 for k, v in km.items()}
+            tot = sum(per.values())
+            print(f'{"/".join(mix):24s} {name:22s} ' + ' '.join(f'{k[2:]} {v:7.1f}' for k, v in per.items()) +
+                  f' us | total {tot:7.1f} us ({N/tot:.1f} M scene-steps/s)', flush=True)
         env.close()
 
 
