@@ -392,6 +392,15 @@ int hope_env_kernel_ms(hope_env_t* h, double* ms, int64_t* launches, int reset) 
     return HOPE_OK;
 }
 
+int hope_env_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages,
+                  const hope_step_out* out, void* stream) {
+    return launch_step(h, actions, active, stages, out, stream, 1);
+}
+
+int hope_env_reset_obs(hope_env_t* h, const uint8_t* active, uint32_t stages, const hope_step_out* out, void* stream) {
+    return launch_step(h, nullptr, active, stages & ~HOPE_STAGE_MOTION, out, stream, 0);
+}
+
 int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* accum) {
     if (!h) return fail(HOPE_EINVAL, "hope_env_download_state: null handle");
     HIPCHK(hipSetDevice(h->device));
