@@ -269,8 +269,8 @@ template <typename OT, typename AT>
 __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
-    const int scene = blockIdx.x;
-    if (scene >= p.n) return;
+    if ((int)blockIdx.x >= p.n) return;
+    const int scene = scene_of_block(blockIdx.x, p.n);
     if (p.active && !p.active[scene]) return;
 
     const int n_obst = p.n_obst[scene];

@@ -35,15 +35,27 @@ def main():
                          ('obs only(no motion)', L.STAGE_OBS), ('motion+obs+reward', L.STAGE_MOTION | L.STAGE_OBS | L.STAGE_REWARD),
                          ('all', L.STAGE_ALL), ('obs -mask', L.STAGE_OBS | 0x2000), ('obs -beams', L.STAGE_OBS | 0x1000),
                          ('obs -beams -mask', L.STAGE_OBS | 0x3000)):
+            def full_step(i):          # keep the episode population realistic: finished scenes start over
+                env.step(acts[i % 4], stages=L.STAGE_ALL)
+                env.restart(env.done)
+                env.reset_obs(active=env.done)
             env.reset_obs(stages=L.STAGE_ALL)
-            for i in range(3):
-                env.step(acts[i % 4], stages=st)
+            for i in range(12):
+                full_step(i)
             torch.cuda.synchronize()
-            env.kernel_ms(reset=True)
+            pose, tt, acc = env.download_state()
+            tot = {k: 0.0 for k in L.KERNELS}
             for i in range(args.steps):
+                env.upload_state(pose=pose, t=tt, accum=acc)     # same poses for every measured configuration
+                env.kernel_ms(reset=True)
                 env.step(acts[i % 4], stages=st)
-            torch.cuda.synchronize()
-            km = env.kernel_ms(reset=True)
+                torch.cuda.synchronize()
+                for k, v in env.kernel_ms(reset=True).items():
+                    tot[k] += v[0]
+            class _K:                                            # adapter for the print below
+                pass
+            env_kernel = {k: (v, 1) for k, v in tot.items()}
+            km = env_kernel
             per = {k: v[0] / args.steps * 1e3 for k, v in km.items()}
             tot = sum(per.values())
             print(f'{"/".join(mix):24s} {name:22s} ' + ' '.join(f'{k[2:]} {v:7.1f}' for k, v in per.items()) +
