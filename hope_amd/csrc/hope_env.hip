@@ -46,6 +46,10 @@ struct hope_env {
     int32_t* rs_count = nullptr;
     int32_t* rs_list = nullptr;
     double* kin = nullptr;
+    // per tile class (0: n_obst <= SMALL_TILE, 1: larger) dense scene lists; classes are static between set_scenes calls
+    int32_t* cls_list[2] = {nullptr, nullptr};
+    int cls_count[2] = {0, 0};
+    std::vector<int32_t> n_obst_host;
     void* rs_words = nullptr;
     int32_t* rs_nwords = nullptr;
     // staging for set_scenes
@@ -182,6 +186,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     hope_env* h = new (std::nothrow) hope_env();
     if (!h) return fail(HOPE_ENOMEM, "hope_env_create: host allocation failed");
     h->n = n_scenes; h->max_obst = max_obstacles; h->device = device_id; h->flags = flags;
+    h->n_obst_host.assign(n_scenes, 0);
     snprintf(h->arch, sizeof(h->arch), "%s", prop.gcnArchName);
     size_t N = (size_t)n_scenes;
 #define ALLOC(ptr, bytes)                                                                          \
@@ -201,9 +206,11 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->pmax, NL * sizeof(double));
     ALLOC(h->hull_base, NBEAM * sizeof(double));
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
-    ALLOC(h->rs_count, sizeof(int32_t));
-    ALLOC(h->rs_list, N * sizeof(int32_t));
+    ALLOC(h->rs_count, 2 * sizeof(int32_t));
+    ALLOC(h->rs_list, 2 * N * sizeof(int32_t));
     ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
+    ALLOC(h->cls_list[0], N * sizeof(int32_t));
+    ALLOC(h->cls_list[1], N * sizeof(int32_t));
     ALLOC(h->rs_words, N * rs_words_bytes_per_scene());
     ALLOC(h->rs_nwords, N * sizeof(int32_t));
 #undef ALLOC
@@ -211,7 +218,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->scene_c, 0, N * SC_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->state, 0, N * ST_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
-    HIPCHK(hipMemset(h->rs_count, 0, sizeof(int32_t)));
+    HIPCHK(hipMemset(h->rs_count, 0, 2 * sizeof(int32_t)));
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -229,7 +236,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->rs_words, h->rs_nwords, h->stage};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->stage};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -303,6 +310,17 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
         hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
                            (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), h->verts, h->max_obst);
     HIPCHK(hipGetLastError());
+    // rebuild the dense per-class scene lists (host mirror of n_obst; N ints, reset-time only)
+    for (int k = 0; k < n; k++) h->n_obst_host[scene_ids[k]] = n_obst[k];
+    {
+        std::vector<int32_t> l0, l1;
+        l0.reserve(h->n); l1.reserve(h->n);
+        const bool two = h->max_obst > SMALL_TILE;
+        for (int i = 0; i < h->n; i++) (two && h->n_obst_host[i] > SMALL_TILE ? l1 : l0).push_back(i);
+        h->cls_count[0] = (int)l0.size(); h->cls_count[1] = (int)l1.size();
+        if (!l0.empty()) HIPCHK(hipMemcpy(h->cls_list[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!l1.empty()) HIPCHK(hipMemcpy(h->cls_list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipDeviceSynchronize());
     h->have_scenes = true;
     return HOPE_OK;
@@ -323,10 +341,9 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     p.actions = actions; p.active = active; p.kin = h->kin;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
-    p.rs_count = h->rs_count; p.rs_list = h->rs_list;
-    if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, sizeof(int32_t), s));
+    if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, 2 * sizeof(int32_t), s));
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
-    dim3 grid(h->n), block(WAVE);
+    dim3 block(WAVE);
     const bool prof = h->flags & HOPE_F_PROFILE;
     if (prof && h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
     EventTimer timer(h);
@@ -342,9 +359,13 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     // waves; a wave whose scene belongs to the other class exits at once
     const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
     for (int c = 0; c < n_cls; c++) {
-        p.cls_lo = (c == 0) ? -1 : SMALL_TILE;
-        p.cls_hi = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
-        p.tile_cap = p.cls_hi;
+        if (h->cls_count[c] == 0) continue;
+        p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
+        p.scene_list = h->cls_list[c];
+        p.n_list = h->cls_count[c];
+        p.rs_count = h->rs_count + c;
+        p.rs_list = h->rs_list + (size_t)c * h->n;
+        const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
         if (tm) tm->begin(HOPE_K_STEP, s);
         if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
@@ -355,14 +376,20 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     }
     HIPCHK(hipGetLastError());
     if ((stages & HOPE_STAGE_RS) && out->rs_word) {
-        RsParams r;
-        r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
-        r.tile_cap = h->max_obst; r.cls_lo = -1; r.cls_hi = h->max_obst;
-        r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
-        r.rs_count = h->rs_count; r.rs_list = h->rs_list;
-        r.rs_words = (RsWord*)h->rs_words; r.rs_nwords = h->rs_nwords;
-        r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
-        HIPCHK(launch_rs_search(r, s, tm));
+        for (int c = 0; c < n_cls; c++) {
+            if (h->cls_count[c] == 0) continue;
+            RsParams r;
+            r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
+            r.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
+            r.max_queue = h->cls_count[c];
+            r.slot_base = (c == 0) ? 0 : h->n - 1;          // the two classes fill the word storage from both ends
+            r.slot_dir = (c == 0) ? 1 : -1;
+            r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
+            r.rs_count = h->rs_count + c; r.rs_list = h->rs_list + (size_t)c * h->n;
+            r.rs_words = (RsWord*)h->rs_words; r.rs_nwords = h->rs_nwords;
+            r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
+            HIPCHK(launch_rs_search(r, s, tm));
+        }
     }
     if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
     return HOPE_OK;

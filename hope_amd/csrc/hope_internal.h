@@ -17,7 +17,9 @@ constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generat
 
 struct RsParams {
     int n, max_obst;
-    int tile_cap, cls_lo, cls_hi;   // LDS tile capacity / obstacle-count class served by this launch
+    int tile_cap;             // LDS tile capacity of this launch's tile class
+    int max_queue;            // upper bound of *rs_count (= scenes in the class): grid size
+    int slot_base, slot_dir;  // word storage slot of queue entry q = slot_base + slot_dir * q (classes fill from both ends)
     int obs_f64;
     const double* verts;      // [n][max_obst][4][2] world frame
     const int32_t* n_obst;    // [n]
@@ -37,7 +39,7 @@ struct LaunchTimer {
     virtual void end(hipStream_t s) = 0;
 };
 // launches the Reeds-Shepp feasibility kernels over the scenes queued in rs_list (hope_rs.hip)
-hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);   // one tile class
 size_t rs_lds_bytes(int max_obst);
 size_t rs_words_bytes_per_scene();
 

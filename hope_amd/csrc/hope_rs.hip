@@ -302,9 +302,9 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     __shared__ int hid[64];
     __shared__ int order[64];
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x;
-    if (slot >= *p.rs_count) return;
-    const int scene = p.rs_list[slot];
+    if ((int)blockIdx.x >= *p.rs_count) return;
+    const int scene = p.rs_list[blockIdx.x];
+    const int slot = p.slot_base + p.slot_dir * (int)blockIdx.x;
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double* st = p.state + (size_t)scene * ST_WORDS;
     const double q0x = st[0], q0y = st[1], q0w = st[2];
@@ -521,14 +521,13 @@ constexpr int RSB_QCAP = 512;
 __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x;
-    if (slot >= *p.rs_count) return;
+    if ((int)blockIdx.x >= *p.rs_count) return;
     if (obs_f64 & 0x400) return;                          // profiling switch: words kernel only
+    const int slot = p.slot_base + p.slot_dir * (int)blockIdx.x;
     const int n_paths = p.rs_nwords[slot];
     if (n_paths == 0) return;
-    const int scene = p.rs_list[slot];
+    const int scene = p.rs_list[blockIdx.x];
     const int n_obst = p.n_obst[scene];
-    if (n_obst <= p.cls_lo || n_obst > p.cls_hi) return;          // served by the launch of the other tile class
     double* tile = lds;
     double* obb = lds + 8 * p.tile_cap;
     double* scr = lds + 12 * p.tile_cap;
@@ -729,31 +728,21 @@ size_t rs_lds_bytes(int max_obst) {
 }
 size_t rs_words_bytes_per_scene() { return sizeof(RsWord) * RS_WORDS_PER_SCENE; }
 
-hipError_t launch_rs_search(const RsParams& p0, hipStream_t stream, LaunchTimer* timer) {
-    RsParams p = p0;
-    size_t lds_full = rs_lds_bytes(p.max_obst);
-    static bool attr_done = false;
-    if (lds_full > 48 * 1024 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer) {
+    if (p.max_queue <= 0) return hipSuccess;
+    size_t lds = rs_lds_bytes(p.tile_cap);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
-    p.tile_cap = p.max_obst; p.cls_lo = -1; p.cls_hi = p.max_obst;
+    // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
     if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
-    hipLaunchKernelGGL(k_rs_words, dim3(p.n), dim3(WAVE), 0, stream, p);
+    hipLaunchKernelGGL(k_rs_words, dim3(p.max_queue), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
-    // one validation launch per tile class (small LDS tile -> more resident waves), as for the step kernel
-    constexpr int SMALL = 32;
-    const int n_cls = p.max_obst > SMALL ? 2 : 1;
-    for (int c = 0; c < n_cls; c++) {
-        p.cls_lo = (c == 0) ? -1 : SMALL;
-        p.cls_hi = (c == 0 && n_cls == 2) ? SMALL : p.max_obst;
-        p.tile_cap = p.cls_hi;
-        static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
-        if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
-        hipLaunchKernelGGL(k_rs_validate, dim3(p.n), dim3(WAVE), rs_lds_bytes(p.tile_cap), stream, p, (p.obs_f64 ? 1 : 0) | dbg);
-        if (timer) timer->end(stream);
-    }
+    static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
+    if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
+    hipLaunchKernelGGL(k_rs_validate, dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    if (timer) timer->end(stream);
     return hipGetLastError();
 }
 

@@ -22,7 +22,8 @@ namespace hope {
 struct StepParams {
     int n, max_obst;          // max_obst = HBM tile stride (obstacle slots per scene)
     int tile_cap;             // LDS tile capacity of THIS launch (obstacles)
-    int cls_lo, cls_hi;       // this launch serves scenes with cls_lo < n_obst <= cls_hi
+    const int32_t* scene_list; // scenes of this launch's tile class (dense launch: grid = n_list)
+    int n_list;
     uint32_t stages;
     int has_action;
     const double* verts;      // [n][max_obst][4][2]
@@ -38,8 +39,8 @@ struct StepParams {
     const double* hull_base;  // [NBEAM]
     const double* beam_ab;    // [NBEAM][2]
     hope_step_out out;
-    int32_t* rs_count;        // [1] number of scenes queued for the Reeds-Shepp kernel
-    int32_t* rs_list;         // [n]
+    int32_t* rs_count;        // [1] scenes of THIS tile class queued for the Reeds-Shepp kernels
+    int32_t* rs_list;         // [n] queue of this tile class
 };
 
 // LDS per wave (doubles): tile 8*tile_cap | region A [320] | hb[10] cb[10] sb[10] px[10] py[10] | dest box[8] |
@@ -269,12 +270,11 @@ template <typename OT, typename AT>
 __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= p.n) return;
-    const int scene = scene_of_block(blockIdx.x, p.n);
+    if ((int)blockIdx.x >= p.n_list) return;
+    const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
     if (p.active && !p.active[scene]) return;
 
     const int n_obst = p.n_obst[scene];
-    if (n_obst <= p.cls_lo || n_obst > p.cls_hi) return;          // served by the launch of the other tile class
 
     double* tile = lds;
     double* scr = lds + 8 * p.tile_cap;
