@@ -236,13 +236,17 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, const void* actions, const uint8_t* active,
                                                   uint32_t stages, double* kin) {
+    // the 64 scenes of a block own 64 x 50 contiguous doubles of `kin`: results go through LDS so that the block
+    // writes them with fully coalesced stores (a per-thread 400 B stride cost 7x the write requests: PMC WRITE_SIZE)
+    __shared__ double buf[WAVE * KIN_WORDS];
     const int scene = blockIdx.x * WAVE + threadIdx.x;
-    if (scene >= n) return;
-    if (active && !active[scene]) return;
-    const double* st = state + (size_t)scene * ST_WORDS;
+    const bool live = scene < n && !(active && !active[scene]);
+    if (__all(!live)) return;
+    const int sc_ = live ? scene : 0;
+    const double* st = state + (size_t)sc_ * ST_WORDS;
     double x = st[0], y = st[1], h = st[2];
     const AT* act = (const AT*)actions;
-    const double a0 = (double)act[2 * (size_t)scene], a1 = (double)act[2 * (size_t)scene + 1];
+    const double a0 = (double)act[2 * (size_t)sc_], a1 = (double)act[2 * (size_t)sc_ + 1];
     double steer = a0, speed = a1;
     if (!(stages & HOPE_ACTION_PHYSICAL)) {
         steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
     speed = clipd(speed, SPEED_LO, SPEED_HI);
     steer = clipd(steer, STEER_LO, STEER_HI);
     const double dh = speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
-    double* out = kin + (size_t)scene * KIN_WORDS;
+    double* out = buf + threadIdx.x * KIN_WORDS;
     for (int k = 0; k < NUM_STEP; k++) {
         for (int j = 0; j < MINI_ITER; j++) {
             double s_, c_;
@@ -263,6 +267,14 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
         double sb, cb;
         sincos(h, &sb, &cb);
         out[k] = h; out[10 + k] = cb; out[20 + k] = sb; out[30 + k] = x; out[40 + k] = y;
+    }
+    __syncthreads();
+    const int first = blockIdx.x * WAVE;
+    const int n_here = min(WAVE, n - first);
+    double* dst = kin + (size_t)first * KIN_WORDS;
+    for (int w = threadIdx.x; w < n_here * KIN_WORDS; w += WAVE) {
+        const int s = w / KIN_WORDS;
+        if (!active || active[first + s]) dst[w] = buf[w];
     }
 }
 
