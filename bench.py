@@ -66,12 +66,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})')
     dist = None
+    # test hook (1-GPU boxes): HOPE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the
+    # barrier / MAX-reduce, so the multi-rank control flow can be exercised without N GPUs
+    share = os.environ.get('HOPE_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the product has no CPU path')
     dev = torch.device(f'cuda:{local_rank}')
@@ -131,7 +139,7 @@ def main():
     done_frac = float(env.done.float().mean().item())
     rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device='cpu' if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
