@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "hope_math.h"
+
 namespace hope {
 
 constexpr int NBEAM = 120;   // configs.py:96

@@ -117,7 +117,7 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
     for (int i = 0; i < 3; i++) { c[SC_START + i] = start[3 * k + i]; c[SC_DEST + i] = dest[3 * k + i]; }
     for (int i = 0; i < 4; i++) c[SC_BBOX + i] = bbox[4 * k + i];
     double sn, ct;
-    sincos(dest[3 * k + 2], &sn, &ct);
+    hm_sincos(dest[3 * k + 2], &sn, &ct);
     Box b = make_box(dest[3 * k], dest[3 * k + 1], ct, sn);       // dest.create_box()
     for (int v = 0; v < 4; v++) { c[SC_DBOX + 2 * v] = b.x[v]; c[SC_DBOX + 2 * v + 1] = b.y[v]; }
     // Polygon(dest_box).area: GEOS Area::ofRingSigned
@@ -134,6 +134,27 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
     st[0] = start[3 * k]; st[1] = start[3 * k + 1]; st[2] = start[3 * k + 2]; st[3] = 0.0;
     tstep[s] = 0;
     n_obst[s] = nob[k];
+}
+
+__global__ void k_debug_math(int fn, int n, const double* a, const double* b, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = a[i], y = b ? b[i] : 0.0, r;
+    switch (fn) {
+        case 0: r = hm_sin(x); break;
+        case 1: r = hm_cos(x); break;
+        case 2: r = hm_tan(x); break;
+        case 3: r = hm_atan2(x, y); break;
+        case 4: r = hm_asin(x); break;
+        case 5: r = hm_acos(x); break;
+        case 6: r = hm_hypot(x, y); break;
+        case 7: r = hm_fmod(x, y); break;
+        case 8: r = hm_tanh(x); break;
+        case 9: r = hm_exp(x); break;
+        case 10: r = sqrt(x); break;
+        default: r = x / y; break;
+    }
+    out[i] = r;
 }
 
 // episode restart: pose = start, t = 0, accum = 0 for masked scenes
@@ -426,6 +447,14 @@ int hope_env_step(hope_env_t* h, const void* actions, const uint8_t* active, uin
 
 int hope_env_reset_obs(hope_env_t* h, const uint8_t* active, uint32_t stages, const hope_step_out* out, void* stream) {
     return launch_step(h, nullptr, active, stages & ~HOPE_STAGE_MOTION, out, stream, 0);
+}
+
+int hope_debug_math(int fn, int n, const double* a, const double* b, double* out, void* stream) {
+    if (n < 0 || !a || !out) return fail(HOPE_EINVAL, "hope_debug_math: bad argument");
+    if (n == 0) return HOPE_OK;
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, a, b, out);
+    HIPCHK(hipGetLastError());
+    return HOPE_OK;
 }
 
 int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* accum) {

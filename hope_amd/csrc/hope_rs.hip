@@ -29,7 +29,7 @@ namespace hope {
 
 namespace {
 
-constexpr double MAXC = 0.3327130214085973;      // math.tan(VALID_STEER[-1]) / WHEEL_BASE  (car_parking_base.py:422)
+constexpr double MAXC = 0.3327130214085973;      // math.hm_tan(VALID_STEER[-1]) / WHEEL_BASE  (car_parking_base.py:422)
 constexpr double RS_STEP = 0.1;                  // step_size passed by find_rs_path (:424)
 constexpr double MAX_LENGTH = 1000.0;            // reeds_shepp.py:6
 constexpr int NCAND = 46;
@@ -37,7 +37,7 @@ constexpr int NCAND = 46;
 enum { TS = 0, TL = 1, TR = 2 };
 
 __device__ __forceinline__ double py_mod(double v, double w) {   // Python float %
-    double m = fmod(v, w);
+    double m = hm_fmod(v, w);
     if (m != 0) { if ((w < 0) != (m < 0)) m += w; } else m = copysign(0.0, w);
     return m;
 }
@@ -47,7 +47,7 @@ __device__ __forceinline__ double rs_M(double theta) {           // reeds_shepp.
     if (phi > PI) phi -= 2.0 * PI;
     return phi;
 }
-__device__ __forceinline__ void rs_R(double x, double y, double& r, double& th) { r = hypot(x, y); th = atan2(y, x); }
+__device__ __forceinline__ void rs_R(double x, double y, double& r, double& th) { r = hm_hypot(x, y); th = hm_atan2(y, x); }
 __device__ __forceinline__ double pi_2_pi(double t) {            // :561-568
     while (t > PI) t -= 2.0 * PI;
     while (t < -PI) t += 2.0 * PI;
@@ -57,23 +57,23 @@ __device__ __forceinline__ double pi_2_pi(double t) {            // :561-568
 __device__ bool rs_SLS(double x, double y, double phi, double& t, double& u, double& v) {   // :133-149
     phi = rs_M(phi);
     if (y > 0.0 && 0.0 < phi && phi < PI * 0.99) {
-        double xd = -y / tan(phi) + x;
-        t = xd - tan(phi / 2.0);
+        double xd = -y / hm_tan(phi) + x;
+        t = xd - hm_tan(phi / 2.0);
         u = phi;
-        v = sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        v = sqrt((x - xd) * (x - xd) + y * y) - hm_tan(phi / 2.0);
         return true;
     } else if (y < 0.0 && 0.0 < phi && phi < PI * 0.99) {
-        double xd = -y / tan(phi) + x;
-        t = xd - tan(phi / 2.0);
+        double xd = -y / hm_tan(phi) + x;
+        t = xd - hm_tan(phi / 2.0);
         u = phi;
-        v = -sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        v = -sqrt((x - xd) * (x - xd) + y * y) - hm_tan(phi / 2.0);
         return true;
     }
     return false;
 }
 __device__ bool rs_LSL(double x, double y, double phi, double& t, double& u, double& v) {   // :79-87
     double uu, tt;
-    rs_R(x - sin(phi), y - 1.0 + cos(phi), uu, tt);
+    rs_R(x - hm_sin(phi), y - 1.0 + hm_cos(phi), uu, tt);
     if (tt >= 0.0) {
         double vv = rs_M(phi - tt);
         if (vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -82,11 +82,11 @@ __device__ bool rs_LSL(double x, double y, double phi, double& t, double& u, dou
 }
 __device__ bool rs_LSR(double x, double y, double phi, double& t, double& u, double& v) {   // :90-103
     double u1, t1;
-    rs_R(x + sin(phi), y - 1.0 - cos(phi), u1, t1);
+    rs_R(x + hm_sin(phi), y - 1.0 - hm_cos(phi), u1, t1);
     u1 = u1 * u1;
     if (u1 >= 4.0) {
         double uu = sqrt(u1 - 4.0);
-        double theta = atan2(2.0, uu);
+        double theta = hm_atan2(2.0, uu);
         double tt = rs_M(t1 + theta);
         double vv = rs_M(tt - phi);
         if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -95,9 +95,9 @@ __device__ bool rs_LSR(double x, double y, double phi, double& t, double& u, dou
 }
 __device__ bool rs_LRL(double x, double y, double phi, double& t, double& u, double& v) {   // :106-117
     double u1, t1;
-    rs_R(x - sin(phi), y - 1.0 + cos(phi), u1, t1);
+    rs_R(x - hm_sin(phi), y - 1.0 + hm_cos(phi), u1, t1);
     if (u1 <= 4.0) {
-        double uu = -2.0 * asin(0.25 * u1);
+        double uu = -2.0 * hm_asin(0.25 * u1);
         double tt = rs_M(t1 + 0.5 * uu + PI);
         double vv = rs_M(phi - tt + uu);
         if (tt >= 0.0 && uu <= 0.0) { t = tt; u = uu; v = vv; return true; }
@@ -106,28 +106,28 @@ __device__ bool rs_LRL(double x, double y, double phi, double& t, double& u, dou
 }
 __device__ void calc_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega) {
     double delta = rs_M(u - v);                                                             // :228-243
-    double A = sin(u) - sin(delta);
-    double B = cos(u) - cos(delta) - 1.0;
-    double t1 = atan2(eta * A - xi * B, xi * A + eta * B);
-    double t2 = 2.0 * (cos(delta) - cos(v) - cos(u)) + 3.0;
+    double A = hm_sin(u) - hm_sin(delta);
+    double B = hm_cos(u) - hm_cos(delta) - 1.0;
+    double t1 = hm_atan2(eta * A - xi * B, xi * A + eta * B);
+    double t2 = 2.0 * (hm_cos(delta) - hm_cos(v) - hm_cos(u)) + 3.0;
     if (t2 < 0) tau = rs_M(t1 + PI); else tau = rs_M(t1);
     omega = rs_M(tau - u + v - phi);
 }
 __device__ bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double& v) { // :246-257
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi);
     double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
     if (rho <= 1.0) {
-        double uu = acos(rho), tt, vv;
+        double uu = hm_acos(rho), tt, vv;
         calc_tauOmega(uu, -uu, xi, eta, phi, tt, vv);
         if (tt >= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
     }
     return false;
 }
 __device__ bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double& v) { // :260-272
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi);
     double rho = (20.0 - xi * xi - eta * eta) / 16.0;
     if (0.0 <= rho && rho <= 1.0) {
-        double uu = -acos(rho);
+        double uu = -hm_acos(rho);
         if (uu >= -0.5 * PI) {
             double tt, vv;
             calc_tauOmega(uu, uu, xi, eta, phi, tt, vv);
@@ -137,7 +137,7 @@ __device__ bool rs_LRLRp(double x, double y, double phi, double& t, double& u, d
     return false;
 }
 __device__ bool rs_LRSR(double x, double y, double phi, double& t, double& u, double& v) {  // :311-323
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi), rho, theta;
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi), rho, theta;
     rs_R(-eta, xi, rho, theta);
     if (rho >= 2.0) {
         double tt = theta, uu = 2.0 - rho, vv = rs_M(tt + 0.5 * PI - phi);
@@ -146,24 +146,24 @@ __device__ bool rs_LRSR(double x, double y, double phi, double& t, double& u, do
     return false;
 }
 __device__ bool rs_LRSL(double x, double y, double phi, double& t, double& u, double& v) {  // :326-339
-    double xi = x - sin(phi), eta = y - 1.0 + cos(phi), rho, theta;
+    double xi = x - hm_sin(phi), eta = y - 1.0 + hm_cos(phi), rho, theta;
     rs_R(xi, eta, rho, theta);
     if (rho >= 2.0) {
         double r = sqrt(rho * rho - 4.0);
         double uu = 2.0 - r;
-        double tt = rs_M(theta + atan2(r, -2.0));
+        double tt = rs_M(theta + hm_atan2(r, -2.0));
         double vv = rs_M(phi - 0.5 * PI - tt);
         if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { t = tt; u = uu; v = vv; return true; }
     }
     return false;
 }
 __device__ bool rs_LRSLR(double x, double y, double phi, double& t, double& u, double& v) { // :414-429
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi), rho, theta;
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi), rho, theta;
     rs_R(xi, eta, rho, theta);
     if (rho >= 2.0) {
         double uu = 4.0 - sqrt(rho * rho - 4.0);
         if (uu <= 0.0) {
-            double tt = rs_M(atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
+            double tt = rs_M(hm_atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
             double vv = rs_M(tt - phi);
             if (tt >= 0.0 && vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
         }
@@ -194,9 +194,9 @@ __device__ __forceinline__ void interpolate(double l, int m, double ox, double o
         py = oy + l / MAXC * s_oy;
         pyaw = oyaw;
     } else {
-        double ldx = sin(l) / MAXC;
-        double ldy = (m == TL) ? (1.0 - cos(l)) / MAXC : (1.0 - cos(l)) / (-MAXC);
-        double gdx = c_noy * ldx + s_noy * ldy;          // cos(-oyaw)*ldx + sin(-oyaw)*ldy
+        double ldx = hm_sin(l) / MAXC;
+        double ldy = (m == TL) ? (1.0 - hm_cos(l)) / MAXC : (1.0 - hm_cos(l)) / (-MAXC);
+        double gdx = c_noy * ldx + s_noy * ldy;          // hm_cos(-oyaw)*ldx + hm_sin(-oyaw)*ldy
         double gdy = -s_noy * ldx + c_noy * ldy;
         px = ox + gdx;
         py = oy + gdy;
@@ -218,7 +218,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
     if (active) {
         if (wx < xmin || wx > xmax || wy < ymin || wy > ymax) bad = true;      // :462-464
         double st, ct;
-        sincos(wyaw, &st, &ct);
+        hm_sincos(wyaw, &st, &ct);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             vx[k] = ct * car_x(k) - st * car_y(k) + wx;                         // :468-471
@@ -293,7 +293,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
 // Kernel A: generate_path + set_path + heapdict order  ->  ordered word list per queued scene
 // ================================================================================================
 // The 46 solver calls run one per lane.  Instead of twelve divergent solver bodies, the lanes share the
-// expensive steps: one sincos(phi'), one (hypot, atan2) of the solver's polar argument, one asin/acos,
+// expensive steps: one hm_sincos(phi'), one (hypot, atan2) of the solver's polar argument, one asin/acos,
 // one second atan2, then short per-family tails -- the arithmetic of each solver is unchanged.
 constexpr int RSA_LM = 0, RSA_PR = 64, RSA_WORDS = 128;     // LDS doubles, then ints hid[64], order[64]
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     {
         double dx = gx - q0x, dy = gy - q0y;
         PHI = gw - q0w;
-        double c = cos(q0w), s = sin(q0w);
+        double c = hm_cos(q0w), s = hm_sin(q0w);
         X = (c * dx + s * dy) * MAXC;
         Y = (-s * dx + c * dy) * MAXC;
     }
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
         cand_decode(lane, g, q);
         double bx = X, by = Y;
         if (g == 4 || g == 9 || g == 10) {               // "backwards" (:206-207, :376-377)
-            bx = X * cos(PHI) + Y * sin(PHI);
-            by = X * sin(PHI) - Y * cos(PHI);
+            bx = X * hm_cos(PHI) + Y * hm_sin(PHI);
+            by = X * hm_sin(PHI) - Y * hm_cos(PHI);
         }
         const double sx = (q & 1) ? -bx : bx;
         const double sy = (q & 2) ? -by : by;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
             ok = rs_SLS(sx, sy, sp, t, u, v);
         } else {
             double s_, c_;
-            sincos(sp, &s_, &c_);
+            hm_sincos(sp, &s_, &c_);
             const bool plus = (g == 2 || g == 5 || g == 6 || g == 8 || g == 10 || g == 11);
             const double xi = plus ? sx + s_ : sx - s_;
             const double eta = plus ? sy - 1.0 - c_ : sy - 1.0 + c_;
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
             double r = 0, th = 0;
             if (!isLRLR) {                                // R(.,.) (:571-578); LRSR uses R(-eta, xi) (:314)
                 double ra = isLRSR ? -eta : xi, rb = isLRSR ? xi : eta;
-                r = hypot(ra, rb);
-                th = atan2(rb, ra);
+                r = hm_hypot(ra, rb);
+                th = hm_atan2(rb, ra);
             }
             bool alive = true, needC = false;
             double cy = 0, cx = 1, vv = 0, t2 = 0;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
                 if (alive) { u = sqrt(u1 - 4.0); cy = 2.0; cx = u; needC = true; }
             } else if (g == 3 || g == 4) {                // LRL :106-117
                 alive = r <= 4.0;
-                if (alive) u = -2.0 * asin(0.25 * r);
+                if (alive) u = -2.0 * hm_asin(0.25 * r);
             } else if (isLRSR) {                          // LRSR :311-323
                 alive = r >= 2.0;
                 if (alive) { t = th; u = 2.0 - r; v = rs_M(t + 0.5 * PI - sp); }
@@ -378,25 +378,25 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
                 if (g == 5) {
                     double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
                     alive = rho <= 1.0;
-                    if (alive) { u = acos(rho); vv = -u; }
+                    if (alive) { u = hm_acos(rho); vv = -u; }
                 } else {
                     double rho = (20.0 - xi * xi - eta * eta) / 16.0;
                     alive = 0.0 <= rho && rho <= 1.0;
-                    if (alive) { u = -acos(rho); alive = u >= -0.5 * PI; vv = u; }
+                    if (alive) { u = -hm_acos(rho); alive = u >= -0.5 * PI; vv = u; }
                 }
                 if (alive) {
                     double delta = rs_M(u - vv);
                     double su, cu, sd, cd;
-                    sincos(u, &su, &cu);
-                    sincos(delta, &sd, &cd);
+                    hm_sincos(u, &su, &cu);
+                    hm_sincos(delta, &sd, &cd);
                     double A = su - sd;
                     double B = cu - cd - 1.0;
                     cy = eta * A - xi * B; cx = xi * A + eta * B; needC = true;
-                    t2 = 2.0 * (cd - cos(vv) - cu) + 3.0;
+                    t2 = 2.0 * (cd - hm_cos(vv) - cu) + 3.0;
                 }
             }
             double th2 = 0;
-            if (alive && needC) th2 = atan2(cy, cx);
+            if (alive && needC) th2 = hm_atan2(cy, cx);
             if (alive) {
                 if (g == 1) { v = rs_M(sp - t); ok = v >= 0.0; }
                 else if (g == 2) { t = rs_M(th + th2); v = rs_M(t - sp); ok = t >= 0.0 && v >= 0.0; }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     const double* st = p.state + (size_t)scene * ST_WORDS;
     const double q0x = st[0], q0y = st[1], q0w = st[2];
     const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
-    const double c_q = cos(-q0w), s_q = sin(-q0w);
+    const double c_q = hm_cos(-q0w), s_q = hm_sin(-q0w);
     const double step = RS_STEP * MAXC;                   // step_size * maxc (:44)
     wsync();
 
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
         // Segment origins first.  The origin headings are plain sums (oyaw_{i+1} = oyaw_i +- l_i), so every
         // sine/cosine the path needs -- of the five origin headings and of the five segment lengths (for the
         // segment end points, interpolate(ind, l, ...) :497-498) -- comes from ONE lane-parallel sincos
-        // (lanes 0-4: headings, lanes 5-9: lengths); cos(-x) = cos x and sin(-x) = -sin x give :522-523.
+        // (lanes 0-4: headings, lanes 5-9: lengths); hm_cos(-x) = cos x and hm_sin(-x) = -sin x give :522-523.
         bool invalid = false;
         {
             double hy[5];
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
                 if (lane == 5 + i) arg = len[i];
             }
             double sv, cv;
-            sincos(arg, &sv, &cv);
+            hm_sincos(arg, &sv, &cv);
             double ox = 0, oy = 0;
             wsync();
 #pragma unroll

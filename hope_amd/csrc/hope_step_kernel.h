@@ -254,18 +254,18 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
     }
     speed = clipd(speed, SPEED_LO, SPEED_HI);
     steer = clipd(steer, STEER_LO, STEER_HI);
-    const double dh = speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
+    const double dh = speed * hm_tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
     double* out = buf + threadIdx.x * KIN_WORDS;
     for (int k = 0; k < NUM_STEP; k++) {
         for (int j = 0; j < MINI_ITER; j++) {
             double s_, c_;
-            sincos(h, &s_, &c_);
+            hm_sincos(h, &s_, &c_);
             x += speed * c_ * STEP_LENGTH / MINI_ITER;
             y += speed * s_ * STEP_LENGTH / MINI_ITER;
             h += dh;
         }
         double sb, cb;
-        sincos(h, &sb, &cb);
+        hm_sincos(h, &sb, &cb);
         out[k] = h; out[10 + k] = cb; out[20 + k] = sb; out[30 + k] = x; out[40 + k] = y;
     }
     __syncthreads();
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     }
     t += 1;                                                             // :277
 
-    if (!have_cs) sincos(h, &sn, &ct);
+    if (!have_cs) hm_sincos(h, &sn, &ct);
     Box box = make_box(x, y, ct, sn);
 
     // ---- status (:279-282, _check_status :175-184) -------------------------------------------------
@@ -390,14 +390,14 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (p.stages & HOPE_STAGE_REWARD) {
         if (status == HOPE_STATUS_CONTINUE) {
             if (!have_ua) { ua = overlap_area(box, dbox, scr + LDS_SH, lane); have_ua = true; }
-            ri0 = -tanh((double)t / (10 * TOLERANT_TIME));
+            ri0 = -hm_tanh((double)t / (10 * TOLERANT_TIME));
             double ddx = x - destx, ddy = y - desty;
             double dist_diff = sqrt(ddx * ddx + ddy * ddy);
             double pdx = prev_x - destx, pdy = prev_y - desty;
             double prev_dist_diff = sqrt(pdx * pdx + pdy * pdy);
-            double ad = acos(cos(h - desth));
+            double ad = hm_acos(hm_cos(h - desth));
             ad = ad < PI / 2 ? ad : PI - ad;
-            double pad = acos(cos(prev_h - desth));
+            double pad = hm_acos(hm_cos(prev_h - desth));
             pad = pad < PI / 2 ? pad : PI - pad;
             const double dnorm = sc[SC_DNORM];
             ri2 = prev_dist_diff / dnorm - dist_diff / dnorm;
@@ -450,14 +450,14 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (p.out.target && lane == 0) {
         double rdx = destx - x, rdy = desty - y;
         double rel_distance = sqrt(rdx * rdx + rdy * rdy);
-        double rel_angle = atan2(rdy, rdx) - h;
+        double rel_angle = hm_atan2(rdy, rdx) - h;
         double rel_dest_heading = desth - h;
         OT* tg = (OT*)p.out.target + 5 * (size_t)scene;
         tg[0] = (OT)rel_distance;
-        tg[1] = (OT)cos(rel_angle);
-        tg[2] = (OT)sin(rel_angle);
-        tg[3] = (OT)cos(rel_dest_heading);
-        tg[4] = (OT)cos(rel_dest_heading);
+        tg[1] = (OT)hm_cos(rel_angle);
+        tg[2] = (OT)hm_sin(rel_angle);
+        tg[3] = (OT)hm_cos(rel_dest_heading);
+        tg[4] = (OT)hm_cos(rel_dest_heading);
     }
 
     // ---- lidar (lidar_simulator.py:31-135) -----------------------------------------------------------

@@ -24,6 +24,22 @@
  */
 #include <math.h>
 #include <stdint.h>
+
+/* Deterministic elementary functions shared with the HIP kernels (see the header for why).  The oracle stays an
+ * independent restatement of the reference ALGORITHM; only sin/cos/atan2/... come from this common header, and
+ * they are validated against libm in tests/test_math.py.  Build with -DORC_USE_LIBM to use glibc instead. */
+#include "../hope_amd/csrc/hope_math.h"
+#ifdef ORC_USE_LIBM
+#define hm_sin sin
+#define hm_cos cos
+#define hm_tan tan
+#define hm_atan2 atan2
+#define hm_asin asin
+#define hm_acos acos
+#define hm_hypot hypot
+#define hm_fmod fmod
+#define hm_tanh tanh
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -93,16 +109,16 @@ static void build_vehicle_boxes(void) {
     double car[4][2];
     vehicle_box_local(car);
     for (int a = 0; a < NACT; a++) {
-        double radius = 1 / (tan(g_actions[a][0]) / WHEEL_BASE);
-        double Ox = 0 - radius * sin(0.0);
-        double Oy = 0 + radius * cos(0.0);
+        double radius = 1 / (hm_tan(g_actions[a][0]) / WHEEL_BASE);
+        double Ox = 0 - radius * hm_sin(0.0);
+        double Oy = 0 + radius * hm_cos(0.0);
         double delta_phi = 0.5 * g_actions[a][1] / 10 / radius;
         double ptheta = 0;
         for (int k = 0; k < NITER; k++) {
             ptheta = ptheta + delta_phi;
-            double px = Ox + radius * sin(ptheta);
-            double py = Oy - radius * cos(ptheta);
-            double ct = cos(ptheta), st = sin(ptheta);
+            double px = Ox + radius * hm_sin(ptheta);
+            double py = Oy - radius * hm_cos(ptheta);
+            double ct = hm_cos(ptheta), st = hm_sin(ptheta);
             for (int v = 0; v < 4; v++) {
                 g_boxes[a][k][v][0] = ct * car[v][0] - st * car[v][1] + px;
                 g_boxes[a][k][v][1] = st * car[v][0] + ct * car[v][1] + py;
@@ -136,12 +152,12 @@ static double hull_range(double ex, double ey) {
 
 static void build_hull_base(void) {
     for (int l = 0; l < NBEAM; l++) {
-        /* action_mask.py:25-26: np.cos(l*np.pi/lidar_num*2)*lidar_range */
+        /* action_mask.py:25-26: np.hm_cos(l*np.pi/lidar_num*2)*lidar_range */
         double th = l * PI / NBEAM * 2;
-        g_hull_base[l] = hull_range(cos(th) * LIDAR_RANGE, sin(th) * LIDAR_RANGE);
+        g_hull_base[l] = hull_range(hm_cos(th) * LIDAR_RANGE, hm_sin(th) * LIDAR_RANGE);
         /* lidar_simulator.py:86-88: theta = a*pi/lidar_num*2 ; a=sin, b=-cos */
-        g_beam_a[l] = sin(th);
-        g_beam_b[l] = -cos(th);
+        g_beam_a[l] = hm_sin(th);
+        g_beam_b[l] = -hm_cos(th);
     }
 }
 
@@ -176,7 +192,7 @@ static void build_dist_star(void) {
     const double max_distance = LIDAR_RANGE * 10;
     for (int l = 0; l < NBEAM; l++) {
         double ang = (double)l / NBEAM * 2 * PI; /* lidar_line_idx/lidar_num*2*np.pi */
-        double ex = cos(ang) * max_distance, ey = sin(ang) * max_distance;
+        double ex = hm_cos(ang) * max_distance, ey = hm_sin(ang) * max_distance;
         for (int a = 0; a < NACT; a++)
             for (int k = 0; k < NITER; k++) {
                 double best = -INFINITY;
@@ -240,7 +256,7 @@ void orc_get_tables(double *actions, double *boxes, double *hull_base, double *b
 
 /* Inject tables (any pointer may be NULL = keep).  The beam sin/cos table matters bit-for-bit:
  * the reference's lidar has tolerance-free bbox tests, so a hit on an exactly axis-aligned
- * edge depends on the last ulp of sin/cos(theta_i), which numpy (SIMD) and libm round
+ * edge depends on the last ulp of sin/hm_cos(theta_i), which numpy (SIMD) and libm round
  * differently on some beams.  Tests pin the oracle to the reference's captured table. */
 void orc_set_tables(const double *hull_base, const double *beam_a, const double *beam_b, const double *dist_star) {
     orc_init();
@@ -262,9 +278,9 @@ void orc_ks_step(double *pose, const double *action, double *speed_steer) {
     steer = clipd(steer, VALID_STEER_LO, VALID_STEER_HI);
     const int mini_iter = 20;
     for (int it = 0; it < mini_iter; it++) {
-        x += speed * cos(h) * STEP_LENGTH / mini_iter;
-        y += speed * sin(h) * STEP_LENGTH / mini_iter;
-        h += speed * tan(steer) / WHEEL_BASE * STEP_LENGTH / mini_iter;
+        x += speed * hm_cos(h) * STEP_LENGTH / mini_iter;
+        y += speed * hm_sin(h) * STEP_LENGTH / mini_iter;
+        h += speed * hm_tan(steer) / WHEEL_BASE * STEP_LENGTH / mini_iter;
     }
     pose[0] = x; pose[1] = y; pose[2] = h;
     if (speed_steer) { speed_steer[0] = speed; speed_steer[1] = steer; }
@@ -274,7 +290,7 @@ void orc_ks_step(double *pose, const double *action, double *speed_steer) {
 void orc_create_box(const double *pose, double *box /*[4][2]*/) {
     double car[4][2];
     vehicle_box_local(car);
-    double ct = cos(pose[2]), st = sin(pose[2]);
+    double ct = hm_cos(pose[2]), st = hm_sin(pose[2]);
     for (int v = 0; v < 4; v++) {
         box[2 * v] = ct * car[v][0] + (-st) * car[v][1] + pose[0];
         box[2 * v + 1] = st * car[v][0] + ct * car[v][1] + pose[1];
@@ -494,7 +510,7 @@ void orc_lidar_observation(const double *pose, const double *verts, const int32_
                            double *out) {
     orc_init();
     double x = pose[0], y = pose[1], theta = pose[2];
-    double a = cos(theta), b = sin(theta);
+    double a = hm_cos(theta), b = hm_sin(theta);
     double x_off = -x * a - y * b;
     double y_off = x * b - y * a;
     double *rv = (double *)malloc(sizeof(double) * 8 * (n_obst > 0 ? n_obst : 1));
@@ -604,7 +620,7 @@ typedef struct { rs_word w[RS_MAXP]; int n; } rs_set;
 
 /* Python float %: result takes the sign of the divisor */
 static double py_mod(double v, double w) {
-    double m = fmod(v, w);
+    double m = hm_fmod(v, w);
     if (m != 0) { if ((w < 0) != (m < 0)) m += w; } else m = copysign(0.0, w);
     return m;
 }
@@ -614,7 +630,7 @@ static double rs_M(double theta) { /* :581-592 */
     if (phi > PI) phi -= 2.0 * PI;
     return phi;
 }
-static void rs_R(double x, double y, double *r, double *th) { *r = hypot(x, y); *th = atan2(y, x); } /* :571 */
+static void rs_R(double x, double y, double *r, double *th) { *r = hm_hypot(x, y); *th = hm_atan2(y, x); } /* :571 */
 static double pi_2_pi(double t) { /* :561-568 */
     while (t > PI) t -= 2.0 * PI;
     while (t < -PI) t += 2.0 * PI;
@@ -648,23 +664,23 @@ static void set_path(rs_set *ps, const double *lengths, const int *ct, int n) {
 static int rs_SLS(double x, double y, double phi, double *t, double *u, double *v) { /* :133-149 */
     phi = rs_M(phi);
     if (y > 0.0 && 0.0 < phi && phi < PI * 0.99) {
-        double xd = -y / tan(phi) + x;
-        *t = xd - tan(phi / 2.0);
+        double xd = -y / hm_tan(phi) + x;
+        *t = xd - hm_tan(phi / 2.0);
         *u = phi;
-        *v = sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        *v = sqrt((x - xd) * (x - xd) + y * y) - hm_tan(phi / 2.0);
         return 1;
     } else if (y < 0.0 && 0.0 < phi && phi < PI * 0.99) {
-        double xd = -y / tan(phi) + x;
-        *t = xd - tan(phi / 2.0);
+        double xd = -y / hm_tan(phi) + x;
+        *t = xd - hm_tan(phi / 2.0);
         *u = phi;
-        *v = -sqrt((x - xd) * (x - xd) + y * y) - tan(phi / 2.0);
+        *v = -sqrt((x - xd) * (x - xd) + y * y) - hm_tan(phi / 2.0);
         return 1;
     }
     return 0;
 }
 static int rs_LSL(double x, double y, double phi, double *t, double *u, double *v) { /* :79-87 */
     double uu, tt;
-    rs_R(x - sin(phi), y - 1.0 + cos(phi), &uu, &tt);
+    rs_R(x - hm_sin(phi), y - 1.0 + hm_cos(phi), &uu, &tt);
     if (tt >= 0.0) {
         double vv = rs_M(phi - tt);
         if (vv >= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
@@ -673,11 +689,11 @@ static int rs_LSL(double x, double y, double phi, double *t, double *u, double *
 }
 static int rs_LSR(double x, double y, double phi, double *t, double *u, double *v) { /* :90-103 */
     double u1, t1;
-    rs_R(x + sin(phi), y - 1.0 - cos(phi), &u1, &t1);
+    rs_R(x + hm_sin(phi), y - 1.0 - hm_cos(phi), &u1, &t1);
     u1 = u1 * u1;
     if (u1 >= 4.0) {
         double uu = sqrt(u1 - 4.0);
-        double theta = atan2(2.0, uu);
+        double theta = hm_atan2(2.0, uu);
         double tt = rs_M(t1 + theta);
         double vv = rs_M(tt - phi);
         if (tt >= 0.0 && vv >= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
@@ -686,9 +702,9 @@ static int rs_LSR(double x, double y, double phi, double *t, double *u, double *
 }
 static int rs_LRL(double x, double y, double phi, double *t, double *u, double *v) { /* :106-117 */
     double u1, t1;
-    rs_R(x - sin(phi), y - 1.0 + cos(phi), &u1, &t1);
+    rs_R(x - hm_sin(phi), y - 1.0 + hm_cos(phi), &u1, &t1);
     if (u1 <= 4.0) {
-        double uu = -2.0 * asin(0.25 * u1);
+        double uu = -2.0 * hm_asin(0.25 * u1);
         double tt = rs_M(t1 + 0.5 * uu + PI);
         double vv = rs_M(phi - tt + uu);
         if (tt >= 0.0 && uu <= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
@@ -697,28 +713,28 @@ static int rs_LRL(double x, double y, double phi, double *t, double *u, double *
 }
 static void calc_tauOmega(double u, double v, double xi, double eta, double phi, double *tau, double *omega) {
     double delta = rs_M(u - v); /* :228-243 */
-    double A = sin(u) - sin(delta);
-    double B = cos(u) - cos(delta) - 1.0;
-    double t1 = atan2(eta * A - xi * B, xi * A + eta * B);
-    double t2 = 2.0 * (cos(delta) - cos(v) - cos(u)) + 3.0;
+    double A = hm_sin(u) - hm_sin(delta);
+    double B = hm_cos(u) - hm_cos(delta) - 1.0;
+    double t1 = hm_atan2(eta * A - xi * B, xi * A + eta * B);
+    double t2 = 2.0 * (hm_cos(delta) - hm_cos(v) - hm_cos(u)) + 3.0;
     if (t2 < 0) *tau = rs_M(t1 + PI); else *tau = rs_M(t1);
     *omega = rs_M(*tau - u + v - phi);
 }
 static int rs_LRLRn(double x, double y, double phi, double *t, double *u, double *v) { /* :246-257 */
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi);
     double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
     if (rho <= 1.0) {
-        double uu = acos(rho), tt, vv;
+        double uu = hm_acos(rho), tt, vv;
         calc_tauOmega(uu, -uu, xi, eta, phi, &tt, &vv);
         if (tt >= 0.0 && vv <= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
     }
     return 0;
 }
 static int rs_LRLRp(double x, double y, double phi, double *t, double *u, double *v) { /* :260-272 */
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi);
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi);
     double rho = (20.0 - xi * xi - eta * eta) / 16.0;
     if (0.0 <= rho && rho <= 1.0) {
-        double uu = -acos(rho);
+        double uu = -hm_acos(rho);
         if (uu >= -0.5 * PI) {
             double tt, vv;
             calc_tauOmega(uu, uu, xi, eta, phi, &tt, &vv);
@@ -728,7 +744,7 @@ static int rs_LRLRp(double x, double y, double phi, double *t, double *u, double
     return 0;
 }
 static int rs_LRSR(double x, double y, double phi, double *t, double *u, double *v) { /* :311-323 */
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi), rho, theta;
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi), rho, theta;
     rs_R(-eta, xi, &rho, &theta);
     if (rho >= 2.0) {
         double tt = theta, uu = 2.0 - rho, vv = rs_M(tt + 0.5 * PI - phi);
@@ -737,24 +753,24 @@ static int rs_LRSR(double x, double y, double phi, double *t, double *u, double 
     return 0;
 }
 static int rs_LRSL(double x, double y, double phi, double *t, double *u, double *v) { /* :326-339 */
-    double xi = x - sin(phi), eta = y - 1.0 + cos(phi), rho, theta;
+    double xi = x - hm_sin(phi), eta = y - 1.0 + hm_cos(phi), rho, theta;
     rs_R(xi, eta, &rho, &theta);
     if (rho >= 2.0) {
         double r = sqrt(rho * rho - 4.0);
         double uu = 2.0 - r;
-        double tt = rs_M(theta + atan2(r, -2.0));
+        double tt = rs_M(theta + hm_atan2(r, -2.0));
         double vv = rs_M(phi - 0.5 * PI - tt);
         if (tt >= 0.0 && uu <= 0.0 && vv <= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
     }
     return 0;
 }
 static int rs_LRSLR(double x, double y, double phi, double *t, double *u, double *v) { /* :414-429 */
-    double xi = x + sin(phi), eta = y - 1.0 - cos(phi), rho, theta;
+    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi), rho, theta;
     rs_R(xi, eta, &rho, &theta);
     if (rho >= 2.0) {
         double uu = 4.0 - sqrt(rho * rho - 4.0);
         if (uu <= 0.0) {
-            double tt = rs_M(atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
+            double tt = rs_M(hm_atan2((4.0 - uu) * xi - 2.0 * eta, -2.0 * xi + (uu - 4.0) * eta));
             double vv = rs_M(tt - phi);
             if (tt >= 0.0 && vv >= 0.0) { *t = tt; *u = uu; *v = vv; return 1; }
         }
@@ -769,7 +785,7 @@ static int rs_LRSLR(double x, double y, double phi, double *t, double *u, double
 /* :540-557 generate_path (+ SCS :120, CSC :152, CCC :188, CCCC :275, CCSC :342, CCSCC :432) */
 static void rs_generate_path(const double *q0, const double *q1, double maxc, rs_set *ps) {
     double dx = q1[0] - q0[0], dy = q1[1] - q0[1], dth = q1[2] - q0[2];
-    double c = cos(q0[2]), s = sin(q0[2]);
+    double c = hm_cos(q0[2]), s = hm_sin(q0[2]);
     double x = (c * dx + s * dy) * maxc;
     double y = (-s * dx + c * dy) * maxc;
     double phi = dth, t, u, v;
@@ -794,8 +810,8 @@ static void rs_generate_path(const double *q0, const double *q1, double maxc, rs
     if (rs_LRL(x, -y, -phi, &t, &u, &v)) SP3(t, u, v, R, L, R);
     if (rs_LRL(-x, -y, phi, &t, &u, &v)) SP3(-t, -u, -v, R, L, R);
     {
-        double xb = x * cos(phi) + y * sin(phi);
-        double yb = x * sin(phi) - y * cos(phi);
+        double xb = x * hm_cos(phi) + y * hm_sin(phi);
+        double yb = x * hm_sin(phi) - y * hm_cos(phi);
         if (rs_LRL(xb, yb, phi, &t, &u, &v)) SP3(v, u, t, L, R, L);
         if (rs_LRL(-xb, yb, -phi, &t, &u, &v)) SP3(-v, -u, -t, L, R, L);
         if (rs_LRL(xb, -yb, -phi, &t, &u, &v)) SP3(v, u, t, R, L, R);
@@ -820,8 +836,8 @@ static void rs_generate_path(const double *q0, const double *q1, double maxc, rs
     if (rs_LRSR(x, -y, -phi, &t, &u, &v)) SP4(t, -hp, u, v, R, L, S, L);
     if (rs_LRSR(-x, -y, phi, &t, &u, &v)) SP4(-t, hp, -u, -v, R, L, S, L);
     {
-        double xb = x * cos(phi) + y * sin(phi);
-        double yb = x * sin(phi) - y * cos(phi);
+        double xb = x * hm_cos(phi) + y * hm_sin(phi);
+        double yb = x * hm_sin(phi) - y * hm_cos(phi);
         if (rs_LRSL(xb, yb, phi, &t, &u, &v)) SP4(v, u, -hp, t, L, S, R, L);
         if (rs_LRSL(-xb, yb, -phi, &t, &u, &v)) SP4(-v, -u, hp, -t, L, S, R, L);
         if (rs_LRSL(xb, -yb, -phi, &t, &u, &v)) SP4(v, u, -hp, t, R, S, L, R);
@@ -842,15 +858,15 @@ static void rs_generate_path(const double *q0, const double *q1, double maxc, rs
 static void rs_interpolate(int ind, double l, int m, double maxc, double ox, double oy, double oyaw,
                            double *px, double *py, double *pyaw, int *dir) {
     if (m == C_S) {
-        px[ind] = ox + l / maxc * cos(oyaw);
-        py[ind] = oy + l / maxc * sin(oyaw);
+        px[ind] = ox + l / maxc * hm_cos(oyaw);
+        py[ind] = oy + l / maxc * hm_sin(oyaw);
         pyaw[ind] = oyaw;
     } else {
-        double ldx = sin(l) / maxc, ldy = 0;
-        if (m == C_L) ldy = (1.0 - cos(l)) / maxc;
-        else if (m == C_R) ldy = (1.0 - cos(l)) / (-maxc);
-        double gdx = cos(-oyaw) * ldx + sin(-oyaw) * ldy;
-        double gdy = -sin(-oyaw) * ldx + cos(-oyaw) * ldy;
+        double ldx = hm_sin(l) / maxc, ldy = 0;
+        if (m == C_L) ldy = (1.0 - hm_cos(l)) / maxc;
+        else if (m == C_R) ldy = (1.0 - hm_cos(l)) / (-maxc);
+        double gdx = hm_cos(-oyaw) * ldx + hm_sin(-oyaw) * ldy;
+        double gdy = -hm_sin(-oyaw) * ldx + hm_cos(-oyaw) * ldy;
         px[ind] = ox + gdx;
         py[ind] = oy + gdy;
     }
@@ -920,8 +936,8 @@ static int rs_calc_all_paths(const double *q0, const double *q1, double maxc, do
         p->yaw = lyaw;
         p->dir = ldir;
         for (int k = 0; k < n; k++) {
-            p->x[k] = cos(-q0[2]) * lx[k] + sin(-q0[2]) * ly[k] + q0[0];
-            p->y[k] = -sin(-q0[2]) * lx[k] + cos(-q0[2]) * ly[k] + q0[1];
+            p->x[k] = hm_cos(-q0[2]) * lx[k] + hm_sin(-q0[2]) * ly[k] + q0[0];
+            p->y[k] = -hm_sin(-q0[2]) * lx[k] + hm_cos(-q0[2]) * ly[k] + q0[1];
             p->yaw[k] = pi_2_pi(lyaw[k] + q0[2]);
         }
         free(lx);
@@ -993,7 +1009,7 @@ int orc_is_traj_valid(const double *traj, int T, const double *verts, const int3
     double *vx2 = (double *)malloc(sizeof(double) * 4 * T), *vy2 = (double *)malloc(sizeof(double) * 4 * T);
     double x_max = -INFINITY, x_min = INFINITY, y_max = -INFINITY, y_min = INFINITY;
     for (int t = 0; t < T; t++) {
-        double ct = cos(traj[3 * t + 2]), st = sin(traj[3 * t + 2]);
+        double ct = hm_cos(traj[3 * t + 2]), st = hm_sin(traj[3 * t + 2]);
         double vx = traj[3 * t], vy = traj[3 * t + 1];
         for (int k = 0; k < 4; k++) {
             int k2 = (k + 1) & 3;
@@ -1086,7 +1102,9 @@ static int hd_pop(hd_t *h) {
 int orc_find_rs_path(const double *pose, const double *dest, const double *verts, const int32_t *nvert,
                      int n_obst, const double *bbox, int32_t *out_nseg, int32_t *out_ct, double *out_len,
                      double *out_L, int32_t *out_ntested) {
-    double radius = tan(VALID_STEER_HI) / WHEEL_BASE;
+    /* math.tan(VALID_STEER[-1]) / WHEEL_BASE (car_parking_base.py:422) as Python's math (glibc) evaluates it; the
+     * value is a constant of the path, kept literal so that both math flavours and the kernels share it */
+    const double radius = 0.3327130214085973;
     rs_path P[RS_MAXP];
     int n = rs_calc_all_paths(pose, dest, radius, 0.1, P);
     int found = 0, ntested = 0;
@@ -1135,17 +1153,17 @@ int orc_find_rs_path(const double *pose, const double *dest, const double *verts
 /* car_parking_base.py:372-381 _get_targt_repr (5th entry is cos again, :380) */
 void orc_target_repr(const double *ego, const double *dest, double *out) {
     double rel_distance = sqrt((dest[0] - ego[0]) * (dest[0] - ego[0]) + (dest[1] - ego[1]) * (dest[1] - ego[1]));
-    double rel_angle = atan2(dest[1] - ego[1], dest[0] - ego[0]) - ego[2];
+    double rel_angle = hm_atan2(dest[1] - ego[1], dest[0] - ego[0]) - ego[2];
     double rel_dest_heading = dest[2] - ego[2];
     out[0] = rel_distance;
-    out[1] = cos(rel_angle);
-    out[2] = sin(rel_angle);
-    out[3] = cos(rel_dest_heading);
-    out[4] = cos(rel_dest_heading);
+    out[1] = hm_cos(rel_angle);
+    out[2] = hm_sin(rel_angle);
+    out[3] = hm_cos(rel_dest_heading);
+    out[4] = hm_cos(rel_dest_heading);
 }
 
 static double angle_diff(double a1, double a2) { /* :203-206 */
-    double d = acos(cos(a1 - a2));
+    double d = hm_acos(hm_cos(a1 - a2));
     return d < PI / 2 ? d : PI - d;
 }
 static double pdist(double ax, double ay, double bx, double by) { /* Point.distance */
@@ -1157,7 +1175,7 @@ static double pdist(double ax, double ay, double bx, double by) { /* Point.dista
  * (union_area = |hull ∩ dest|, dest_area = |dest|).  accum in/out. */
 void orc_reward_terms(const double *prev, const double *cur, const double *dest, const double *start,
                       double t, double union_area, double dest_area, double *accum, double *out) {
-    double time_cost = -tanh(t / (10 * TOLERANT_TIME));
+    double time_cost = -hm_tanh(t / (10 * TOLERANT_TIME));
     double rs_dist_reward = 0; /* REWARD_WEIGHT['rs_dist_reward'] == 0 (:192) */
     double dist_diff = pdist(cur[0], cur[1], dest[0], dest[1]);
     double ang = angle_diff(cur[2], dest[2]);
@@ -1367,4 +1385,26 @@ int orc_num_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* elementary-function test hook: fn 0 sin, 1 cos, 2 tan, 3 atan2(a,b), 4 asin, 5 acos, 6 hypot(a,b), 7 fmod(a,b), 8 tanh,
+ * 9 exp, 10 sqrt, 11 a/b */
+void orc_math(int fn, int n, const double *a, const double *b, double *out) {
+    for (int i = 0; i < n; i++) {
+        double x = a[i], y = b ? b[i] : 0.0;
+        switch (fn) {
+            case 0: out[i] = hm_sin(x); break;
+            case 1: out[i] = hm_cos(x); break;
+            case 2: out[i] = hm_tan(x); break;
+            case 3: out[i] = hm_atan2(x, y); break;
+            case 4: out[i] = hm_asin(x); break;
+            case 5: out[i] = hm_acos(x); break;
+            case 6: out[i] = hm_hypot(x, y); break;
+            case 7: out[i] = hm_fmod(x, y); break;
+            case 8: out[i] = hm_tanh(x); break;
+            case 9: out[i] = hm_exp(x); break;
+            case 10: out[i] = sqrt(x); break;
+            default: out[i] = x / y; break;
+        }
+    }
 }

@@ -15,21 +15,29 @@ CT_NAMES = {0: 'S', 1: 'L', 2: 'R'}
 
 
 def build(force=False):
-    so = os.path.join(_HERE, '_build', 'libhope_oracle.so')
+    so = os.path.join(_HERE, '_build', 'libhope_oracle_libm.so')
     src = os.path.join(_HERE, 'hope_oracle.c')
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    hdr = os.path.join(os.path.dirname(_HERE), 'hope_amd', 'csrc', 'hope_math.h')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(['make', '-C', _HERE, '-s'])
     return so
 
 
 _libs = {}
+_flavour = {'libm': False}
+
+
+def use_libm(flag):
+    """select the glibc-math build (strict pinning against the reference vectors) for the single-thread library;
+    default is the hope_math.h build that is bit-compatible with the HIP kernels."""
+    _flavour['libm'] = bool(flag)
 
 
 def lib(omp=False):
-    key = 'omp' if omp else 'st'
+    key = 'omp' if omp else ('libm' if _flavour['libm'] else 'st')
     if key not in _libs:
         build()
-        name = 'libhope_oracle_omp.so' if omp else 'libhope_oracle.so'
+        name = {'omp': 'libhope_oracle_omp.so', 'st': 'libhope_oracle.so', 'libm': 'libhope_oracle_libm.so'}[key]
         L = C.CDLL(os.path.join(_HERE, '_build', name))
         L.orc_init()
         L.orc_quad_intersection_area.restype = C.c_double
@@ -72,6 +80,15 @@ def set_dist_star_coarse(coarse):
     assert c.shape == (NBEAM, NACT, NITER)
     for flavour in (False, True):
         lib(flavour).orc_set_dist_star_coarse(_p(c))
+
+
+def math_fn(fn, a, b=None):
+    """evaluate one of hope_math.h's functions on the host (fn: see orc_math in hope_oracle.c)."""
+    a = _f64(a)
+    bb = _f64(b) if b is not None else None
+    out = np.zeros_like(a)
+    lib().orc_math(C.c_int(fn), C.c_int(a.size), _p(a), _p(bb), _p(out))
+    return out
 
 
 def ks_step(pose, action):

@@ -1,0 +1,71 @@
+"""hope_amd/csrc/hope_math.h: accuracy against libm on the host, and (-m gpu) bit-equality device vs host."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+FN = dict(sin=0, cos=1, tan=2, atan2=3, asin=4, acos=5, hypot=6, fmod=7, tanh=8, exp=9, sqrt=10, div=11)
+
+
+def ulps(got, want):
+    return np.abs(got - want) / np.spacing(np.abs(want) + 1e-300)
+
+
+def inputs(seed=0):
+    rng = np.random.default_rng(seed)
+    x = np.concatenate([rng.uniform(-100, 100, 100000), rng.uniform(-7, 7, 100000), rng.uniform(-1e4, 1e4, 20000),
+                        [0.0, -0.0, 1e-300, math.pi / 2, math.pi, -math.pi, 1e-9, 0.75, -0.75]])
+    y, xx = rng.normal(0, 5, len(x)), rng.normal(0, 5, len(x))
+    y[:8] = [0.0, 0.0, 1.0, -1.0, 0.0, -0.0, 2.0, 0.0]
+    xx[:8] = [1.0, -1.0, 0.0, 0.0, 0.0, -1.0, -2.0, -0.0]
+    z = np.concatenate([rng.uniform(-1, 1, len(x) - 4), [1.0, -1.0, 0.0, 0.25]])
+    w = np.concatenate([rng.uniform(-0.15, 0.15, len(x) // 2), rng.uniform(-6, 6, len(x) - len(x) // 2)])
+    return x, y, xx, z, w
+
+
+def test_accuracy_against_libm():
+    x, y, xx, z, w = inputs()
+    assert ulps(O.math_fn(FN['sin'], x), np.sin(x)).max() <= 2
+    assert ulps(O.math_fn(FN['cos'], x), np.cos(x)).max() <= 2
+    assert ulps(O.math_fn(FN['tan'], x), np.tan(x)).max() <= 4
+    assert ulps(O.math_fn(FN['atan2'], y, xx), np.arctan2(y, xx)).max() <= 2
+    assert ulps(O.math_fn(FN['asin'], z), np.arcsin(z)).max() <= 3
+    assert ulps(O.math_fn(FN['acos'], z), np.arccos(z)).max() <= 3
+    assert ulps(O.math_fn(FN['hypot'], y, xx), np.hypot(y, xx)).max() <= 1
+    assert np.array_equal(O.math_fn(FN['fmod'], x, np.full_like(x, 2 * math.pi)), np.fmod(x, 2 * math.pi))
+    assert ulps(O.math_fn(FN['tanh'], w), np.tanh(w)).max() <= 3
+    assert ulps(O.math_fn(FN['exp'], w * 4), np.exp(w * 4)).max() <= 2
+    # exact symmetries the kernels rely on (reeds_shepp.py:522-523 uses cos(-x), sin(-x))
+    assert np.array_equal(O.math_fn(FN['sin'], -x), -O.math_fn(FN['sin'], x))
+    assert np.array_equal(O.math_fn(FN['cos'], -x), O.math_fn(FN['cos'], x))
+    # zeros: C semantics
+    for a, b in [(0.0, 1.0), (0.0, -1.0), (-0.0, -1.0), (1.0, 0.0), (-1.0, 0.0), (0.0, 0.0)]:
+        assert O.math_fn(FN['atan2'], [a], [b])[0] == math.atan2(a, b)
+
+
+@pytest.mark.gpu
+def test_device_equals_host_bit_for_bit():
+    """same source, IEEE-exact operations only, contraction off -> identical bits on gfx950 and x86-64
+    (also pins the device's float64 sqrt and division as correctly rounded)."""
+    torch = pytest.importorskip('torch')
+    from hope_amd import _lib as L
+    lib = L.load_library()
+    x, y, xx, z, w = inputs(1)
+    cases = [('sin', x, None), ('cos', x, None), ('tan', x, None), ('atan2', y, xx), ('asin', z, None), ('acos', z, None),
+             ('hypot', y, xx), ('fmod', x, np.full_like(x, 2 * math.pi)), ('tanh', w, None), ('exp', w * 4, None),
+             ('sqrt', np.abs(x), None), ('div', y, xx)]
+    for name, a, b in cases:
+        ta = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        tb = torch.from_numpy(np.ascontiguousarray(b)).cuda() if b is not None else None
+        out = torch.empty_like(ta)
+        L.check(lib.hope_debug_math(FN[name], ta.numel(), C.c_void_p(ta.data_ptr()),
+                                    C.c_void_p(tb.data_ptr()) if tb is not None else None,
+                                    C.c_void_p(out.data_ptr()), None), 'hope_debug_math')
+        torch.cuda.synchronize()
+        host = O.math_fn(FN[name], a, b)
+        dev = out.cpu().numpy()
+        same = (dev.view(np.int64) == host.view(np.int64)) | (np.isnan(dev) & np.isnan(host))
+        assert same.all(), (name, int((~same).sum()), a[~same][:3], dev[~same][:3], host[~same][:3])
