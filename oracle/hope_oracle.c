@@ -7,7 +7,10 @@
  * `cpu_baseline` ("port").  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it.  Nothing under hope_amd/ links, imports or calls it.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).  Two flavours: the default
+ * takes sin/cos/atan2/... from hope_amd/csrc/hope_math.h (deterministic, bit-compatible with the HIP kernels);
+ * -DORC_USE_LIBM takes them from glibc (what Python's math gave the reference run).  Both are pinned by
+ * tests/test_oracle_golden.py.
  *
  * Pinning status:
  *   - pinned against reference-generated golden vectors (tests/golden, .npz files): KSModel.step,
