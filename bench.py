@@ -8,9 +8,9 @@ MAX over ranks, rank 0 prints ONE JSON line.
 
 A "step" = one pass of the full hot path (CarParkingWrapper.step: kinematics + collision sub-steps,
 lidar, action mask, reward, Reeds-Shepp feasibility search) over a batch of `--scenes` synthetic
-scenes PER GPU (weak scaling; default 65 536 = BASELINE.json's "64k scenes"), followed by the
-episode turnover the reference's loop performs (`reset` of finished episodes: restart + the
-action-less observation step).  Inputs (scene tiles, actions) are resident in HBM when the timed
+scenes PER GPU (weak scaling; default 65 536 = BASELINE.json's "64k scenes"), including the
+episode turnover the reference's loop performs (`reset` of finished episodes on the same map and its
+action-less observation step), fused into the step kernel (HOPE_AUTO_RESET).  Inputs (scene tiles, actions) are resident in HBM when the timed
 region starts.  Independent scenes shard over ranks with no data-path collective.
 """
 import argparse
@@ -115,9 +115,8 @@ def main():
     act_bank = [torch.rand((N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
 
     def one_step(i):
-        env.step(act_bank[i % len(act_bank)], stages=stages)
-        env.restart(env.done)                      # episode turnover: finished scenes start over
-        env.reset_obs(active=env.done, stages=stages)
+        # episode turnover is fused into the step (HOPE_AUTO_RESET = step + restart(done) + reset_obs(active=done))
+        env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
 
     env.reset_obs(stages=stages)
     for i in range(args.warmup):
@@ -149,8 +148,8 @@ def main():
         value = total_scenes * args.steps / elapsed
         # Per-kernel HIP-event statistics recorded by the library around EVERY launch on the launch stream.
         # Dominant kernel = largest accumulated time.  `kernel_ms` is its AVERAGE LAUNCH duration (directly
-        # comparable with rocprofv3's AverageNs for that kernel: k_env_step is launched once per tile class for the
-        # step and once per class for the active-masked reset observation, i.e. 4 launches per bench step);
+        # comparable with rocprofv3's AverageNs for that kernel: k_env_step is launched once per tile class, i.e. 2
+        # launches per bench step);
         # `algorithmic bytes per launch` is averaged over the same launches, so achieved = bytes/launch / kernel_ms.
         per_step = {k: v[0] / max(args.steps, 1) for k, v in kstats.items()}
         dom = max(per_step, key=per_step.get)

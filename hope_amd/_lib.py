@@ -9,6 +9,7 @@ LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10,
 F_OBS_F64, F_ACTION_F64, F_PROFILE = 0x1, 0x2, 0x4
 STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 ACTION_PHYSICAL = 0x10
+AUTO_RESET = 0x20
 KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate')
 ABI_VERSION = 1
 

@@ -79,8 +79,11 @@ class ParkingBatch:
                 'hope_env_reset_obs')
         return self
 
-    def step(self, actions, active=None, stages=L.STAGE_ALL):
-        """actions: [N, 2] (steer, speed) in [-1, 1] on this device."""
+    def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False):
+        """actions: [N, 2] (steer, speed) in [-1, 1] on this device.  auto_reset=True: finished scenes restart inside
+        the step (their lidar / action_mask / target are the new episode's first observation)."""
+        if auto_reset:
+            stages |= L.AUTO_RESET
         assert actions.shape == (self.n, 2) and actions.dtype == self.action_dtype and actions.is_contiguous()
         assert actions.device == self.device
         ap = C.c_void_p(active.data_ptr()) if active is not None else None

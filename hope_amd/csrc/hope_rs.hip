@@ -230,15 +230,17 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         hmaxy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
     }
     if (__any(bad)) return bad;
-    // union box of the chunk
-    double uminx = hminx, umaxx = hmaxx, uminy = hminy, umaxy = hmaxy;
+    // union box of the pass: float, rounded outwards (only used to cull whole obstacles, so a superset is exact)
+    float ulox = active ? __double2float_rd(hminx) : INFINITY, uhix = active ? __double2float_ru(hmaxx) : -INFINITY;
+    float uloy = active ? __double2float_rd(hminy) : INFINITY, uhiy = active ? __double2float_ru(hmaxy) : -INFINITY;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        uminx = fmin(uminx, __shfl_xor(uminx, off));
-        umaxx = fmax(umaxx, __shfl_xor(umaxx, off));
-        uminy = fmin(uminy, __shfl_xor(uminy, off));
-        umaxy = fmax(umaxy, __shfl_xor(umaxy, off));
+        ulox = fminf(ulox, __shfl_xor(ulox, off));
+        uhix = fmaxf(uhix, __shfl_xor(uhix, off));
+        uloy = fminf(uloy, __shfl_xor(uloy, off));
+        uhiy = fmaxf(uhiy, __shfl_xor(uhiy, off));
     }
+    const double uminx = ulox, umaxx = uhix, uminy = uloy, umaxy = uhiy;
     int nc = 0;
     for (int base = 0; base < n_obst; base += WAVE) {
         int o = base + lane;

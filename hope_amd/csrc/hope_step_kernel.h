@@ -416,6 +416,30 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         reward *= 0.1;
     }
 
+    // ---- fused episode turnover (HOPE_AUTO_RESET): CarParking.reset on the same map + its action-less step -------
+    const bool turnover = (p.stages & HOPE_AUTO_RESET) && (p.stages & HOPE_STAGE_REWARD) && status != HOPE_STATUS_CONTINUE;
+    int rs_status = status;          // the RS gate below belongs to the finished step
+    if (turnover) {
+        x = sc[SC_START]; y = sc[SC_START + 1]; h = sc[SC_START + 2];
+        accum = 0.0;
+        t = 1;                                                          // reset: t = 0, then step() -> t = 1
+        hm_sincos(h, &sn, &ct);
+        box = make_box(x, y, ct, sn);
+        // the action-less step's status decides whether _get_reward runs (it only touches accum_arrive_reward)
+        wsync();
+        const int n_near0 = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
+        wsync();
+        const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
+        bool cont = !detect_collision(box, tile, nlist, n_near0, lane) && !(x > xmax || x < xmin || y > ymax || y < ymin);
+        if (cont) {
+            const double ua0 = overlap_area(box, dbox, scr + LDS_SH, lane);
+            if (!(ua0 / dest_area > 0.95)) {                            // not ARRIVED (and t = 1 is not OUTTIME): CONTINUE
+                const double bur = ua0 / (2 * dest_area - ua0);
+                if (!(bur < accum)) accum = bur;                        // :221-226 with accum = 0
+            }
+        }
+    }
+
     // ---- write state + scalar outputs ---------------------------------------------------------------
     if (lane == 0) {
         st[0] = x; st[1] = y; st[2] = h; st[3] = accum;
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             int8_t* w = p.out.rs_word + 8 * (size_t)scene;
             w[0] = w[1] = w[2] = w[3] = w[4] = HOPE_RS_NONE; w[5] = 0; w[6] = 0; w[7] = 0;
         }
-        if ((p.stages & HOPE_STAGE_RS) && t > 1 && status == HOPE_STATUS_CONTINUE) {       // gate :293-294
+        if ((p.stages & HOPE_STAGE_RS) && t > 1 && rs_status == HOPE_STATUS_CONTINUE) {    // gate :293-294
             double ddx = x - destx, ddy = y - desty;
             if (sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST) {
                 int slot = atomicAdd(p.rs_count, 1);

@@ -77,6 +77,13 @@ extern "C" {
  * (car_parking_base.py:235); without it they are the wrapper's [-1,1] actions and action_rescale
  * (env_wrapper.py:37-50) is applied first.  KSModel's own clip (vehicle.py:85-86) always applies. */
 #define HOPE_ACTION_PHYSICAL 0x10
+/* modifier bit: fused episode turnover (gym VectorEnv "autoreset").  A scene whose step ends with status !=
+ * CONTINUE is reset in the same kernel exactly as CarParking.reset (:127-138) does on the same map: pose = start,
+ * accum_arrive_reward = 0, t = 0 and the action-less step (t = 1, incl. its _get_reward bookkeeping).  reward /
+ * reward_info / status / done / RS outputs are those of the FINISHED step; lidar / action_mask / target / pose are
+ * the new episode's first observation.  Equivalent to hope_env_step + hope_env_restart(done) +
+ * hope_env_reset_obs(active = done) without the extra launches. */
+#define HOPE_AUTO_RESET 0x20
 
 typedef struct hope_env hope_env_t;
 

@@ -319,3 +319,47 @@ def test_parity_stress_8k_scenes():
     s['seen'] = sorted(seen)
     assert set(s['seen']) >= {1, 2, 3}
     env.close()
+
+
+def test_auto_reset_equals_step_restart_reset_obs():
+    """HOPE_AUTO_RESET: one launch sequence == step + restart(done) + reset_obs(active=done), bit for bit, and the
+    oracle's step + reset reproduces the new episode's first observation."""
+    envA, orc, rng = make_pair(1024, seed=41, level='mixed')
+    envB, _, _ = make_pair(1024, seed=41, level='mixed')
+    envA.reset_obs(); envB.reset_obs(); orc.reset_obs()
+    n_done = 0
+    for it in range(40):
+        act = rng.uniform(-1.3, 1.3, (envA.n, 2))
+        act[:, 1] = np.where(np.arange(envA.n) % 2 == 0, np.sign(act[:, 1] + 1e-9), act[:, 1])   # many leave the map box
+        a = torch.from_numpy(act).to(envA.device)
+        envA.step(a, auto_reset=True)
+        envB.step(a)
+        torch.cuda.synchronize()
+        fin = {k: getattr(envB, k).clone() for k in ('reward', 'reward_info', 'status', 'done', 'rs_word', 'rs_lengths')}
+        envB.restart(envB.done)
+        envB.reset_obs(active=fin['done'])
+        torch.cuda.synchronize()
+        for k, v in fin.items():                       # outputs of the finished step
+            assert torch.equal(getattr(envA, k), v), k
+        for k in ('lidar', 'action_mask', 'target', 'pose'):   # first observation of the new episode
+            assert torch.equal(getattr(envA, k), getattr(envB, k)), k
+        pa, ta, aa = envA.download_state()
+        pb, tb, ab = envB.download_state()
+        assert np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(aa, ab)
+        o = orc.step(act)
+        assert np.array_equal(envA.status.cpu().numpy(), o['status'])
+        done = o['status'] != 1
+        n_done += int(done.sum())
+        if done.any():
+            ids = np.nonzero(done)[0]
+            orc.pose[ids] = orc.start[ids]; orc.t[ids] = 0; orc.accum[ids] = 0
+            # oracle has no active mask: run the action-less step on a copy of the finished scenes only
+            sub = orc.__class__(len(ids), orc.max_obst)
+            sub.set_scenes(np.arange(len(ids)), orc.start[ids], orc.dest[ids], orc.bbox[ids], orc.verts[ids], orc.nvert[ids], orc.n_obst[ids])
+            so = sub.reset_obs()
+            orc.pose[ids] = sub.pose; orc.t[ids] = sub.t; orc.accum[ids] = sub.accum
+            assert np.array_equal(envA.lidar.cpu().numpy()[ids], so['lidar']) and np.array_equal(envA.action_mask.cpu().numpy()[ids], so['mask'])
+        assert np.array_equal(pa, orc.pose) and np.array_equal(ta, orc.t.astype(np.int32)) and np.array_equal(aa, orc.accum)
+    print('auto-reset: episodes finished', n_done)
+    assert n_done > 50
+    envA.close(); envB.close()
