@@ -482,6 +482,57 @@ def gold_wrapper_reward(rng):
          accum_in=acc_in, accum_out=acc_out, target=tgt, reward_list=rew)
 
 
+def gold_agent_glue(rng):
+    """agent-side glue right after the env step: RsPlanner expansion, ActionMask.choose_action
+    probabilities, StateNorm recurrence."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('parking_agent', os.path.join(REF, 'src', 'model', 'agent', 'parking_agent.py'))
+    pa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pa)
+    from model.state_norm import StateNorm
+    g = np.load(os.path.join(HERE, 'reeds_shepp.npz'))
+    names = {0: 'S', 1: 'L', 2: 'R'}
+    words, lens, acts, off = [], [], [], [0]
+    special = [([1, 0, 2], [1.25, 2.5, -1.25]), ([0], [0.001]), ([1, 2], [3.75, -0.0005]), ([2, 0, 1, 2, 1], [-5.1, 0.3, 2.5000001, -1.2499999, 9.99])]
+    cases = [(list(g['ctypes'][k][g['ctypes'][k] >= 0]), list(g['lengths'][k][g['ctypes'][k] >= 0])) for k in range(0, 1200, 3)] + special
+    for ct, ln in cases:
+        path = types.SimpleNamespace(ctypes=[names[int(c)] for c in ct], lengths=[float(v) for v in ln])
+        pl = pa.RsPlanner(0.05 * 10 * 2.5)
+        pl.set_rs_path(path)
+        w = np.full(5, -1, np.int8); w[:len(ct)] = ct
+        l = np.zeros(5); l[:len(ln)] = ln
+        words.append(w); lens.append(l)
+        acts.extend([[float(a[0]), float(a[1])] for a in pl.actions])
+        off.append(len(acts))
+    # choose_action probabilities (np.random.choice intercepted)
+    am = ActionMask()
+    n = 200
+    mean = rng.uniform(-1.2, 1.2, (n, 2)); std = rng.uniform(0.05, 1.5, (n, 2))
+    mask = rng.integers(0, 11, (n, 42)) / 10.0
+    mask[::7] = 0.01
+    probs = np.zeros((n, 42))
+    orig = np.random.choice
+    for i in range(n):
+        cap = {}
+        np.random.choice = lambda a, p=None, _c=cap: (_c.__setitem__('p', np.array(p)), 0)[1]
+        am.choose_action(mean[i].copy(), std[i].copy(), mask[i].copy())
+        probs[i] = cap['p']
+    np.random.choice = orig
+    # StateNorm recurrence
+    sn = StateNorm({'lidar': (120,), 'target': (5,), 'action_mask': (42,)},
+                   {'img': False, 'lidar': True, 'target': True, 'action_mask': False})
+    seq_l = rng.uniform(0, 10, (300, 120)); seq_t = rng.normal(0, 3, (300, 5))
+    outs = []
+    for i in range(300):
+        o = sn.state_norm({'lidar': seq_l[i].copy(), 'target': seq_t[i].copy(), 'action_mask': np.zeros(42)}, update=True)
+        outs.append(o['target'].copy())
+    save('agent_glue.npz', words=np.array(words), lengths=np.array(lens), actions=np.array(acts), action_off=np.array(off, np.int32),
+         pa_mean=mean, pa_std=std, pa_mask=mask, pa_probs=probs, sn_lidar=seq_l, sn_target=seq_t,
+         sn_mean_lidar=np.asarray(sn.state_mean['lidar'], np.float64), sn_std_lidar=np.asarray(sn.state_std['lidar'], np.float64),
+         sn_mean_target=np.asarray(sn.state_mean['target'], np.float64), sn_std_target=np.asarray(sn.state_std['target'], np.float64),
+         sn_norm_target=np.array(outs), sn_n=np.array(sn.n_state))
+
+
 def main():
     rng = np.random.default_rng(20240807)
     print('decoding dlp.data')
@@ -495,6 +546,7 @@ def main():
     gold_rs(rng)
     gold_traj_and_rs_search(d, rng)
     gold_wrapper_reward(rng)
+    gold_agent_glue(np.random.default_rng(7))
 
 
 if __name__ == '__main__':

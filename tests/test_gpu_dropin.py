@@ -162,3 +162,24 @@ def test_empty_and_full_tiles():
         a = rng.uniform(-1, 1, (1, 2))
         env.step(torch.from_numpy(a).to(env.device)); _same(env, orc.step(a))
     env.close()
+
+
+def test_batched_rollout_loop_runs_and_parks():
+    """env (auto-reset) + StateNorm + stand-in policy + mask-weighted sampling + RS-path replay, 2048 scenes.  The RS
+    replay alone parks cars (the reference's hybrid controller), so successes must appear."""
+    from hope_amd import ParkingBatch
+    from hope_amd.rollout import BatchedRollout
+    from hope_amd.scenes import SceneSource
+    src = SceneSource(levels=('Normal', 'Complex'), seed=5)
+    uniq = [src.draw() for _ in range(256)]
+    n = 2048
+    env = ParkingBatch(n, 32)
+    env.set_scenes(np.arange(n), [uniq[i % 256] for i in range(n)])
+    ro = BatchedRollout(env, seed=1)
+    for _ in range(120):
+        a = ro.step()
+        assert a.shape == (n, 2) and float(a.abs().max()) <= 1.0 + 1e-6
+    st = ro.stats()
+    print('rollout:', st)
+    assert st['episodes'] > 100 and st['success_rate'] > 0.02
+    env.close()
