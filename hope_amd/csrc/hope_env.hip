@@ -370,7 +370,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     EventTimer timer(h);
     LaunchTimer* tm = prof ? &timer : nullptr;
     if ((stages & HOPE_STAGE_MOTION) && has_action) {
-        dim3 kg((h->n + WAVE - 1) / WAVE);
+        dim3 kg((h->n + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
         if (tm) tm->begin(HOPE_K_KINEMATICS, s);
         if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
         else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);

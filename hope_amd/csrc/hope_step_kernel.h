@@ -227,19 +227,24 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_kinematics: ONE THREAD PER SCENE.  action_rescale (env_wrapper.py:37-50), KSModel clip (vehicle.py:85-86) and
-// the 10 x 20 explicit-Euler micro-steps (vehicle.py:88-93) are a strictly sequential float64 recurrence per
-// scene (h += dh and x += v cos h dt/20 accumulate rounding step by step) with no cross-lane work, so it is run
-// thread-per-scene with coalesced loads over the scene batch; the wave-per-scene step kernel then only consumes
-// the ten sub-step poses.  Writes kin[scene][50] = h[10], cos h[10], sin h[10], x[10], y[10].
+// k_kinematics: FOUR LANES PER SCENE (16 scenes per wave).  action_rescale (env_wrapper.py:37-50), KSModel clip
+// (vehicle.py:85-86) and the 10 x 20 explicit-Euler micro-steps (vehicle.py:88-93) form a strictly sequential
+// float64 recurrence per scene: h += dh and x += v cos(h) dt/20 accumulate rounding step by step.  The recurrence
+// is kept exactly, but its expensive part is spread over a quad: lane q walks the SAME heading chain and stops at
+// micro-steps m = 4r + q (4 sequential additions per round, so every lane sees the reference's partial sums), all
+// four evaluate sincos + the displacement terms of "their" micro-step at once, and the x / y sums then consume
+// the four terms in micro-step order through quad broadcasts.  The ten sub-step poses do not depend on collisions
+// (only where the step stops does), so k_env_step just reads them: kin[scene][50] = h[10] cos[10] sin[10] x[10]
+// y[10], written through LDS with coalesced stores.
 // ------------------------------------------------------------------------------------------------------------
+constexpr int KIN_SCENES_PER_BLOCK = WAVE / 4;
+
 template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, const void* actions, const uint8_t* active,
                                                   uint32_t stages, double* kin) {
-    // the 64 scenes of a block own 64 x 50 contiguous doubles of `kin`: results go through LDS so that the block
-    // writes them with fully coalesced stores (a per-thread 400 B stride cost 7x the write requests: PMC WRITE_SIZE)
-    __shared__ double buf[WAVE * KIN_WORDS];
-    const int scene = blockIdx.x * WAVE + threadIdx.x;
+    __shared__ double buf[KIN_SCENES_PER_BLOCK * KIN_WORDS];
+    const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
+    const int scene = blockIdx.x * KIN_SCENES_PER_BLOCK + ls;
     const bool live = scene < n && !(active && !active[scene]);
     if (__all(!live)) return;
     const int sc_ = live ? scene : 0;
@@ -255,22 +260,33 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
     speed = clipd(speed, SPEED_LO, SPEED_HI);
     steer = clipd(steer, STEER_LO, STEER_HI);
     const double dh = speed * hm_tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
-    double* out = buf + threadIdx.x * KIN_WORDS;
-    for (int k = 0; k < NUM_STEP; k++) {
-        for (int j = 0; j < MINI_ITER; j++) {
-            double s_, c_;
-            hm_sincos(h, &s_, &c_);
-            x += speed * c_ * STEP_LENGTH / MINI_ITER;
-            y += speed * s_ * STEP_LENGTH / MINI_ITER;
-            h += dh;
+    double* out = buf + ls * KIN_WORDS;
+    const int qbase = lane & ~3;
+    for (int i = 0; i < q; i++) h = h + dh;                  // lane q starts at micro-step q
+    for (int r = 0; r < NUM_STEP * MINI_ITER / 4; r++) {     // round r: micro-steps 4r .. 4r+3, one per lane
+        double s_, c_;
+        hm_sincos(h, &s_, &c_);
+        if (q == 0 && r > 0 && r % (MINI_ITER / 4) == 0) {   // lane 0 sits on a sub-step boundary: h_{20k}
+            const int k = r / (MINI_ITER / 4) - 1;
+            out[k] = h; out[10 + k] = c_; out[20 + k] = s_; out[30 + k] = x; out[40 + k] = y;
         }
-        double sb, cb;
-        hm_sincos(h, &sb, &cb);
-        out[k] = h; out[10 + k] = cb; out[20 + k] = sb; out[30 + k] = x; out[40 + k] = y;
+        const double tx = speed * c_ * STEP_LENGTH / MINI_ITER;
+        const double ty = speed * s_ * STEP_LENGTH / MINI_ITER;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                        // x += ..., y += ... in micro-step order (vehicle.py:90-91)
+            x += __shfl(tx, qbase + j);
+            y += __shfl(ty, qbase + j);
+        }
+        h = h + dh; h = h + dh; h = h + dh; h = h + dh;      // four steps of the sequential chain
+    }
+    if (q == 0) {                                            // after micro-step 199: the 10th sub-step pose
+        double s_, c_;
+        hm_sincos(h, &s_, &c_);
+        out[9] = h; out[19] = c_; out[29] = s_; out[39] = x; out[49] = y;
     }
     __syncthreads();
-    const int first = blockIdx.x * WAVE;
-    const int n_here = min(WAVE, n - first);
+    const int first = blockIdx.x * KIN_SCENES_PER_BLOCK;
+    const int n_here = min(KIN_SCENES_PER_BLOCK, n - first);
     double* dst = kin + (size_t)first * KIN_WORDS;
     for (int w = threadIdx.x; w < n_here * KIN_WORDS; w += WAVE) {
         const int s = w / KIN_WORDS;
@@ -622,10 +638,15 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     // and at the coarse beams themselves (w1 = 1, w2 = 0: exact) cnt(10i,a) = #{k : tab[10i][k][a] <= x_i}.
     // With  m    = min_i #{k : tab[10i][k][a] <= x_i}          (exact counts at the 120 coarse beams: upper bound)
     //       mlow = min_i #{k : tab[10i][k][a] <= x_i - 1e-9}    (=> every fine beam has cnt >= mlow: lower bound)
-    // the answer lies in [mlow, m].  They differ only if some table entry is within 1e-9 of x_i (e.g. the
+    // the answer lies in [mlow, m].  They can differ only if some table entry is within 1e-9 of x_i (e.g. the
     // structural tie of the straight arcs when an obstacle touches the hull side); then, and only then, the
     // full 1200-beam evaluation below runs.  120 row probes instead of up to 1200 x 10 rows.
-    int mstep = NITER, mlow = NITER;
+    // `tie` replaces a second set of probes for mlow: the table is monotone in k, so if the largest entry that is
+    // <= x_i (the one at the lane's count boundary, which the probe / walk has already loaded) is also <= x_i - 1e-9,
+    // every lower entry is too and this row cannot push the lower bound below the exact count.  Any boundary value
+    // inside (x_i - 1e-9, x_i] raises `tie` -> exact evaluation.
+    int mstep = NITER;
+    bool tie = false;
     {
         // lane-parallel activity test (one lane per coarse beam), then only the active rows are visited,
         // four at a time so that their probes are in flight together
@@ -644,32 +665,36 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 }
                 if (lane < NACT) {
                     const double* row[4];
-                    double xv[4], v[4], vl[4];
+                    double xv[4], v[4];
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         xv[g] = xs[ib[g]];
                         row[g] = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + lane;
                         v[g] = mstep > 0 ? row[g][(mstep - 1) * NACT] : 0.0;
-                        vl[g] = mlow > 0 ? row[g][(mlow - 1) * NACT] : 0.0;
                     }
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
-                        if (mstep > 0 && v[g] > xv[g]) {
-                            int c = mstep;
-                            while (c > 0 && row[g][(c - 1) * NACT] > xv[g]) c--;
-                            mstep = c;
-                        }
-                        if (mlow > 0 && vl[g] > xv[g] - 1e-9) {
-                            int c = mlow;
-                            while (c > 0 && row[g][(c - 1) * NACT] > xv[g] - 1e-9) c--;
-                            mlow = c;
+                        if (mstep > 0) {
+                            double bv = v[g];                     // boundary value: largest examined entry <= x
+                            if (bv > xv[g]) {
+                                int c = mstep;
+                                bv = -INFINITY;
+                                while (c > 0) {
+                                    bv = row[g][(c - 1) * NACT];
+                                    if (!(bv > xv[g])) break;
+                                    c--;
+                                }
+                                if (c == 0) bv = -INFINITY;
+                                mstep = c;
+                            }
+                            if (bv > xv[g] - 1e-9) tie = true;
                         }
                     }
                 }
             }
         }
     }
-    if (__any(mlow != mstep)) {
+    if (__any(tie)) {
         // ---- exact fall-back over all 1200 beams (rare) ---------------------------------------------------
         for (int r = 0; r < (NL + WAVE - 1) / WAVE; r++) {
             int l = r * WAVE + lane;

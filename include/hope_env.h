@@ -146,7 +146,7 @@ int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
 /* With HOPE_F_PROFILE every kernel launch is bracketed by its own HIP event pair on the launch stream.
  * Returns the accumulated time (ms) and launch count per kernel since the last call with reset != 0:
  * arrays of HOPE_N_KERNELS entries indexed by HOPE_K_*.  Host-synchronous. */
-#define HOPE_K_KINEMATICS 0    /* k_kinematics   (thread per scene)                         */
+#define HOPE_K_KINEMATICS 0    /* k_kinematics   (four lanes per scene)                      */
 #define HOPE_K_STEP 1          /* k_env_step     (wave per scene; one launch per tile class) */
 #define HOPE_K_RS_WORDS 2      /* k_rs_words     (wave per queued scene)                     */
 #define HOPE_K_RS_VALIDATE 3   /* k_rs_validate  (wave per queued scene; per tile class)     */
