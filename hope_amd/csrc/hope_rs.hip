@@ -628,8 +628,8 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
         // Resumable sample generator + ONE window test site.  Samples are appended to the queue until it cannot
         // take another chunk (or the path ends); then the window is tested coarse-to-fine: a path is invalid as
         // soon as ANY of its samples is bad, whatever the order they are looked at, and a path that crosses an
-        // obstacle has long runs of bad samples -- so every 8th queued sample goes first (one pass for up to 512
-        // samples) and only clean windows pay for the other seven eighths.  Exact: all of them are real samples
+        // obstacle has long runs of bad samples -- so a strided subset that fills one wave goes first and only clean
+        // windows pay for the remaining samples.  Exact: all of them are real samples
         // of generate_local_course.
         // window size: generate <= 130 samples, test them, continue (measured best of 66/130/258/512: larger windows
         // lose the early exit on invalid paths, smaller ones pay more partially filled passes)
@@ -680,11 +680,15 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
             }
             wsync();
             const int n = nq;
-            const int n_rest = n - (n + 7) / 8;
+            // coarse pass: every `stride`-th sample with stride = ceil(n / 64), i.e. as dense as one full-wave pass
+            // allows (a fixed stride of 8 left 3/4 of the lanes idle on a 130-sample window)
+            const int stride = (n + WAVE - 1) / WAVE;
+            const int n_coarse = (n + stride - 1) / stride;
+            const int n_rest = n - n_coarse;
             for (int rnd = 0; rnd == 0 || (rnd - 1) * WAVE < n_rest; rnd++) {
                 int idx;
-                if (rnd == 0) idx = (8 * lane < n) ? 8 * lane : -1;
-                else { const int r = (rnd - 1) * WAVE + lane; idx = r < n_rest ? r + r / 7 + 1 : -1; }
+                if (rnd == 0) idx = (lane < n_coarse) ? stride * lane : -1;
+                else { const int r = (rnd - 1) * WAVE + lane; idx = r < n_rest ? r + r / (stride - 1) + 1 : -1; }
                 const bool active = idx >= 0;
                 double px = 0, py = 0, pyaw = 0;
                 if (active) {

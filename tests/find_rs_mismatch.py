@@ -2,7 +2,7 @@
 """Runs the stress configuration and dumps every scene-step where the GPU and the oracle disagree on the RS result."""
 import copy, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root (this dev tool lives under tests/: it uses the oracle)
 import torch
 from hope_amd import ParkingBatch
 from hope_amd.scenes import SceneSource, pack_scenes
