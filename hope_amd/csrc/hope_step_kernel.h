@@ -347,31 +347,81 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         wsync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------
-        for (int k = 0; k < NUM_STEP; k++) {
-            const double px = x, py = y, ph = h;          // prev_info
-            const bool prev_free = known_free;
-            x = scr[LDS_PX + k];
-            y = scr[LDS_PY + k];
-            h = scr[LDS_HB + k];
-            ct = scr[LDS_CB + k];
-            sn = scr[LDS_SB + k];
-            have_cs = true;
-            have_ua = false;
-            Box box = make_box(x, y, ct, sn);
-            if (arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {           // _check_arrived :164-170
-                ua = overlap_area(box, dbox, scr + LDS_SH, lane);
-                have_ua = true;
-                if (ua / dest_area > 0.95) { arrive = true; break; }
+        // The ten poses are known, so several sub-steps can be examined per pass when the near list is short:
+        // S = edge slots per sub-step (power of two >= 4 n_near), G = 64 / S sub-steps per pass, lane = (g, e).
+        // Two ballots (arrival possible / collision) are then walked in sub-step order, which reproduces
+        // "arrived? -> stop; collided? -> retreat and stop" exactly.
+        const int S = n_near <= 1 ? 4 : (n_near <= 2 ? 8 : (n_near <= 4 ? 16 : (n_near <= 8 ? 32 : 64)));
+        int ev_k = NUM_STEP;              // first sub-step with an event (NUM_STEP: none)
+        bool ev_arrive = false;
+        if (S < WAVE) {
+            const int G = WAVE / S;
+            const int g = lane / S, e = lane % S;
+            const bool has_edge = e < 4 * n_near;
+            double ex1 = 0, ey1 = 0, ex2 = 0, ey2 = 0;
+            if (has_edge) {
+                const double* v = tile + 8 * nlist[e >> 2];
+                const int j = e & 3, j2 = (e + 1) & 3;
+                ex1 = v[2 * j]; ey1 = v[2 * j + 1]; ex2 = v[2 * j2]; ey2 = v[2 * j2 + 1];
             }
-            if (detect_collision(box, tile, nlist, n_near, lane)) {              // retreat :264-271
-                x = px; y = py; h = ph;
-                known_free = prev_free;
-                have_ua = false;
-                have_cs = false;
-                break;
+            const unsigned long long gmask0 = (1ull << S) - 1;
+            for (int k0 = 0; k0 < NUM_STEP && ev_k == NUM_STEP; k0 += G) {
+                const int k = k0 + g;
+                const bool kv = k < NUM_STEP;
+                const int kk = kv ? k : NUM_STEP - 1;
+                const double qx = scr[LDS_PX + kk], qy = scr[LDS_PY + kk], qc = scr[LDS_CB + kk], qs = scr[LDS_SB + kk];
+                const bool ap = kv && e == 0 && arrival_possible(qx, qy, qc, qs, dcx, dcy, dcd, dsd);
+                bool hit = false;
+                if (kv && has_edge) {
+                    const Box b = make_box(qx, qy, qc, qs);
+                    const double hminx = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3]));
+                    const double hmaxx = fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3]));
+                    const double hminy = fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3]));
+                    const double hmaxy = fmax(fmax(b.y[0], b.y[1]), fmax(b.y[2], b.y[3]));
+                    if (!(fmin(ex1, ex2) > hmaxx || fmax(ex1, ex2) < hminx || fmin(ey1, ey2) > hmaxy || fmax(ey1, ey2) < hminy)) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const int c2 = (c + 1) & 3;
+                            hit = hit || segments_intersect(b.x[c], b.y[c], b.x[c2], b.y[c2], ex1, ey1, ex2, ey2);
+                        }
+                    }
+                }
+                const unsigned long long hm = __ballot(hit), am = __ballot(ap);
+                if (hm | am) {
+                    for (int gg = 0; gg < G && k0 + gg < NUM_STEP; gg++) {
+                        const unsigned long long gm = gmask0 << (gg * S);
+                        const int kq = k0 + gg;
+                        if (am & gm) {                                                   // _check_arrived :164-170
+                            const Box bq = make_box(scr[LDS_PX + kq], scr[LDS_PY + kq], scr[LDS_CB + kq], scr[LDS_SB + kq]);
+                            ua = overlap_area(bq, dbox, scr + LDS_SH, lane);
+                            if (ua / dest_area > 0.95) { ev_k = kq; ev_arrive = true; break; }
+                        }
+                        if (hm & gm) { ev_k = kq; break; }                               // _detect_collision :264
+                    }
+                }
             }
-            known_free = true;
+        } else {
+            for (int k = 0; k < NUM_STEP; k++) {
+                const double qx = scr[LDS_PX + k], qy = scr[LDS_PY + k], qc = scr[LDS_CB + k], qs = scr[LDS_SB + k];
+                const Box b = make_box(qx, qy, qc, qs);
+                if (arrival_possible(qx, qy, qc, qs, dcx, dcy, dcd, dsd)) {               // _check_arrived :164-170
+                    ua = overlap_area(b, dbox, scr + LDS_SH, lane);
+                    if (ua / dest_area > 0.95) { ev_k = k; ev_arrive = true; break; }
+                }
+                if (detect_collision(b, tile, nlist, n_near, lane)) { ev_k = k; break; }  // _detect_collision :264
+            }
         }
+        // final pose of the motion: the arrival pose, the pose BEFORE the colliding sub-step (retreat :264-271), or
+        // the tenth pose
+        arrive = ev_arrive;
+        const int kf = ev_arrive ? ev_k : (ev_k == NUM_STEP ? NUM_STEP - 1 : ev_k - 1);
+        if (kf >= 0) {
+            x = scr[LDS_PX + kf]; y = scr[LDS_PY + kf]; h = scr[LDS_HB + kf];
+            ct = scr[LDS_CB + kf]; sn = scr[LDS_SB + kf];
+            have_cs = true;
+            known_free = !ev_arrive;            // passed its own collision test (or is the arrival pose: not needed)
+        }
+        have_ua = ev_arrive;
     }
     t += 1;                                                             // :277
 
