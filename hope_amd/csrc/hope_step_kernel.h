@@ -69,14 +69,13 @@ __device__ __forceinline__ double ring_area_signed_lds(const double* px, const d
 }
 
 // Polygon(A).intersection(Polygon(B)).area for convex CCW quads: Sutherland-Hodgman + shoelace.
-// Runs on ONE lane with LDS scratch sh[64] (two 8-vertex ping-pong buffers of x and y).
-__device__ __noinline__ double quad_intersection_area_lane0(const Box& A, const double* B /*8 words x,y*/,
-                                                            double* sh) {
+// Runs on ONE lane with LDS scratch sh[64] (two 8-vertex ping-pong buffers of x and y); quad A is already in
+// sh[0..3] (x) and sh[16..19] (y).  Out of line (it is long and rare), so every argument is an LDS pointer: a Box
+// passed by reference would have to live in scratch memory, and those stores were most of the kernel's HBM writes.
+__device__ __noinline__ double quad_intersection_area_lane0(const double* B /*8 words x,y*/, double* sh) {
     double* ax = sh;      double* ay = sh + 16;
     double* bx = sh + 32; double* by = sh + 48;
     int n = 4;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { ax[i] = A.x[i]; ay[i] = A.y[i]; }
     for (int e = 0; e < 4 && n > 0; e++) {
         double c1x = B[2 * e], c1y = B[2 * e + 1];
         double c2x = B[2 * ((e + 1) & 3)], c2y = B[2 * ((e + 1) & 3) + 1];
@@ -113,7 +112,11 @@ __device__ __forceinline__ double overlap_area(const Box& box, const double* dbo
     const double reach = 5.2;   // 2 * half-diagonal (2.5378) + slack
     if (dx * dx + dy * dy > reach * reach) return 0.0;
     double area = 0.0;
-    if (lane == 0) area = quad_intersection_area_lane0(box, dbox_lds, sh);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { sh[i] = box.x[i]; sh[16 + i] = box.y[i]; }
+        area = quad_intersection_area_lane0(dbox_lds, sh);
+    }
     return __shfl(area, 0);
 }
 
