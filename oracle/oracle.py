@@ -16,9 +16,9 @@ CT_NAMES = {0: 'S', 1: 'L', 2: 'R'}
 
 def build(force=False):
     so = os.path.join(_HERE, '_build', 'libhope_oracle_libm.so')
-    src = os.path.join(_HERE, 'hope_oracle.c')
-    hdr = os.path.join(os.path.dirname(_HERE), 'hope_amd', 'csrc', 'hope_math.h')
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    srcs = [os.path.join(_HERE, 'hope_oracle.c'), os.path.join(_HERE, 'hope_oracle_img.c'),
+            os.path.join(os.path.dirname(_HERE), 'hope_amd', 'csrc', 'hope_math.h')]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(['make', '-C', _HERE, '-s'])
     return so
 
@@ -223,6 +223,43 @@ def action_rescale(act):
     return out
 
 
+# ---- bird's-eye image observation (hope_oracle_img.c; PARITY UNPINNED, see its header) -------------------------
+def bev_world(verts, nvert, start, dest, bbox, pose, traj):
+    """the 500x500 world raster of CarParking._render as palette ids; traj = vehicle.trajectory (poses, oldest first)"""
+    verts, nvert = _f64(verts), _i32(nvert)
+    traj = _f64(traj).reshape(-1, 3)
+    last = np.ascontiguousarray(traj[-20:])
+    world = np.zeros((500, 500), np.uint8)
+    lib().orc_bev_world(_p(verts), _p(nvert), C.c_int(len(nvert)), _p(_f64(start)), _p(_f64(dest)), _p(_f64(bbox)),
+                        _p(_f64(pose)), _p(last), C.c_int(len(last)), C.c_int(len(traj)), _p(world))
+    return world
+
+
+def bev_raw(world, bbox, pose):
+    """_get_img_observation: [256,256,3] uint8"""
+    raw = np.zeros((256, 256, 3), np.uint8)
+    lib().orc_bev_raw(_p(np.ascontiguousarray(world, np.uint8)), _p(_f64(bbox)), _p(_f64(pose)), _p(raw))
+    return raw
+
+
+def bev_process(raw):
+    """Obs_Processor.process_img * 255: [64,64,3] uint8"""
+    out = np.zeros((64, 64, 3), np.uint8)
+    lib().orc_bev_process(_p(np.ascontiguousarray(raw, np.uint8)), _p(out))
+    return out
+
+
+def bev_image(verts, nvert, start, dest, bbox, pose, traj, omp=False):
+    """obs['img'] * 255 after the wrapper's transpose: [3,64,64] uint8"""
+    verts, nvert = _f64(verts), _i32(nvert)
+    traj = _f64(traj).reshape(-1, 3)
+    last = np.ascontiguousarray(traj[-20:])
+    out = np.zeros((3, 64, 64), np.uint8)
+    lib(omp).orc_bev_image(_p(verts), _p(nvert), C.c_int(len(nvert)), _p(_f64(start)), _p(_f64(dest)), _p(_f64(bbox)),
+                           _p(_f64(pose)), _p(last), C.c_int(len(last)), C.c_int(len(traj)), _p(out))
+    return out
+
+
 class BatchOracle:
     """N independent scenes stepped by the C oracle (fixed stride of max_obst obstacles/scene).
     Mirrors the product's batch interface so parity tests can run both on identical inputs."""
@@ -243,6 +280,7 @@ class BatchOracle:
                         reward_info=np.zeros((n, 5)), reward=np.zeros(n), status=np.zeros(n, np.int32),
                         rs_found=np.zeros(n, np.int32), rs_ctypes=np.zeros((n, 5), np.int32),
                         rs_lengths=np.zeros((n, 5)), substeps=np.zeros(n, np.int32))
+        self.traj = [[] for _ in range(n)]        # vehicle.trajectory (vehicle.py:114,132-133,144,158), last 20 kept
 
     def set_scenes(self, ids, start, dest, bbox, verts, nvert, n_obst):
         ids = np.asarray(ids)
@@ -254,9 +292,16 @@ class BatchOracle:
             m = int(n_obst[k])
             self.verts[i, :m] = verts[k][:m]
             self.nvert[i, :m] = nvert[k][:m]
-        self.pose[ids] = start
+        self.restart(ids)
+
+    def restart(self, ids):
+        """CarParking.reset's state part (:128-136): accumulators zeroed, vehicle.reset(start), trajectory = [start]"""
+        ids = np.asarray(ids)
+        self.pose[ids] = self.start[ids]
         self.t[ids] = 0.0
         self.accum[ids] = 0.0
+        for i in ids:
+            self.traj[int(i)] = [self.start[int(i)].copy()]
 
     def _call(self, actions, with_rs):
         o = self.out
@@ -266,7 +311,24 @@ class BatchOracle:
                               _p(a), C.c_int(int(with_rs)), _p(o['lidar']), _p(o['mask']), _p(o['target']),
                               _p(o['reward_info']), _p(o['reward']), _p(o['status']), _p(o['rs_found']),
                               _p(o['rs_ctypes']), _p(o['rs_lengths']), _p(o['substeps']))
+        if actions is not None:
+            # car_parking_base.py:259-276: of the sub-step states only the last kept one stays in vehicle.trajectory
+            for i in np.nonzero(o['substeps'] > 0)[0]:
+                tr = self.traj[int(i)]
+                tr.append(self.pose[i].copy())
+                if len(tr) > 21:                   # keep len > 20 distinguishable from len == 20; only 20 are drawn
+                    del tr[0]
         return o
+
+    def image(self, ids=None):
+        """obs['img'] * 255 for the given scenes: [len(ids),3,64,64] uint8"""
+        ids = np.arange(self.n) if ids is None else np.asarray(ids)
+        out = np.zeros((len(ids), 3, 64, 64), np.uint8)
+        for k, i in enumerate(ids):
+            m = int(self.n_obst[i])
+            out[k] = bev_image(self.verts[i, :m], self.nvert[i, :m], self.start[i], self.dest[i], self.bbox[i],
+                               self.pose[i], np.array(self.traj[int(i)]))
+        return out
 
     def reset_obs(self, with_rs=True):
         """the action-less step every scene performs at reset (t: 0 -> 1)."""
