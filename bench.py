@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--mix', default='mixed', choices=['mixed', 'dlp', 'normal'])
     ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
     ap.add_argument('--unique', type=int, default=2048, help='distinct generated scenes (tiled to --scenes)')
+    ap.add_argument('--image', action='store_true', help="also render obs['img'] (USE_IMG, configs.py:100) every step")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scenes', type=int, default=192)
     ap.add_argument('--cpu-steps', type=int, default=12)
@@ -98,7 +99,7 @@ def main():
               'motion': L.STAGE_MOTION | L.STAGE_REWARD}[args.stages]
 
     env = ParkingBatch(N, args.max_obst, device=str(dev), obs_dtype=torch.float32, action_dtype=torch.float32,
-                       profile=True)
+                       profile=True, image=args.image)
     chunk = 8192
     for a in range(0, N, chunk):
         b = min(N, a + chunk)
@@ -109,6 +110,8 @@ def main():
     edges = 4.0 * n_obst_all
     # algorithmic bytes per scene-step = 808 + 16*E (reads 64 + 16E, writes 744)
     bytes_per_launch = float(np.sum(808.0 + 16.0 * edges))
+    if args.image:
+        bytes_per_launch += 3.0 * 64 * 64 * N        # + the uint8 image written per scene-step
 
     g = torch.Generator(device=dev)
     g.manual_seed(args.seed + rank)
@@ -169,7 +172,7 @@ def main():
             'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}, random actions U[-1,1]^2, '
+            'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},

@@ -6,12 +6,14 @@ from .build import lib_path
 
 # mirror of include/hope_env.h
 LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10, 5, 5
-F_OBS_F64, F_ACTION_F64, F_PROFILE = 0x1, 0x2, 0x4
+F_OBS_F64, F_ACTION_F64, F_PROFILE, F_IMAGE = 0x1, 0x2, 0x4, 0x8
 STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 ACTION_PHYSICAL = 0x10
+STAGE_IMG = 0x40
+IMG_SIZE, IMG_CHANNELS, TRAJ_RENDER_LEN = 64, 3, 20
 AUTO_RESET = 0x20
-KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate')
-ABI_VERSION = 1
+KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image')
+ABI_VERSION = 2
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',
            'hope_env_set_scenes', 'hope_env_step', 'hope_env_reset_obs', 'hope_env_download_state',
@@ -25,7 +27,7 @@ class HopeError(RuntimeError):
 class StepOut(C.Structure):
     _fields_ = [('lidar', C.c_void_p), ('action_mask', C.c_void_p), ('target', C.c_void_p), ('reward', C.c_void_p),
                 ('reward_info', C.c_void_p), ('status', C.c_void_p), ('done', C.c_void_p), ('pose', C.c_void_p),
-                ('rs_word', C.c_void_p), ('rs_lengths', C.c_void_p)]
+                ('rs_word', C.c_void_p), ('rs_lengths', C.c_void_p), ('img', C.c_void_p)]
 
 
 _lib = None

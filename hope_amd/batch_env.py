@@ -15,7 +15,7 @@ from .scenes import pack_scenes
 
 class ParkingBatch:
     def __init__(self, n_scenes, max_obstacles=128, device='cuda:0', obs_dtype=torch.float32,
-                 action_dtype=torch.float32, tables=None, profile=False):
+                 action_dtype=torch.float32, tables=None, profile=False, image=False):
         if not torch.cuda.is_available():
             raise L.HopeError('ParkingBatch needs a HIP device (torch.cuda.is_available() is False); no CPU fallback')
         self.lib = L.load_library()
@@ -23,7 +23,8 @@ class ParkingBatch:
         self.n, self.max_obst = int(n_scenes), int(max_obstacles)
         assert obs_dtype in (torch.float32, torch.float64) and action_dtype in (torch.float32, torch.float64)
         self.obs_dtype, self.action_dtype = obs_dtype, action_dtype
-        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0) | (L.F_PROFILE if profile else 0)
+        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0) | (L.F_PROFILE if profile else 0) | (L.F_IMAGE if image else 0)
+        self.image = bool(image)
         h = C.c_void_p()
         L.check(self.lib.hope_env_create(C.byref(h), self.n, self.max_obst, self.device.index or 0, flags),
                 'hope_env_create')
@@ -46,10 +47,12 @@ class ParkingBatch:
         self.pose = torch.zeros((n, 3), dtype=torch.float64, device=dev)
         self.rs_word = torch.full((n, 8), -1, dtype=torch.int8, device=dev)
         self.rs_lengths = torch.zeros((n, L.RS_MAX_SEG), dtype=od, device=dev)
+        # obs['img'] * 255 as uint8, channel-first (env_wrapper.py:53-54); the reference's float image is img / 255
+        self.img = torch.zeros((n, L.IMG_CHANNELS, L.IMG_SIZE, L.IMG_SIZE), dtype=torch.uint8, device=dev) if image else None
         self._out = L.StepOut(self.lidar.data_ptr(), self.action_mask.data_ptr(), self.target.data_ptr(),
                               self.reward.data_ptr(), self.reward_info.data_ptr(), self.status.data_ptr(),
                               self.done.data_ptr(), self.pose.data_ptr(), self.rs_word.data_ptr(),
-                              self.rs_lengths.data_ptr())
+                              self.rs_lengths.data_ptr(), self.img.data_ptr() if image else None)
 
     # -- scenes ------------------------------------------------------------------------------------
     def set_scenes(self, ids, scenes):
@@ -74,6 +77,8 @@ class ParkingBatch:
 
     def reset_obs(self, active=None, stages=L.STAGE_ALL):
         """the action-less step of CarParking.reset (car_parking_base.py:138)."""
+        if self.image and stages == L.STAGE_ALL:
+            stages |= L.STAGE_IMG
         ap = C.c_void_p(active.data_ptr()) if active is not None else None
         L.check(self.lib.hope_env_reset_obs(self.h, ap, stages, C.byref(self._out), self._stream()),
                 'hope_env_reset_obs')
@@ -82,6 +87,8 @@ class ParkingBatch:
     def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False):
         """actions: [N, 2] (steer, speed) in [-1, 1] on this device.  auto_reset=True: finished scenes restart inside
         the step (their lidar / action_mask / target are the new episode's first observation)."""
+        if self.image and stages == L.STAGE_ALL:
+            stages |= L.STAGE_IMG                    # USE_IMG (configs.py:100): the image is part of the observation
         if auto_reset:
             stages |= L.AUTO_RESET
         assert actions.shape == (self.n, 2) and actions.dtype == self.action_dtype and actions.is_contiguous()
@@ -105,7 +112,7 @@ class ParkingBatch:
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(L.KERNELS)}
 
     def obs(self):
-        return {'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
+        return {'img': self.img, 'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
 
     # -- state -------------------------------------------------------------------------------------
     def download_state(self):

@@ -46,6 +46,8 @@ struct hope_env {
     int32_t* rs_count = nullptr;
     int32_t* rs_list = nullptr;
     double* kin = nullptr;
+    double* traj = nullptr;        // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory
+    int32_t* traj_len = nullptr;   // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
     // per tile class (0: n_obst <= SMALL_TILE, 1: larger) dense scene lists; classes are static between set_scenes calls
     int32_t* cls_list[2] = {nullptr, nullptr};
     int cls_count[2] = {0, 0};
@@ -59,8 +61,8 @@ struct hope_env {
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0};
-    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0};
+    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0};
+    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0};
 };
 
 static hipEvent_t get_event(hope_env* h) {
@@ -109,7 +111,7 @@ namespace {
 // one thread per uploaded scene: constants, derived dest box, episode state reset
 __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* start, const double* dest,
                                    const double* bbox, const int32_t* nob, double* scene_c, double* state,
-                                   int32_t* tstep, int32_t* n_obst) {
+                                   int32_t* tstep, int32_t* n_obst, double* traj, int32_t* traj_len) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int s = ids[k];
@@ -134,6 +136,11 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
     st[0] = start[3 * k]; st[1] = start[3 * k + 1]; st[2] = start[3 * k + 2]; st[3] = 0.0;
     tstep[s] = 0;
     n_obst[s] = nob[k];
+    if (traj) {                                                   // vehicle.reset: trajectory = [start]  vehicle.py:132-133
+        double* tr = traj + (size_t)s * BEV_TRAJ_LEN * 3;
+        tr[0] = st[0]; tr[1] = st[1]; tr[2] = st[2];
+        traj_len[s] = 1;
+    }
 }
 
 __global__ void k_debug_math(int fn, int n, const double* a, const double* b, double* out) {
@@ -158,13 +165,19 @@ __global__ void k_debug_math(int fn, int n, const double* a, const double* b, do
 }
 
 // episode restart: pose = start, t = 0, accum = 0 for masked scenes
-__global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, double* state, int32_t* tstep) {
+__global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, double* state, int32_t* tstep, double* traj,
+                          int32_t* traj_len) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n || !mask[s]) return;
     const double* c = scene_c + (size_t)s * SC_WORDS;
     double* st = state + (size_t)s * ST_WORDS;
     st[0] = c[SC_START]; st[1] = c[SC_START + 1]; st[2] = c[SC_START + 2]; st[3] = 0.0;
     tstep[s] = 0;
+    if (traj) {
+        double* tr = traj + (size_t)s * BEV_TRAJ_LEN * 3;
+        tr[0] = st[0]; tr[1] = st[1]; tr[2] = st[2];
+        traj_len[s] = 1;
+    }
 }
 
 // one block per uploaded scene: copy its obstacle tile
@@ -234,7 +247,15 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->cls_list[1], N * sizeof(int32_t));
     ALLOC(h->rs_words, N * rs_words_bytes_per_scene());
     ALLOC(h->rs_nwords, N * sizeof(int32_t));
+    if (flags & HOPE_F_IMAGE) {
+        ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
+        ALLOC(h->traj_len, N * sizeof(int32_t));
+    }
 #undef ALLOC
+    if (h->traj) {
+        HIPCHK(hipMemset(h->traj, 0, N * BEV_TRAJ_LEN * 3 * sizeof(double)));
+        HIPCHK(hipMemset(h->traj_len, 0, N * sizeof(int32_t)));
+    }
     HIPCHK(hipMemset(h->n_obst, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->scene_c, 0, N * SC_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->state, 0, N * ST_WORDS * sizeof(double)));
@@ -257,7 +278,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->stage};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->stage, h->traj, h->traj_len};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -326,7 +347,7 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     if (verts) HIPCHK(hipMemcpy(sp + o_verts, verts, tile * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_scene_consts, dim3((n + 127) / 128), dim3(128), 0, 0, n, (const int32_t*)(sp + o_ids),
                        (const double*)(sp + o_start), (const double*)(sp + o_dest), (const double*)(sp + o_bbox),
-                       (const int32_t*)(sp + o_nob), h->scene_c, h->state, h->tstep, h->n_obst);
+                       (const int32_t*)(sp + o_nob), h->scene_c, h->state, h->tstep, h->n_obst, h->traj, h->traj_len);
     if (verts)
         hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
                            (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), h->verts, h->max_obst);
@@ -354,12 +375,17 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_step: hope_env_set_scenes has not been called");
     if (has_action && !actions) return fail(HOPE_EINVAL, "hope_env_step: actions is null");
     if (stages & HOPE_STAGE_RS) stages |= HOPE_STAGE_REWARD;       // the RS gate needs the status
+    if (stages & HOPE_STAGE_IMG) {
+        if (!h->traj) return fail(HOPE_ESTATE, "hope_env_step: HOPE_STAGE_IMG needs a handle created with HOPE_F_IMAGE");
+        if (!out->img) return fail(HOPE_EINVAL, "hope_env_step: HOPE_STAGE_IMG without out->img");
+    }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     StepParams p;
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
     p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
     p.actions = actions; p.active = active; p.kin = h->kin;
+    p.traj = h->traj; p.traj_len = h->traj_len;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
     if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, 2 * sizeof(int32_t), s));
@@ -412,6 +438,14 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
             HIPCHK(launch_rs_search(r, s, tm));
         }
     }
+    if (stages & HOPE_STAGE_IMG) {
+        BevParams b;
+        b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
+        b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.img = out->img;
+        // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
+        b.active = active;
+        HIPCHK(launch_bev_image(b, s, tm));
+    }
     if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
     return HOPE_OK;
 }
@@ -421,7 +455,7 @@ int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_restart: hope_env_set_scenes has not been called");
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_restart, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->n, mask, h->scene_c,
-                       h->state, h->tstep);
+                       h->state, h->tstep, h->traj, h->traj_len);
     HIPCHK(hipGetLastError());
     return HOPE_OK;
 }

@@ -33,6 +33,21 @@ struct RsParams {
     void* rs_lengths;         // real [n][5]
 };
 
+// bird's-eye image observation (hope_bev.hip)
+constexpr int BEV_IMG = HOPE_IMG_SIZE;
+constexpr int BEV_TRAJ_LEN = HOPE_TRAJ_RENDER_LEN;
+struct BevParams {
+    int n, max_obst;
+    const double* verts;      // [n][max_obst][4][2] world frame
+    const int32_t* n_obst;    // [n]
+    const double* scene_c;    // [n][SC_WORDS]
+    const double* state;      // [n][ST_WORDS]
+    const double* traj;       // [n][BEV_TRAJ_LEN][3] ring of vehicle.trajectory: entry e lives in slot e % BEV_TRAJ_LEN
+    const int32_t* traj_len;  // [n] len(vehicle.trajectory)
+    const uint8_t* active;    // [n] or null
+    uint8_t* img;             // [n][3][64][64]
+};
+
 // optional per-launch profiling hook: begin(kind) / end() bracket ONE kernel launch
 struct LaunchTimer {
     virtual void begin(int kind, hipStream_t s) = 0;
@@ -42,5 +57,7 @@ struct LaunchTimer {
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);   // one tile class
 size_t rs_lds_bytes(int max_obst);
 size_t rs_words_bytes_per_scene();
+hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer);
+size_t bev_lds_bytes();
 
 }  // namespace hope

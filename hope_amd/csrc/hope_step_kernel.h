@@ -33,6 +33,8 @@ struct StepParams {
     int32_t* tstep;           // [n]
     const void* actions;      // [n][2]
     double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
+    double* traj;             // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory (entry e in slot e % 20), else null
+    int32_t* traj_len;        // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
     const uint8_t* active;    // [n] or null
     const double* tab;        // prefix-max mask table [NL][NITER][NACT]
     const double* pmax;       // [NL] max over (a,k) of tab
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     int t = p.tstep[scene];
     wsync();
 
-    bool arrive = false;
+    bool arrive = false, moved = false;
     bool known_free = false;     // final pose already passed _detect_collision in the sub-step loop
     bool have_ua = false;        // overlap area of the final pose already computed
     double ua = 0.0;
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         // the tenth pose
         arrive = ev_arrive;
         const int kf = ev_arrive ? ev_k : (ev_k == NUM_STEP ? NUM_STEP - 1 : ev_k - 1);
+        moved = kf >= 0;
         if (kf >= 0) {
             x = scr[LDS_PX + kf]; y = scr[LDS_PY + kf]; h = scr[LDS_HB + kf];
             ct = scr[LDS_CB + kf]; sn = scr[LDS_SB + kf];
@@ -513,6 +516,17 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (lane == 0) {
         st[0] = x; st[1] = y; st[2] = h; st[3] = accum;
         p.tstep[scene] = t;
+        if (p.traj) {
+            // vehicle.trajectory: of the sub-step states only the last kept one stays (car_parking_base.py:259-276,
+            // vehicle.py:144,158); a step blocked at its first sub-step adds nothing; reset leaves [start]
+            double* tr = p.traj + (size_t)scene * 60;
+            int tl = turnover ? 0 : p.traj_len[scene];
+            if (turnover || moved) {
+                double* e = tr + 3 * (tl % 20);
+                e[0] = x; e[1] = y; e[2] = h;
+                p.traj_len[scene] = tl + 1;
+            }
+        }
         if (p.out.pose) { p.out.pose[3 * (size_t)scene] = x; p.out.pose[3 * (size_t)scene + 1] = y; p.out.pose[3 * (size_t)scene + 2] = h; }
         if (p.stages & HOPE_STAGE_REWARD) {
             if (p.out.status) p.out.status[scene] = status;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 1
+#define HOPE_ABI_VERSION 2
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -40,6 +40,9 @@ extern "C" {
 #define HOPE_UPSAMPLE 10     /* action_mask.py:18 */
 #define HOPE_TARGET_DIM 5    /* car_parking_base.py:72 */
 #define HOPE_RS_MAX_SEG 5    /* longest Reeds-Shepp word (CCSCC) */
+#define HOPE_IMG_SIZE 64      /* OBS_W // downsample_rate (configs.py:88, observation_processor.py:8) */
+#define HOPE_IMG_CHANNELS 3
+#define HOPE_TRAJ_RENDER_LEN 20 /* configs.py:86 */
 
 /* error codes */
 #define HOPE_OK 0
@@ -66,6 +69,7 @@ extern "C" {
 #define HOPE_F_OBS_F64 0x1      /* observation/reward buffers are float64 (parity mode); default float32 */
 #define HOPE_F_ACTION_F64 0x2   /* action buffer is float64; default float32 */
 #define HOPE_F_PROFILE 0x4      /* record HIP events around every kernel launch (hope_env_kernel_ms) */
+#define HOPE_F_IMAGE 0x8        /* keep vehicle.trajectory (last 20 poses/scene) so that HOPE_STAGE_IMG can be used */
 
 /* hope_env_step stage mask */
 #define HOPE_STAGE_MOTION 0x1   /* kinematics + arrival + collision sub-step loop (CarParking.step :255-277) */
@@ -73,6 +77,10 @@ extern "C" {
 #define HOPE_STAGE_REWARD 0x4   /* status + reward (:279-289) + wrapper reward_shaping                     */
 #define HOPE_STAGE_RS 0x8       /* Reeds-Shepp feasibility search (:293-297, find_rs_path :413)           */
 #define HOPE_STAGE_ALL 0xF
+/* bird's-eye image observation obs['img'] (_render :301-320, _get_img_observation :322-350, Obs_Processor
+ * observation_processor.py:11-23, transpose env_wrapper.py:53-54).  Not part of HOPE_STAGE_ALL (the reference's
+ * USE_IMG switch, configs.py:100); needs a handle created with HOPE_F_IMAGE and out->img. */
+#define HOPE_STAGE_IMG 0x40
 /* modifier bit: actions are already physical (steer [rad], speed [m/s]) as CarParking.step receives them
  * (car_parking_base.py:235); without it they are the wrapper's [-1,1] actions and action_rescale
  * (env_wrapper.py:37-50) is applied first.  KSModel's own clip (vehicle.py:85-86) always applies. */
@@ -100,6 +108,8 @@ typedef struct hope_step_out {
     double *pose;       /* f64  [N][3]    x, y, heading after the step (always float64)               */
     int8_t *rs_word;    /* i8   [N][8]    [0..4] segment types (HOPE_RS_*), [5] n_seg, [6] found, [7] 0 */
     void *rs_lengths;   /* real [N][5]    signed segment lengths in metres (PATH.lengths)             */
+    uint8_t *img;       /* u8   [N][3][64][64]  obs['img'] * 255 (channel-first as the wrapper returns it); the
+                           reference's float image is this / 255.0                                    */
 } hope_step_out;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -150,7 +160,8 @@ int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
 #define HOPE_K_STEP 1          /* k_env_step     (wave per scene; one launch per tile class) */
 #define HOPE_K_RS_WORDS 2      /* k_rs_words     (wave per queued scene)                     */
 #define HOPE_K_RS_VALIDATE 3   /* k_rs_validate  (wave per queued scene; per tile class)     */
-#define HOPE_N_KERNELS 4
+#define HOPE_K_IMAGE 4         /* k_bev_image    (wave per scene tile: 16 per scene)         */
+#define HOPE_N_KERNELS 5
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
 

@@ -1,0 +1,176 @@
+"""-m gpu: the bird's-eye image observation kernel (HOPE_STAGE_IMG, k_bev_image) against oracle/hope_oracle_img.c.
+Integer pixels: the comparison is exact (uint8 equality on every one of the 3 x 64 x 64 values)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+def make_img_pair(scenes, max_obst=128):
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import pack_scenes
+    from oracle import oracle as O
+    n = len(scenes)
+    env = ParkingBatch(n, max_obst, obs_dtype=torch.float64, action_dtype=torch.float64, image=True)
+    env.set_scenes(np.arange(n), scenes)
+    orc = O.BatchOracle(n, max_obst)
+    start, dest, bbox, verts, nob, nvert = pack_scenes(scenes, max_obst)
+    orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+    t = env.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    return env, orc
+
+
+def assert_images_equal(env, orc, what, ids=None):
+    torch.cuda.synchronize()
+    got = env.img.cpu().numpy()
+    want = orc.image(ids)
+    if ids is not None:
+        got = got[ids]
+    bad = np.nonzero((got != want).reshape(len(got), -1).any(1))[0]
+    assert len(bad) == 0, f'{what}: {len(bad)} of {len(got)} images differ, first scene {bad[0]}, ' \
+                          f'{int((got[bad[0]] != want[bad[0]]).sum())} values'
+    return got
+
+
+def restart_done(env, orc):
+    """finished episodes start over on the same map, in both implementations"""
+    from oracle import oracle as O
+    done = env.done.cpu().numpy().astype(bool)
+    if not done.any():
+        return 0
+    ids = np.nonzero(done)[0]
+    env.restart(env.done)
+    env.reset_obs(active=env.done.clone())
+    orc.restart(ids)
+    sub = O.BatchOracle(len(ids), orc.max_obst)
+    sub.set_scenes(np.arange(len(ids)), orc.start[ids], orc.dest[ids], orc.bbox[ids], orc.verts[ids], orc.nvert[ids], orc.n_obst[ids])
+    sub.reset_obs()
+    orc.pose[ids] = sub.pose; orc.t[ids] = sub.t; orc.accum[ids] = sub.accum
+    return len(ids)
+
+
+@pytest.mark.parametrize('level', ['mixed', 'dlp'])
+def test_image_rollout_matches_oracle(level):
+    from hope_amd.scenes import DlpScenePool, SceneSource
+    rng = np.random.default_rng(7)
+    n = 160
+    if level == 'dlp':
+        pool = DlpScenePool()
+        scenes = [pool.sample(rng=rng) for _ in range(n)]
+    else:
+        src = SceneSource(seed=17)
+        scenes = [src.draw() for _ in range(n)]
+    for k in range(0, n, 3):                      # a third start close to the destination
+        s = scenes[k]
+        r, a = rng.uniform(0.0, 6.0), rng.uniform(0, 2 * np.pi)
+        s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.5])
+    env, orc = make_img_pair(scenes)
+    env.reset_obs(); orc.reset_obs()
+    img = assert_images_equal(env, orc, 'reset')
+    assert (img[:, :, 32, 32] == np.array([30, 144, 255])).all()          # len(trajectory) == 1: vehicle colour
+    restarts = 0
+    for it in range(28):                           # > 20 steps: the trajectory ring wraps
+        act = rng.uniform(-1.1, 1.1, (n, 2))
+        if it < 6:
+            act[:, 1] = np.abs(act[:, 1]) * (1 if it % 2 == 0 else -1)
+        env.step(torch.from_numpy(act).to(env.device))
+        o = orc.step(act)
+        torch.cuda.synchronize()
+        assert np.array_equal(env.status.cpu().numpy(), o['status'])
+        assert np.array_equal(env.pose.cpu().numpy(), orc.pose)
+        assert_images_equal(env, orc, f'step {it}')
+        restarts += restart_done(env, orc)
+        assert_images_equal(env, orc, f'step {it} after restarts')
+    lens = np.array([len(t) for t in orc.traj])
+    print(f'{level}: restarts {restarts}, trajectory lengths max {lens.max()}')
+    assert lens.max() >= 21 and restarts > 0
+    env.close()
+
+
+def test_image_special_headings_and_background_pixel():
+    """rotate90 path (heading an exact multiple of 90 degrees in float32), the rotate() background taken from the
+    surface's top-left pixel, cars far outside the window, one-pixel-high and degenerate polygons"""
+    from hope_amd.scenes import Scene
+    quarter = [float(np.float64(np.float32(90.0 * k)) * np.pi / 180.0) for k in (0, 1, 2, 3, -1)]
+    scenes = []
+
+    def rect(x0, y0, x1, y1):
+        return np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], float)
+    obst = [rect(3, 2, 7, 4), rect(-6, -5, -4, 3), np.array([[0, 6], [3, 6.5], [1, 8.0]]), rect(-22, -22, -19, -19),
+            rect(-1, -9, 8, -8.93), rect(10, 10, 10.05, 10.05)]
+    verts = np.zeros((len(obst), 4, 2))
+    nvert = np.array([len(o) for o in obst], np.int32)
+    for i, o in enumerate(obst):
+        verts[i, :len(o)] = o
+        verts[i, len(o):] = o[-1]
+
+    def mk(start, half):
+        return Scene(start=np.array(start, float), dest=np.array([6.0, -6.0, 0.4]), bbox=np.array([-half, half, -half, half], float),
+                     verts=verts.copy(), nvert=nvert.copy(), level='Normal')
+    for h in quarter + [0.3, -2.0, 1e-9, np.pi]:
+        scenes.append(mk([0.5, -1.0, h], 25.0))
+    # near the surface corner: samples fall outside the source; pixel (0,0) is covered by the 4th obstacle
+    for h in (0.7, 2.5, -1.1):
+        scenes.append(mk([-15.0, -15.0, h], 25.0))
+    # far outside the 500 x 500 surface (map larger than the window): mostly fill colour
+    scenes.append(mk([-40.0, 30.0, 0.9], 50.0))
+    env, orc = make_img_pair(scenes, max_obst=16)
+    env.reset_obs(); orc.reset_obs()
+    img = assert_images_equal(env, orc, 'special reset')
+    rng = np.random.default_rng(3)
+    for it in range(6):
+        act = rng.uniform(-1, 1, (len(scenes), 2))
+        act[: len(quarter), 0] = 0.0                # straight: the heading stays an exact multiple of 90 degrees
+        env.step(torch.from_numpy(act).to(env.device)); orc.step(act)
+        assert_images_equal(env, orc, f'special step {it}')
+    grey = (img[-2] == 150).all(0).mean()
+    assert grey > 0.02, 'the corner scene should show the top-left pixel colour outside the source'
+    env.close()
+
+
+def test_image_with_auto_reset_and_active_mask():
+    """HOPE_AUTO_RESET: the image is the NEW episode's first observation, like lidar / mask / target"""
+    from hope_amd.scenes import SceneSource
+    src = SceneSource(levels=('Normal', 'Complex'), seed=5)
+    scenes = [src.draw() for _ in range(96)]
+    envA, orc = make_img_pair(scenes, max_obst=32)
+    envB, _ = make_img_pair(scenes, max_obst=32)
+    envA.reset_obs(); envB.reset_obs(); orc.reset_obs()
+    rng = np.random.default_rng(1)
+    n_done = 0
+    for it in range(45):
+        act = rng.uniform(-1.2, 1.2, (96, 2))
+        act[:, 1] = np.sign(act[:, 1] + 1e-9)
+        a = torch.from_numpy(act).to(envA.device)
+        envA.step(a, auto_reset=True)
+        envB.step(a)
+        orc.step(act)
+        torch.cuda.synchronize()
+        n_done += int(envB.done.sum())
+        restart_done(envB, orc)
+        torch.cuda.synchronize()
+        assert torch.equal(envA.img, envB.img)
+        assert_images_equal(envA, orc, f'auto-reset step {it}')
+    assert n_done >= 4
+    # active mask: untouched scenes keep their previous image
+    before = envA.img.clone()
+    mask = torch.zeros(96, dtype=torch.uint8, device=envA.device)
+    mask[::2] = 1
+    envA.step(torch.from_numpy(rng.uniform(-1, 1, (96, 2))).to(envA.device), active=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(envA.img[1::2], before[1::2])
+    assert not torch.equal(envA.img[::2], before[::2])
+    envA.close(); envB.close()
+
+
+def test_image_stage_needs_the_image_flag():
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scenes import SceneSource
+    env = ParkingBatch(4, 32)
+    env.set_scenes(np.arange(4), [SceneSource(seed=1).draw() for _ in range(4)])
+    with pytest.raises(L.HopeError):
+        env.reset_obs(stages=L.STAGE_ALL | L.STAGE_IMG)
+    env.close()
