@@ -7,18 +7,22 @@
 //   black, and cv2.resize(INTER_LINEAR) to 64 x 64 reads exactly the 2 x 2 centre of every 4 x 4 block.
 //
 // MI355X formulation: nothing outside those 2 x 2 centres is ever observed, so no 500 x 500 surface, no rotated copy
-// and no crop are materialised.  One 64-lane wave renders one 16 x 16-output tile of one scene:
-//   1. the composite crop -> rotate -> world map is evaluated at the tile's four corner samples: the world pixels it
-//      can touch form a window of at most 90 x 90 px, kept as one byte per pixel (palette id) in LDS (8 KB);
-//   2. polygons are converted to integer pixels lane-parallel (lane = obstacle / car box), culled against the window
-//      with a ballot, and the survivors are rasterised one after the other in the reference's draw order with
-//      pygame's exact scan-line rule (lane = row; floor / ceil on alternate intersections; horizontal border pass)
-//      or its Bresenham walk in closed form (lane = step) for the start outline;
-//   3. the 1024 samples of the tile gather their palette id through the fixed-point map, colours are summed in a
-//      packed 3 x 10-bit word, rounded like OpenCV ((s + 2) >> 2) and stored as uint8 CHW.
-// All tiles of a scene run on the same XCD (block -> (scene, tile) map below) so the obstacle tile is fetched into
-// one L2 only.  Integer work throughout, except the pose -> pixel conversion and the rotation setup (float64, shared
-// hope_math.h), so the result is bit-identical to oracle/hope_oracle_img.c.
+// and no crop are materialised.
+//   k_bev_prep  (wave per scene): the crop -> rotate -> world map (12 integers) and, for every car-shaped box that is
+//      new this step (vehicle, newest trajectory entry; dest / start once per episode), its integer pixel corners and
+//      its scan-line spans under pygame's rule (lane = row).  A box keeps its spans for the 20 steps it stays in the
+//      trajectory ring, so they live in a per-scene table in HBM (7 KB/scene), indexed like the ring.
+//   k_bev_image (wave per scene, looping over its 16 tiles of 16 x 16 outputs so that the map, the box headers, the span
+//      tables and the obstacle pixels are fetched once and the waves live long enough to hide latency): the world pixels
+//      a tile can touch form a window of at most 90 x 90 px, kept as one byte per pixel (palette id) in LDS.  Obstacles are converted to
+//      integer pixels lane-parallel (lane = obstacle), culled against the window with a ballot and rasterised with
+//      pygame's exact scan-line rule (lane = row; floor / ceil on alternate intersections; horizontal border pass);
+//      the start outline is pygame's Bresenham walk in closed form (lane = step); boxes are filled from their span
+//      table (copied into LDS once), each trajectory box only where its successor -- drawn next, overlapping ~90 % --
+//      will not overwrite it.  Then the tile's 1024 samples gather their palette id through the fixed-point map,
+//      colours are summed in a packed 3 x 10-bit word, rounded like OpenCV ((s + 2) >> 2) and stored as uint8 CHW.
+// Integer work throughout, except the pose -> pixel conversion and the rotation setup (float64, shared hope_math.h),
+// so the result is bit-identical to oracle/hope_oracle_img.c.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
@@ -40,59 +44,92 @@ constexpr int FB_BYTES = FB_DIM * FB_STRIDE;
 constexpr double RENDER_K = 12.0;              // K  configs.py:103
 constexpr int SRC_MAX = (WIN << 16) - 1;
 
+// ---- per-scene scratch written by k_bev_prep (BEV_SCENE_INTS ints) -------------------------------------------------
+constexpr int N_BOX = 3 + BEV_TRAJ_LEN;        // 0 start, 1 dest, 2 vehicle, 3 + s: trajectory ring slot s
+constexpr int N_TAB = 2 + BEV_TRAJ_LEN;        // span tables: 0 dest, 1 vehicle, 2 + s: ring slot s
+constexpr int TAB_ROWS = 64;                   // a car box is at most 62 px high (diagonal of 56 x 23)
+constexpr int HDR_INTS = 16;
+constexpr int OFF_MAP = 0, OFF_HDR = 16, OFF_TAB = OFF_HDR + N_BOX * HDR_INTS;
+static_assert(OFF_TAB + N_TAB * TAB_ROWS == BEV_SCENE_INTS, "scratch layout");
+enum { M_DXX, M_DXY, M_DX0, M_DYX, M_DYY, M_DY0, M_ROX, M_ROY, M_VEH_HIDDEN };
+enum { H_MINY, H_NROWS, H_FLAGS, H_MINX, H_MAXX, H_MAXY, H_VX, H_VY = H_VX + 4 };
+constexpr int F_SIMPLE = 1;                    // every row has exactly one span and the border pass adds nothing outside
+constexpr uint32_t SPAN_EMPTY = 2u | (1u << 16);   // a0 = 1 > a1 = 0 (stored + 1)
+
 struct Window { int x0, y0, x1, y1; };         // inclusive world-pixel bounds, inside [0, 499]^2
 
-// the crop -> world-surface map of _get_img_observation, wave-uniform
-struct Mapping {
-    int turns;                                 // >= 0: rotate90 path with this many quarter turns; -1: general
-    int cy, xd, yd, isin, icos, ax, ay;        // transform.c rotate()
-    int x0, y0;                                // capture.get_rect(center=(250, 250)) placement
-    int ox, oy;                                // observation.blit(rotate, (int(-dx), int(-dy)))
-};
+// The crop -> world-surface map of _get_img_observation, wave-uniform.  blit offsets, Rect placement and rotate()'s
+// 16.16 stepping (or rotate90's index swap) are all integer-affine in the crop pixel (x, y), so k_bev_prep folds them:
+//   rx = x + rox, ry = y + roy                 pixel of `rotate`; outside [0, 500)^2 -> observation.fill(BG_COLOR)
+//   dx = dxx x + dxy y + dx0, dy = dyx x + dyy y + dy0     source position, 16.16; outside [0, 500 << 16) -> rotate()'s
+//                                              bgcolor, else world pixel (dx >> 16, dy >> 16)
+struct Mapping { int dxx, dxy, dx0, dyx, dyy, dy0, rox, roy; };
 
 __device__ __forceinline__ int to_px(double X, double Y, double k0, double k1, double off) {
     return (int)(k0 * X + k1 * Y + off);       // shapely affine_transform (a*x + b*y + xoff), then C truncation
 }
 
-// source position of crop pixel (x, y) WITHOUT the range tests (used for the window bounds)
-__device__ __forceinline__ void map_raw(const Mapping& m, int x, int y, int& sx, int& sy, int& dx, int& dy) {
-    const int rx = CROP_OFF + x - m.ox, ry = CROP_OFF + y - m.oy;
-    if (m.turns >= 0) {
-        switch (m.turns) {                     // transform.c rotate90
-            case 0: sx = rx; sy = ry; break;
-            case 1: sx = WIN - 1 - ry; sy = rx; break;
-            case 2: sx = WIN - 1 - rx; sy = WIN - 1 - ry; break;
-            default: sx = ry; sy = WIN - 1 - rx; break;
+__device__ __forceinline__ void map_raw(const Mapping& m, int x, int y, int& dx, int& dy) {
+    // coefficients <= 65536 in magnitude, x and y < 256: 24-bit multiplies are exact
+    dx = __mul24(m.dxx, x) + __mul24(m.dxy, y) + m.dx0;
+    dy = __mul24(m.dyx, x) + __mul24(m.dyy, y) + m.dy0;
+}
+
+// ---- pygame draw.c ------------------------------------------------------------------------------------------------
+// draw_fillpoly's scan-line intersections of ONE row, sorted (qsort); cnt = how many (0 when the row is outside)
+struct Spans { int a0, a1, a2, a3, cnt; };
+
+__device__ __forceinline__ Spans row_spans(const int (&px)[5], const int (&py)[5], int n, int maxy, int y, bool active) {
+    Spans r;
+    int cnt = 0, a0 = INT_MAX, a1 = INT_MAX, a2 = INT_MAX, a3 = INT_MAX;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            if (i >= n) continue;
+            const int ip = i ? i - 1 : n - 1;
+            int y1 = py[ip], y2 = py[i], x1 = px[ip], x2 = px[i];
+            if (y1 == y2) continue;                                      // horizontal edges: border pass
+            if (y1 > y2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+            if ((y >= y1 && y < y2) || (y == maxy && y2 == maxy)) {
+                float f = (float)__mul24(y - y1, x2 - x1) / (float)(y2 - y1);   // pixel differences: far below 2^23
+                f = (cnt & 1) ? ceilf(f) : floorf(f);                    // alternate floor / ceil in discovery order
+                const int xv = (int)f + x1;
+                if (cnt == 0) a0 = xv; else if (cnt == 1) a1 = xv; else if (cnt == 2) a2 = xv; else a3 = xv;
+                cnt++;
+            }
         }
-        dx = sx << 16; dy = sy << 16;
-        return;
     }
-    const int X = rx - m.x0, Y = ry - m.y0;
-    dx = (m.ax + m.isin * (m.cy - Y)) + m.xd + m.icos * X;
-    dy = (m.ay - m.icos * (m.cy - Y)) + m.yd + m.isin * X;
-    sx = dx >> 16; sy = dy >> 16;
+    int t;                                                               // missing values are INT_MAX and stay at the end
+    if (a0 > a1) { t = a0; a0 = a1; a1 = t; }
+    if (a2 > a3) { t = a2; a2 = a3; a3 = t; }
+    if (a0 > a2) { t = a0; a0 = a2; a2 = t; }
+    if (a1 > a3) { t = a1; a1 = a3; a3 = t; }
+    if (a1 > a2) { t = a1; a1 = a2; a2 = t; }
+    r.a0 = a0; r.a1 = a1; r.a2 = a2; r.a3 = a3; r.cnt = cnt;
+    return r;
 }
 
-// 0: world pixel (sx, sy); 1: outside `rotate` -> observation.fill(BG_COLOR); 2: outside the source -> rotate()'s bgcolor
-__device__ __forceinline__ int map_sample(const Mapping& m, int x, int y, int& sx, int& sy) {
-    const int rx = CROP_OFF + x - m.ox, ry = CROP_OFF + y - m.oy;
-    if (rx < 0 || rx >= WIN || ry < 0 || ry >= WIN) return 1;
-    int dx, dy;
-    map_raw(m, x, y, sx, sy, dx, dy);
-    if (m.turns < 0 && (dx < 0 || dy < 0 || dx > SRC_MAX || dy > SRC_MAX)) return 2;
-    return 0;
-}
-
-// ---- pygame draw.c on the LDS window ------------------------------------------------------------------------------
 __device__ __forceinline__ void hline(uint8_t* fb, const Window& w, int id, int xa, int y, int xb, int lane) {
     if (y < w.y0 || y > w.y1) return;          // the window lies inside the surface: this is also drawhorzlineclip's test
     if (xb < xa) { const int t = xa; xa = xb; xb = t; }
     xa = max(xa, w.x0); xb = min(xb, w.x1);
-    uint8_t* row = fb + (y - w.y0) * FB_STRIDE - w.x0;
+    uint8_t* row = fb + __mul24(y - w.y0, FB_STRIDE) - w.x0;
     for (int x = xa + lane; x <= xb; x += WAVE) row[x] = (uint8_t)id;
 }
 
-// draw_fillpoly: n points (closing point included), wave-uniform
+// pixels [xa, xb] of one row := id, lane = row.  Four byte stores per trip, lanes that are done (or have no row)
+// store to their own dummy byte instead of branching around the store.
+__device__ __forceinline__ void fill_span(uint8_t* row, uint8_t* dummy, int id, int xa, int xb) {
+    while (__any(xa <= xb)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint8_t* a = (xa + k <= xb) ? row + xa + k : dummy;
+            *a = (uint8_t)id;
+        }
+        xa += 4;
+    }
+}
+// draw_fillpoly on the LDS window: n points (closing point included), wave-uniform; lane = row
 __device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, const int (&px)[5], const int (&py)[5], int n,
                                           int id, int lane) {
     int miny = py[0], maxy = py[0], minx = px[0], maxx = px[0];
@@ -103,44 +140,11 @@ __device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, const in
     const int ylo = max(miny, w.y0), yhi = min(maxy, w.y1);
     for (int yb = ylo; yb <= yhi; yb += WAVE) {
         const int y = yb + lane;
-        int cnt = 0, a0 = INT_MAX, a1 = INT_MAX, a2 = INT_MAX, a3 = INT_MAX;
-        if (y <= yhi) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (i >= n) continue;
-                const int ip = i ? i - 1 : n - 1;
-                int y1 = py[ip], y2 = py[i], x1 = px[ip], x2 = px[i];
-                if (y1 == y2) continue;                                  // horizontal edges: border pass below
-                if (y1 > y2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
-                if ((y >= y1 && y < y2) || (y == maxy && y2 == maxy)) {
-                    float f = (float)((y - y1) * (x2 - x1)) / (float)(y2 - y1);
-                    f = (cnt & 1) ? ceilf(f) : floorf(f);                // alternate floor / ceil in discovery order
-                    const int xv = (int)f + x1;
-                    if (cnt == 0) a0 = xv; else if (cnt == 1) a1 = xv; else if (cnt == 2) a2 = xv; else a3 = xv;
-                    cnt++;
-                }
-            }
-        }
-        // qsort of at most four values (missing ones are INT_MAX and stay at the end)
-        int t;
-        if (a0 > a1) { t = a0; a0 = a1; a1 = t; }
-        if (a2 > a3) { t = a2; a2 = a3; a3 = t; }
-        if (a0 > a2) { t = a0; a0 = a2; a2 = t; }
-        if (a1 > a3) { t = a1; a1 = a3; a3 = t; }
-        if (a1 > a2) { t = a1; a1 = a2; a2 = t; }
-        uint8_t* row = fb + (y - w.y0) * FB_STRIDE - w.x0;
-        int xa = cnt >= 2 ? max(a0, w.x0) : 1, xb = cnt >= 2 ? min(a1, w.x1) : 0;
-        while (__any(xa <= xb)) {
-            if (xa <= xb) row[xa] = (uint8_t)id;
-            xa++;
-        }
-        if (__any(cnt >= 4)) {
-            xa = cnt >= 4 ? max(a2, w.x0) : 1; xb = cnt >= 4 ? min(a3, w.x1) : 0;
-            while (__any(xa <= xb)) {
-                if (xa <= xb) row[xa] = (uint8_t)id;
-                xa++;
-            }
-        }
+        const Spans c = row_spans(px, py, n, maxy, y, y <= yhi);
+        uint8_t* row = fb + __mul24(y - w.y0, FB_STRIDE) - w.x0;
+        uint8_t* dummy = fb + FB_BYTES + lane;
+        fill_span(row, dummy, id, c.cnt >= 2 ? max(c.a0, w.x0) : 1, c.cnt >= 2 ? min(c.a1, w.x1) : 0);
+        if (__any(c.cnt >= 4)) fill_span(row, dummy, id, c.cnt >= 4 ? max(c.a2, w.x0) : 1, c.cnt >= 4 ? min(c.a3, w.x1) : 0);
     }
 #pragma unroll
     for (int i = 0; i < 5; i++) {                                        // horizontal border edges strictly inside in y
@@ -179,27 +183,34 @@ __device__ __forceinline__ uint32_t palette(int id) {
     return r | (g << 10) | (b << 20);
 }
 
-__global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
-    extern __shared__ __align__(16) uint8_t lds_raw[];
-    uint8_t* fb = lds_raw;
-    uint32_t* pal = (uint32_t*)(lds_raw + FB_BYTES + 8);
+// ====================================================================================================================
+// k_bev_prep: wave per scene
+// ====================================================================================================================
+__global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
     const int lane = threadIdx.x;
-    // blocks b, b + 8, b + 16, ... share an XCD: give all 16 tiles of a scene to one XCD
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int scene = ((j >> 4) << 3) + xcd, tile = j & 15;
+    const int scene = blockIdx.x;
     if (scene >= p.n) return;
     if (p.active && !p.active[scene]) return;
-    const int tx = tile & 3, ty = tile >> 2;
-
+    int* out = p.scratch + (size_t)scene * BEV_SCENE_INTS;
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double* st = p.state + (size_t)scene * ST_WORDS;
     const double px_ = st[0], py_ = st[1], ph = st[2];
     // coord_transform_matrix (car_parking_base.py:139-147)
     const double offx = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 1] + sc[SC_BBOX])), offy = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 3] + sc[SC_BBOX + 2]));
+    const int traj_len = p.traj_len[scene];
+    const int valid = p.traj_valid[scene];             // trajectory entries [.., valid) already have their spans
+    const double* ring = p.traj + (size_t)scene * BEV_TRAJ_LEN * 3;
 
-    // ---- the crop -> world map (wave-uniform) --------------------------------------------------------------------
-    Mapping m;
+    // the vehicle box is exactly the newest trajectory box whenever that entry is the current pose (always, unless the
+    // pose was set from outside): it is then completely overdrawn and needs neither spans nor drawing
+    const double* newest = ring + 3 * ((traj_len - 1 + BEV_TRAJ_LEN) % BEV_TRAJ_LEN);
+    const bool veh_hidden = traj_len > 1 && newest[0] == px_ && newest[1] == py_ && newest[2] == ph;
+
+    // ---- the crop -> world map --------------------------------------------------------------------------------------
     {
+        int mv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) mv[i] = 0;
         double sh, ch;
         hm_sincos(ph, &sh, &ch);
         const Box vb = make_box(px_, py_, ch, sh);
@@ -219,176 +230,352 @@ __global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
         const double vcx = RENDER_K * ccx + 0.0 * ccy + offx, vcy = 0.0 * ccx + RENDER_K * ccy + offy;
         const double ddx = (vcx - WIN / 2) * ch + (vcy - WIN / 2) * sh;
         const double ddy = -(vcx - WIN / 2) * sh + (vcy - WIN / 2) * ch;
-        m.ox = (int)(-ddx); m.oy = (int)(-ddy);
+        const int ox = (int)(-ddx), oy = (int)(-ddy);                         // observation.blit(rotate, (int(-dx), int(-dy)))
+        const int rox = CROP_OFF - ox, roy = CROP_OFF - oy;                   // subsurface origin :343-344
+        int dxx, dxy, dx0, dyx, dyy, dy0;                                     // source position as a function of (rx, ry)
         const float angle = (float)(ph * (180.0 / 3.141592653589793));        // np.rad2deg -> C float argument
-        if (hm_fmod((double)angle, 90.0) == 0.0) {
+        if (hm_fmod((double)angle, 90.0) == 0.0) {                            // transform.c rotate90
             int t = ((int)angle / 90) % 4;
             if (t < 0) t += 4;
-            m.turns = t;
-            m.x0 = 0; m.y0 = 0;
-            m.cy = m.xd = m.yd = m.isin = m.icos = m.ax = m.ay = 0;
-        } else {
-            m.turns = -1;
+            const int one = 1 << 16, last = (WIN - 1) << 16;
+            if (t == 0) { dxx = one; dxy = 0; dx0 = 0; dyx = 0; dyy = one; dy0 = 0; }                    // (rx, ry)
+            else if (t == 1) { dxx = 0; dxy = -one; dx0 = last; dyx = one; dyy = 0; dy0 = 0; }            // (499 - ry, rx)
+            else if (t == 2) { dxx = -one; dxy = 0; dx0 = last; dyx = 0; dyy = -one; dy0 = last; }        // (499 - rx, 499 - ry)
+            else { dxx = 0; dxy = one; dx0 = 0; dyx = -one; dyy = 0; dy0 = last; }                        // (ry, 499 - rx)
+        } else {                                                              // transform.c surf_rotate + rotate()
             const double radangle = angle * .01745329251994329;
             double sangle, cangle;
             hm_sincos(radangle, &sangle, &cangle);
             const double cx = cangle * WIN, cy = cangle * WIN, sxx = sangle * WIN, syy = sangle * WIN;
             const int nw = (int)fmax(fmax(fmax(fabs(cx + syy), fabs(cx - syy)), fabs(-cx + syy)), fabs(-cx - syy));
             const int nh = (int)fmax(fmax(fmax(fabs(sxx + cy), fabs(sxx - cy)), fabs(-sxx + cy)), fabs(-sxx - cy));
-            m.cy = nh / 2;
-            m.xd = (WIN - nw) * 32768;
-            m.yd = (WIN - nh) * 32768;
-            m.isin = (int)(sangle * 65536);
-            m.icos = (int)(cangle * 65536);
-            m.ax = (nw * 32768) - (int)(cangle * ((nw - 1) * 32768));
-            m.ay = (nh * 32768) - (int)(sangle * ((nw - 1) * 32768));
-            m.x0 = WIN / 2 - (nw >> 1); m.y0 = WIN / 2 - (nh >> 1);
+            const int rcy = nh / 2;
+            const int xd = (WIN - nw) * 32768, yd = (WIN - nh) * 32768;
+            const int isin = (int)(sangle * 65536), icos = (int)(cangle * 65536);
+            const int ax = (nw * 32768) - (int)(cangle * ((nw - 1) * 32768));
+            const int ay = (nh * 32768) - (int)(sangle * ((nw - 1) * 32768));
+            const int x0 = WIN / 2 - (nw >> 1), y0 = WIN / 2 - (nh >> 1);     // capture.get_rect(center=(250, 250))
+            // capture pixel (X, Y) = (rx - x0, ry - y0):  dx = ax + isin (rcy - Y) + xd + icos X,  dy = ay - icos (rcy - Y) + yd + isin X
+            dxx = icos; dxy = -isin; dx0 = ax + xd + isin * (rcy + y0) - icos * x0;
+            dyx = isin; dyy = icos; dy0 = ay + yd - icos * (rcy + y0) - isin * x0;
         }
-    }
-
-    // ---- world window of this tile: the map is affine, so the extremes are at the corner samples --------------------
-    Window w;
-    bool need_bg = false;
-    {
-        const int cxa = 4 * TILE_OUT * tx + 1, cxb = 4 * TILE_OUT * tx + 4 * TILE_OUT - 2;
-        const int cya = 4 * TILE_OUT * ty + 1, cyb = 4 * TILE_OUT * ty + 4 * TILE_OUT - 2;
-        int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
+        mv[M_DXX] = dxx; mv[M_DXY] = dxy; mv[M_DX0] = dx0 + dxx * rox + dxy * roy;
+        mv[M_DYX] = dyx; mv[M_DYY] = dyy; mv[M_DY0] = dy0 + dyx * rox + dyy * roy;
+        mv[M_ROX] = rox; mv[M_ROY] = roy;
+        mv[M_VEH_HIDDEN] = veh_hidden;
+        int v = 0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            int sx, sy, dx, dy;
-            map_raw(m, (c & 1) ? cxb : cxa, (c & 2) ? cyb : cya, sx, sy, dx, dy);
-            lo_x = min(lo_x, sx); hi_x = max(hi_x, sx); lo_y = min(lo_y, sy); hi_y = max(hi_y, sy);
-            need_bg = need_bg || (m.turns < 0 && (dx < 0 || dy < 0 || dx > SRC_MAX || dy > SRC_MAX));
-        }
-        w.x0 = max(lo_x, 0); w.x1 = min(hi_x, WIN - 1); w.y0 = max(lo_y, 0); w.y1 = min(hi_y, WIN - 1);
+        for (int i = 0; i < 16; i++) v = lane == i ? mv[i] : v;
+        if (lane < 16) out[OFF_MAP + lane] = v;
     }
 
-    if (lane < 25) pal[lane] = palette(lane);
+    // ---- boxes that are new this step: lane = box slot ---------------------------------------------------------------
+    int vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0};
+    bool need = false;
+    if (lane < N_BOX) {
+        double bxp = 0, byp = 0, bh = 0;
+        if (lane == 0) { bxp = sc[SC_START]; byp = sc[SC_START + 1]; bh = sc[SC_START + 2]; need = valid == 0; }
+        else if (lane == 1) { bxp = sc[SC_DEST]; byp = sc[SC_DEST + 1]; bh = sc[SC_DEST + 2]; need = valid == 0; }
+        else if (lane == 2) { bxp = px_; byp = py_; bh = ph; need = !veh_hidden; }
+        else {
+            const int s = lane - 3;
+            // newest entry living in ring slot s: the largest e <= traj_len - 1 with e % 20 == s
+            const int e = (traj_len - 1) - (((traj_len - 1 - s) % BEV_TRAJ_LEN) + BEV_TRAJ_LEN) % BEV_TRAJ_LEN;
+            need = e >= 0 && e >= valid;
+            bxp = ring[3 * s]; byp = ring[3 * s + 1]; bh = ring[3 * s + 2];
+        }
+        if (need) {
+            double sb, cb;
+            hm_sincos(bh, &sb, &cb);
+            const Box bb = make_box(bxp, byp, cb, sb);                       // State.create_box  vehicle.py:32-36
+#pragma unroll
+            for (int k = 0; k < 4; k++) { vx[k] = to_px(bb.x[k], bb.y[k], RENDER_K, 0.0, offx); vy[k] = to_px(bb.x[k], bb.y[k], 0.0, RENDER_K, offy); }
+        }
+    }
+    unsigned long long mask = __ballot(need);
+    while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        int qx[5], qy[5];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
+        qx[4] = qx[0]; qy[4] = qy[0];
+        int miny = qy[0], maxy = qy[0], minx = qx[0], maxx = qx[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++) { miny = min(miny, qy[i]); maxy = max(maxy, qy[i]); minx = min(minx, qx[i]); maxx = max(maxx, qx[i]); }
+        const int nrows = maxy - miny + 1;
+        bool simple = miny != maxy && nrows <= TAB_ROWS;
+        const int y = miny + lane;
+        const Spans c = row_spans(qx, qy, 5, maxy, y, y <= maxy);
+        simple = simple && !__any(y <= maxy && c.cnt != 2);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {                                        // the border pass must not add pixels outside the spans
+            const int ip = i ? i - 1 : 4;
+            const int yy = qy[i];
+            if (miny < yy && qy[ip] == yy && yy < maxy)
+                simple = simple && !__any(y == yy && !(c.a0 <= min(qx[i], qx[ip]) && max(qx[i], qx[ip]) <= c.a1));
+        }
+        int* hdr = out + OFF_HDR + l * HDR_INTS;
+        int hv = 0;
+        hv = lane == H_MINY ? miny : hv; hv = lane == H_NROWS ? min(nrows, TAB_ROWS) : hv; hv = lane == H_FLAGS ? (simple ? F_SIMPLE : 0) : hv;
+        hv = lane == H_MINX ? minx : hv; hv = lane == H_MAXX ? maxx : hv; hv = lane == H_MAXY ? maxy : hv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hv = lane == H_VX + k ? qx[k] : hv; hv = lane == H_VY + k ? qy[k] : hv; }
+        if (lane < HDR_INTS) hdr[lane] = hv;
+        if (l >= 1) {                                                        // spans clamped to the surface (+1: unsigned)
+            uint32_t sp = SPAN_EMPTY;
+            if (y <= maxy && c.cnt >= 2) sp = (uint32_t)(min(max(c.a0, -1), WIN) + 1) | ((uint32_t)(min(max(c.a1, -1), WIN) + 1) << 16);
+            out[OFF_TAB + (l - 1) * TAB_ROWS + lane] = (int)sp;
+        }
+    }
+    if (lane == 0) p.traj_valid[scene] = traj_len;
+}
 
-    const int n_obst = p.n_obst[scene];
+// ====================================================================================================================
+// k_bev_image: wave per (scene, tile)
+// ====================================================================================================================
+// span of a table box on world row y, clipped to [x_lo, x_hi]
+__device__ __forceinline__ void table_span(const uint32_t* tab, int miny, int nrows, int y, int x_lo, int x_hi, int& a, int& b) {
+    const int r = y - miny;
+    const uint32_t sp = (r >= 0 && r < nrows) ? tab[r] : SPAN_EMPTY;
+    a = max((int)(sp & 0xffff) - 1, x_lo);
+    b = min((int)(sp >> 16) - 1, x_hi);
+}
+
+__global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    uint8_t* fb = lds_raw;
+    uint32_t* pal = (uint32_t*)(lds_raw + FB_BYTES + 72);                  // 64 dummy bytes (fill_span) after the window
+    uint32_t* tabs = pal + 32;                                               // [N_TAB][TAB_ROWS]
+    const int lane = threadIdx.x;
+    const int scene = scene_of_block(blockIdx.x, p.n);
+    if (scene >= p.n) return;
+    if (p.active && !p.active[scene]) return;
+    const int* scr = p.scratch + (size_t)scene * BEV_SCENE_INTS;
+    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+    const double offx = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 1] + sc[SC_BBOX])), offy = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 3] + sc[SC_BBOX + 2]));
+
+    // ---- everything the 16 tiles share is fetched once: map, box headers, span tables, obstacle pixels ---------------
+    Mapping m;
+    m.dxx = scr[OFF_MAP + M_DXX]; m.dxy = scr[OFF_MAP + M_DXY]; m.dx0 = scr[OFF_MAP + M_DX0];
+    m.dyx = scr[OFF_MAP + M_DYX]; m.dyy = scr[OFF_MAP + M_DYY]; m.dy0 = scr[OFF_MAP + M_DY0];
+    m.rox = scr[OFF_MAP + M_ROX]; m.roy = scr[OFF_MAP + M_ROY];
+    const bool veh_hidden = scr[OFF_MAP + M_VEH_HIDDEN] != 0;
+    const int n_obst = (p.debug & 2) ? 0 : p.n_obst[scene];
     const int traj_len = p.traj_len[scene];
     const int m_traj = min(traj_len, BEV_TRAJ_LEN);
-    int bg_id = 0;
-    // pass 0 (rare): the rotate() background colour is the surface's top-left pixel -- rasterise a 1 x 1 window there
-    for (int pass = need_bg ? 0 : 1; pass < 2; pass++) {
-        const Window cw = pass == 0 ? Window{0, 0, 0, 0} : w;
-        {   // surface.fill(BG_COLOR)
-            uint32_t* f4 = (uint32_t*)fb;
-            for (int i = lane; i < FB_BYTES / 4; i += WAVE) f4[i] = 0;
-        }
-        wsync();
-        if (cw.x0 <= cw.x1 && cw.y0 <= cw.y1) {
-            // obstacles (car_parking_base.py:303-305), lane = obstacle
-            for (int base = 0; base < n_obst; base += WAVE) {
-                const int o = base + lane;
-                int vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0}, nv = 4;
-                bool hit = false;
-                if (o < n_obst) {
-                    const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { vx[k] = to_px(v[2 * k], v[2 * k + 1], RENDER_K, 0.0, offx); vy[k] = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); }
-                    if (v[6] == v[4] && v[7] == v[5]) nv = 3;              // triangles repeat their last vertex (include/hope_env.h)
-                    const int bx0 = min(min(vx[0], vx[1]), min(vx[2], vx[3])), bx1 = max(max(vx[0], vx[1]), max(vx[2], vx[3]));
-                    const int by0 = min(min(vy[0], vy[1]), min(vy[2], vy[3])), by1 = max(max(vy[0], vy[1]), max(vy[2], vy[3]));
-                    hit = !(bx1 < cw.x0 || bx0 > cw.x1 || by1 < cw.y0 || by0 > cw.y1);
-                }
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    int qx[5], qy[5];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
-                    const int qn = __builtin_amdgcn_readlane(nv, l);
-                    if (qn == 3) { qx[3] = qx[0]; qy[3] = qy[0]; qx[4] = qx[0]; qy[4] = qy[0]; }
-                    else { qx[4] = qx[0]; qy[4] = qy[0]; }
-                    fill_poly(fb, cw, qx, qy, qn + 1, 1, lane);
-                }
-            }
-            // start outline, dest, vehicle, trajectory boxes oldest -> newest (:307-320), lane = box
-            {
-                int vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0}, id = 0;
-                bool hit = false;
-                const int n_box = 3 + (traj_len > 1 ? m_traj : 0);
-                if (lane < n_box) {
-                    double bxp, byp, bh;
-                    if (lane == 0) { bxp = sc[SC_START]; byp = sc[SC_START + 1]; bh = sc[SC_START + 2]; id = 2; }
-                    else if (lane == 1) { bxp = sc[SC_DEST]; byp = sc[SC_DEST + 1]; bh = sc[SC_DEST + 2]; id = 3; }
-                    else if (lane == 2) { bxp = px_; byp = py_; bh = ph; id = 4; }
-                    else {
-                        const int i = lane - 3;
-                        const int e = traj_len - m_traj + i;                 // vehicle.trajectory[-(m - i)]
-                        const double* tp = p.traj + ((size_t)scene * BEV_TRAJ_LEN + (e % BEV_TRAJ_LEN)) * 3;
-                        bxp = tp[0]; byp = tp[1]; bh = tp[2];
-                        id = 5 + (BEV_TRAJ_LEN - m_traj + i);                // TRAJ_COLORS[-(m - i)]
-                    }
-                    double sb, cb;
-                    hm_sincos(bh, &sb, &cb);
-                    const Box bb = make_box(bxp, byp, cb, sb);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { vx[k] = to_px(bb.x[k], bb.y[k], RENDER_K, 0.0, offx); vy[k] = to_px(bb.x[k], bb.y[k], 0.0, RENDER_K, offy); }
-                    const int bx0 = min(min(vx[0], vx[1]), min(vx[2], vx[3])), bx1 = max(max(vx[0], vx[1]), max(vx[2], vx[3]));
-                    const int by0 = min(min(vy[0], vy[1]), min(vy[2], vy[3])), by1 = max(max(vy[0], vy[1]), max(vy[2], vy[3]));
-                    hit = !(bx1 < cw.x0 || bx0 > cw.x1 || by1 < cw.y0 || by0 > cw.y1);
-                }
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    int qx[5], qy[5];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
-                    qx[4] = qx[0]; qy[4] = qy[0];
-                    const int qid = __builtin_amdgcn_readlane(id, l);
-                    if (qid == 2) {                                          // width=1: lines(closed=True)
-#pragma unroll
-                        for (int k = 1; k < 5; k++) line(fb, cw, 2, qx[k - 1], qy[k - 1], qx[k], qy[k], lane);
-                        line(fb, cw, 2, qx[4], qy[4], qx[0], qy[0], lane);
-                    } else {
-                        fill_poly(fb, cw, qx, qy, 5, qid, lane);
-                    }
-                    wsync();                                                 // painter's order between overlapping boxes
-                }
-            }
-        }
-        wsync();
-        if (pass == 0) { bg_id = fb[0]; wsync(); }
+    const int n_box = (p.debug & 4) ? 0 : 3 + (traj_len > 1 ? m_traj : 0);
+    {
+        const uint4* src = (const uint4*)(scr + OFF_TAB);
+        for (int i = lane; i < N_TAB * TAB_ROWS / 4; i += WAVE) ((uint4*)tabs)[i] = src[i];
     }
+    if (lane < 25) pal[lane] = palette(lane);
+    // lane = box in draw order: start outline, dest, vehicle, trajectory oldest -> newest (:307-320)
+    int bslot = 0, bid = 0, h_miny = 0, h_nrows = 0, h_flags = 0, h_minx = 0, h_maxx = 0, h_maxy = 0;
+    if (lane < n_box) {
+        if (lane < 3) { bslot = lane; bid = 2 + lane; }
+        else {
+            const int i = lane - 3;
+            const int e = traj_len - m_traj + i;                             // vehicle.trajectory[-(m - i)]
+            bslot = 3 + e % BEV_TRAJ_LEN;
+            bid = 5 + (BEV_TRAJ_LEN - m_traj + i);                           // TRAJ_COLORS[-(m - i)]
+        }
+        const int* hdr = scr + OFF_HDR + bslot * HDR_INTS;
+        h_miny = hdr[H_MINY]; h_nrows = hdr[H_NROWS]; h_flags = hdr[H_FLAGS]; h_minx = hdr[H_MINX]; h_maxx = hdr[H_MAXX]; h_maxy = hdr[H_MAXY];
+    }
+    // obstacles (car_parking_base.py:303-305) as integer pixels, lane = obstacle; the first 128 stay in registers
+    int ovx[2][4], ovy[2][4], onv[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int o = WAVE * c + lane;
+        onv[c] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ovx[c][k] = 0; ovy[c][k] = 0; }
+        if (o < n_obst) {
+            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ovx[c][k] = to_px(v[2 * k], v[2 * k + 1], RENDER_K, 0.0, offx); ovy[c][k] = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); }
+            onv[c] = (v[6] == v[4] && v[7] == v[5]) ? 3 : 4;                 // triangles repeat their last vertex (include/hope_env.h)
+        }
+    }
+    const int n_chunks = (n_obst + WAVE - 1) / WAVE;
 
-    // ---- gather: lane = 4 consecutive outputs of one tile row; cv2.resize reads crop pixels (4u+1|2, 4v+1|2) ---------
-    const int v = TILE_OUT * ty + (lane >> 2);
-    const int u0 = TILE_OUT * tx + 4 * (lane & 3);
-    const uint32_t pal_bg = pal[bg_id];
-    uint32_t out_r = 0, out_g = 0, out_b = 0;
+    for (int tile = 0; tile < TILES * TILES; tile++) {
+        const int tx = tile & 3, ty = tile >> 2;
+        // ---- world window of this tile: the map is affine, so the extremes are at the corner samples ----------------
+        Window w;
+        bool need_bg = false;
+        {
+            const int cxa = 4 * TILE_OUT * tx + 1, cxb = 4 * TILE_OUT * tx + 4 * TILE_OUT - 2;
+            const int cya = 4 * TILE_OUT * ty + 1, cyb = 4 * TILE_OUT * ty + 4 * TILE_OUT - 2;
+            int lo_x = INT_MAX, hi_x = INT_MIN, lo_y = INT_MAX, hi_y = INT_MIN;
 #pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-        const int u = u0 + jj;
-        uint32_t sum = 0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            int sx, sy;
-            const int kind = map_sample(m, 4 * u + 1 + (s & 1), 4 * v + 1 + (s >> 1), sx, sy);
-            uint32_t c = 0;                                                   // white -> black
-            if (kind == 0) c = pal[fb[(sy - w.y0) * FB_STRIDE + sx - w.x0]];
-            else if (kind == 2) c = pal_bg;
-            sum += c;
+            for (int c = 0; c < 4; c++) {
+                int dx, dy;
+                map_raw(m, (c & 1) ? cxb : cxa, (c & 2) ? cyb : cya, dx, dy);
+                lo_x = min(lo_x, dx >> 16); hi_x = max(hi_x, dx >> 16); lo_y = min(lo_y, dy >> 16); hi_y = max(hi_y, dy >> 16);
+                need_bg = need_bg || (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
+            }
+            w.x0 = max(lo_x, 0); w.x1 = min(hi_x, WIN - 1); w.y0 = max(lo_y, 0); w.y1 = min(hi_y, WIN - 1);
         }
-        const uint32_t r = ((sum & 1023) + 2) >> 2, g = (((sum >> 10) & 1023) + 2) >> 2, bl = (((sum >> 20) & 1023) + 2) >> 2;
-        out_r |= r << (8 * jj); out_g |= g << (8 * jj); out_b |= bl << (8 * jj);
+        int bg_id = 0;
+        // pass 0 (rare): the rotate() background colour is the surface's top-left pixel -- rasterise a 1 x 1 window there
+        for (int pass = need_bg ? 0 : 1; pass < 2; pass++) {
+            const Window cw = pass == 0 ? Window{0, 0, 0, 0} : w;
+            wsync();                                                         // the previous tile's gather is done
+            {   // surface.fill(BG_COLOR)
+                uint4* f4 = (uint4*)fb;
+                for (int i = lane; i < (FB_BYTES + 15) / 16; i += WAVE) f4[i] = make_uint4(0, 0, 0, 0);
+            }
+            wsync();
+            const bool live = cw.x0 <= cw.x1 && cw.y0 <= cw.y1 && !(p.debug & 1);
+            if (live) {
+                for (int c = 0; c < n_chunks; c++) {
+                    int vx[4], vy[4], nv;
+                    if (c < 2) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { vx[k] = c == 0 ? ovx[0][k] : ovx[1][k]; vy[k] = c == 0 ? ovy[0][k] : ovy[1][k]; }
+                        nv = c == 0 ? onv[0] : onv[1];
+                    } else {                                                 // more than 128 obstacles: convert again
+                        const int o = WAVE * c + lane;
+                        nv = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { vx[k] = 0; vy[k] = 0; }
+                        if (o < n_obst) {
+                            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { vx[k] = to_px(v[2 * k], v[2 * k + 1], RENDER_K, 0.0, offx); vy[k] = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); }
+                            nv = (v[6] == v[4] && v[7] == v[5]) ? 3 : 4;
+                        }
+                    }
+                    const int bx0 = min(min(vx[0], vx[1]), min(vx[2], vx[3])), bx1 = max(max(vx[0], vx[1]), max(vx[2], vx[3]));
+                    const int by0 = min(min(vy[0], vy[1]), min(vy[2], vy[3])), by1 = max(max(vy[0], vy[1]), max(vy[2], vy[3]));
+                    unsigned long long omask = __ballot(nv != 0 && !(bx1 < cw.x0 || bx0 > cw.x1 || by1 < cw.y0 || by0 > cw.y1));
+                    while (omask) {
+                        const int l = __builtin_ctzll(omask);
+                        omask &= omask - 1;
+                        int qx[5], qy[5];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
+                        const int qn = __builtin_amdgcn_readlane(nv, l);
+                        if (qn == 3) { qx[3] = qx[0]; qy[3] = qy[0]; qx[4] = qx[0]; qy[4] = qy[0]; }
+                        else { qx[4] = qx[0]; qy[4] = qy[0]; }
+                        fill_poly(fb, cw, qx, qy, qn + 1, 1, lane);
+                    }
+                }
+                // boxes in draw order
+                bool hit = lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
+                if (lane == 2 && veh_hidden) hit = false;
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int qid = __builtin_amdgcn_readlane(bid, l);
+                    const int qslot = __builtin_amdgcn_readlane(bslot, l);
+                    const int qflags = __builtin_amdgcn_readlane(h_flags, l);
+                    if (qid == 2 || !(qflags & F_SIMPLE)) {
+                        const int* hdr = scr + OFF_HDR + qslot * HDR_INTS;
+                        int qx[5], qy[5];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { qx[k] = hdr[H_VX + k]; qy[k] = hdr[H_VY + k]; }
+                        qx[4] = qx[0]; qy[4] = qy[0];
+                        if (qid == 2) {                                      // width=1: lines(closed=True)
+#pragma unroll
+                            for (int k = 1; k < 5; k++) line(fb, cw, 2, qx[k - 1], qy[k - 1], qx[k], qy[k], lane);
+                            line(fb, cw, 2, qx[4], qy[4], qx[0], qy[0], lane);
+                        } else {
+                            fill_poly(fb, cw, qx, qy, 5, qid, lane);         // never for a car-shaped box; kept for exactness
+                        }
+                        continue;
+                    }
+                    const int qminy = __builtin_amdgcn_readlane(h_miny, l), qnrows = __builtin_amdgcn_readlane(h_nrows, l);
+                    const uint32_t* tab = tabs + (qslot - 1) * TAB_ROWS;
+                    // a trajectory box only needs the part its successor (drawn next, overlapping ~90 %) leaves visible
+                    const bool has_next = l >= 3 && mask && __builtin_ctzll(mask) == l + 1 && (__builtin_amdgcn_readlane(h_flags, l + 1) & F_SIMPLE);
+                    int nminy = 0, nnrows = 0;
+                    const uint32_t* ntab = tab;
+                    if (has_next) {
+                        nminy = __builtin_amdgcn_readlane(h_miny, l + 1); nnrows = __builtin_amdgcn_readlane(h_nrows, l + 1);
+                        ntab = tabs + (__builtin_amdgcn_readlane(bslot, l + 1) - 1) * TAB_ROWS;
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < 2; ps++) {
+                        const int y = cw.y0 + WAVE * ps + lane;
+                        if (qminy + qnrows - 1 < cw.y0 + WAVE * ps || qminy > min(cw.y1, cw.y0 + WAVE * ps + WAVE - 1)) continue;   // uniform
+                        int xa = 1, xb = 0, sa = INT_MAX, sb = INT_MIN;
+                        if (y <= cw.y1) {
+                            table_span(tab, qminy, qnrows, y, cw.x0, cw.x1, xa, xb);
+                            if (has_next) {
+                                table_span(ntab, nminy, nnrows, y, cw.x0, cw.x1, sa, sb);
+                                if (sa > sb) { sa = INT_MAX; sb = INT_MIN; }
+                            }
+                        }
+                        uint8_t* row = fb + (WAVE * ps + lane) * FB_STRIDE - cw.x0;
+                        uint8_t* dummy = fb + FB_BYTES + lane;
+                        if (has_next) {                                      // left and right of the successor's span
+                            fill_span(row, dummy, qid, xa, min(xb, sa - 1));
+                            fill_span(row, dummy, qid, sa > sb ? xb + 1 : max(xa, sb + 1), xb);
+                        } else {
+                            fill_span(row, dummy, qid, xa, xb);
+                        }
+                    }
+                }
+            }
+            wsync();
+            if (pass == 0) bg_id = fb[0];
+        }
+
+        // ---- gather: lane = 4 consecutive outputs of one tile row; cv2.resize reads crop pixels (4u+1|2, 4v+1|2) -----
+        if (p.debug & 8) continue;
+        const int v = TILE_OUT * ty + (lane >> 2);
+        const int u0 = TILE_OUT * tx + 4 * (lane & 3);
+        // Branch-free: every sample reads SOME window byte (clamped address) and the result is selected afterwards.
+        // empty window (whole tile outside the surface): nothing is read from it, make the clamps well defined
+        const int wx1 = max(w.x1, w.x0), wy1 = max(w.y1, w.y0);
+        int dxb, dyb;
+        map_raw(m, 4 * u0 + 1, 4 * v + 1, dxb, dyb);                          // first sample of this lane
+        const bool row_out0 = (unsigned)(4 * v + 1 + m.roy) >= (unsigned)WIN, row_out1 = (unsigned)(4 * v + 2 + m.roy) >= (unsigned)WIN;
+        uint32_t ids[4] = {0, 0, 0, 0};                                       // 4 palette ids per output, one byte each
+        const int dxx4 = m.dxx << 2, dyx4 = m.dyx << 2;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int ax_ = 4 * jj + (s & 1), ay_ = s >> 1;               // crop offset from the lane's first sample
+                const int dx = dxb + ((s & 1) ? m.dxx : 0) + (ay_ ? m.dxy : 0), dy = dyb + ((s & 1) ? m.dyx : 0) + (ay_ ? m.dyy : 0);
+                const bool white = (unsigned)(4 * u0 + 1 + ax_ + m.rox) >= (unsigned)WIN || (ay_ ? row_out1 : row_out0);
+                const bool outside = (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
+                const int sx = min(max(dx >> 16, w.x0), wx1), sy = min(max(dy >> 16, w.y0), wy1);
+                int id = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0];
+                id = outside ? bg_id : id;                                    // rotate()'s bgcolor
+                id = white ? 0 : id;                                          // observation.fill(BG_COLOR) -> black later
+                ids[jj] |= (uint32_t)id << (8 * s);
+            }
+            dxb += dxx4; dyb += dyx4;                                         // next output: 4 crop pixels to the right
+        }
+        uint32_t out_r = 0, out_g = 0, out_b = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const uint32_t sum = pal[ids[jj] & 255] + pal[(ids[jj] >> 8) & 255] + pal[(ids[jj] >> 16) & 255] + pal[ids[jj] >> 24];
+            const uint32_t r = ((sum & 1023) + 2) >> 2, g = (((sum >> 10) & 1023) + 2) >> 2, bl = (((sum >> 20) & 1023) + 2) >> 2;
+            out_r |= r << (8 * jj); out_g |= g << (8 * jj); out_b |= bl << (8 * jj);
+        }
+        uint8_t* img = p.img + (size_t)scene * 3 * BEV_IMG * BEV_IMG + v * BEV_IMG + u0;
+        *(uint32_t*)(img) = out_r;
+        *(uint32_t*)(img + BEV_IMG * BEV_IMG) = out_g;
+        *(uint32_t*)(img + 2 * BEV_IMG * BEV_IMG) = out_b;
     }
-    uint8_t* img = p.img + (size_t)scene * 3 * BEV_IMG * BEV_IMG + v * BEV_IMG + u0;
-    *(uint32_t*)(img) = out_r;
-    *(uint32_t*)(img + BEV_IMG * BEV_IMG) = out_g;
-    *(uint32_t*)(img + 2 * BEV_IMG * BEV_IMG) = out_b;
 }
 
 }  // namespace
 
-size_t bev_lds_bytes() { return FB_BYTES + 8 + 32 * sizeof(uint32_t); }
+size_t bev_lds_bytes() { return FB_BYTES + 72 + 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t); }
 
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer) {
-    const int groups = (p.n + 7) / 8;
-    const dim3 grid(groups * 8 * TILES * TILES), block(WAVE);
+    if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
+    hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
+    if (timer) timer->end(stream);
+    const dim3 grid(p.n), block(WAVE);
     if (timer) timer->begin(HOPE_K_IMAGE, stream);
     hipLaunchKernelGGL(k_bev_image, grid, block, bev_lds_bytes(), stream, p);
     if (timer) timer->end(stream);

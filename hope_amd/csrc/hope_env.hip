@@ -48,6 +48,8 @@ struct hope_env {
     double* kin = nullptr;
     double* traj = nullptr;        // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory
     int32_t* traj_len = nullptr;   // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
+    int32_t* traj_valid = nullptr; // HOPE_F_IMAGE: [n] entries below this index have span tables in bev_scratch
+    int* bev_scratch = nullptr;    // HOPE_F_IMAGE: [n][BEV_SCENE_INTS]
     // per tile class (0: n_obst <= SMALL_TILE, 1: larger) dense scene lists; classes are static between set_scenes calls
     int32_t* cls_list[2] = {nullptr, nullptr};
     int cls_count[2] = {0, 0};
@@ -61,8 +63,8 @@ struct hope_env {
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0};
-    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0};
+    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0};
+    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0};
 };
 
 static hipEvent_t get_event(hope_env* h) {
@@ -111,7 +113,7 @@ namespace {
 // one thread per uploaded scene: constants, derived dest box, episode state reset
 __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* start, const double* dest,
                                    const double* bbox, const int32_t* nob, double* scene_c, double* state,
-                                   int32_t* tstep, int32_t* n_obst, double* traj, int32_t* traj_len) {
+                                   int32_t* tstep, int32_t* n_obst, double* traj, int32_t* traj_len, int32_t* traj_valid) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int s = ids[k];
@@ -140,6 +142,7 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
         double* tr = traj + (size_t)s * BEV_TRAJ_LEN * 3;
         tr[0] = st[0]; tr[1] = st[1]; tr[2] = st[2];
         traj_len[s] = 1;
+        traj_valid[s] = 0;
     }
 }
 
@@ -166,7 +169,7 @@ __global__ void k_debug_math(int fn, int n, const double* a, const double* b, do
 
 // episode restart: pose = start, t = 0, accum = 0 for masked scenes
 __global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, double* state, int32_t* tstep, double* traj,
-                          int32_t* traj_len) {
+                          int32_t* traj_len, int32_t* traj_valid) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n || !mask[s]) return;
     const double* c = scene_c + (size_t)s * SC_WORDS;
@@ -177,6 +180,7 @@ __global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, dou
         double* tr = traj + (size_t)s * BEV_TRAJ_LEN * 3;
         tr[0] = st[0]; tr[1] = st[1]; tr[2] = st[2];
         traj_len[s] = 1;
+        traj_valid[s] = 0;
     }
 }
 
@@ -250,11 +254,15 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     if (flags & HOPE_F_IMAGE) {
         ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
         ALLOC(h->traj_len, N * sizeof(int32_t));
+        ALLOC(h->traj_valid, N * sizeof(int32_t));
+        ALLOC(h->bev_scratch, N * BEV_SCENE_INTS * sizeof(int));
     }
 #undef ALLOC
     if (h->traj) {
         HIPCHK(hipMemset(h->traj, 0, N * BEV_TRAJ_LEN * 3 * sizeof(double)));
         HIPCHK(hipMemset(h->traj_len, 0, N * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->traj_valid, 0, N * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->bev_scratch, 0, N * BEV_SCENE_INTS * sizeof(int)));
     }
     HIPCHK(hipMemset(h->n_obst, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->scene_c, 0, N * SC_WORDS * sizeof(double)));
@@ -278,7 +286,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->stage, h->traj, h->traj_len};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -347,7 +355,7 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     if (verts) HIPCHK(hipMemcpy(sp + o_verts, verts, tile * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_scene_consts, dim3((n + 127) / 128), dim3(128), 0, 0, n, (const int32_t*)(sp + o_ids),
                        (const double*)(sp + o_start), (const double*)(sp + o_dest), (const double*)(sp + o_bbox),
-                       (const int32_t*)(sp + o_nob), h->scene_c, h->state, h->tstep, h->n_obst, h->traj, h->traj_len);
+                       (const int32_t*)(sp + o_nob), h->scene_c, h->state, h->tstep, h->n_obst, h->traj, h->traj_len, h->traj_valid);
     if (verts)
         hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
                            (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), h->verts, h->max_obst);
@@ -385,7 +393,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
     p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
     p.actions = actions; p.active = active; p.kin = h->kin;
-    p.traj = h->traj; p.traj_len = h->traj_len;
+    p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
     if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, 2 * sizeof(int32_t), s));
@@ -441,9 +449,10 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (stages & HOPE_STAGE_IMG) {
         BevParams b;
         b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
-        b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.img = out->img;
+        b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.traj_valid = h->traj_valid; b.scratch = h->bev_scratch; b.img = out->img;
         // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
         b.active = active;
+        b.debug = (stages >> 12) & 0xF;
         HIPCHK(launch_bev_image(b, s, tm));
     }
     if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
@@ -455,7 +464,7 @@ int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_restart: hope_env_set_scenes has not been called");
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_restart, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->n, mask, h->scene_c,
-                       h->state, h->tstep, h->traj, h->traj_len);
+                       h->state, h->tstep, h->traj, h->traj_len, h->traj_valid);
     HIPCHK(hipGetLastError());
     return HOPE_OK;
 }

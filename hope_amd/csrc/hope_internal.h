@@ -36,6 +36,7 @@ struct RsParams {
 // bird's-eye image observation (hope_bev.hip)
 constexpr int BEV_IMG = HOPE_IMG_SIZE;
 constexpr int BEV_TRAJ_LEN = HOPE_TRAJ_RENDER_LEN;
+constexpr int BEV_SCENE_INTS = 16 + (3 + BEV_TRAJ_LEN) * 16 + (2 + BEV_TRAJ_LEN) * 64;   // k_bev_prep's per-scene scratch
 struct BevParams {
     int n, max_obst;
     const double* verts;      // [n][max_obst][4][2] world frame
@@ -44,8 +45,11 @@ struct BevParams {
     const double* state;      // [n][ST_WORDS]
     const double* traj;       // [n][BEV_TRAJ_LEN][3] ring of vehicle.trajectory: entry e lives in slot e % BEV_TRAJ_LEN
     const int32_t* traj_len;  // [n] len(vehicle.trajectory)
+    int32_t* traj_valid;      // [n] trajectory entries below this index already have their span table
+    int* scratch;             // [n][BEV_SCENE_INTS] map + box headers + span tables (k_bev_prep -> k_bev_image)
     const uint8_t* active;    // [n] or null
     uint8_t* img;             // [n][3][64][64]
+    int debug;                // internal profiling switches (stages bits 0x1000.. >> 12)
 };
 
 // optional per-launch profiling hook: begin(kind) / end() bracket ONE kernel launch

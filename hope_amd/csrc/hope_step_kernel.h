@@ -35,6 +35,7 @@ struct StepParams {
     double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
     double* traj;             // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory (entry e in slot e % 20), else null
     int32_t* traj_len;        // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
+    int32_t* traj_valid;      // HOPE_F_IMAGE: [n] span-table watermark of the image kernels (0 after a reset)
     const uint8_t* active;    // [n] or null
     const double* tab;        // prefix-max mask table [NL][NITER][NACT]
     const double* pmax;       // [NL] max over (a,k) of tab
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             // vehicle.py:144,158); a step blocked at its first sub-step adds nothing; reset leaves [start]
             double* tr = p.traj + (size_t)scene * 60;
             int tl = turnover ? 0 : p.traj_len[scene];
+            if (turnover) p.traj_valid[scene] = 0;
             if (turnover || moved) {
                 double* e = tr + 3 * (tl % 20);
                 e[0] = x; e[1] = y; e[2] = h;
