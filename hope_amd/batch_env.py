@@ -77,7 +77,7 @@ class ParkingBatch:
 
     def reset_obs(self, active=None, stages=L.STAGE_ALL):
         """the action-less step of CarParking.reset (car_parking_base.py:138)."""
-        if self.image and stages == L.STAGE_ALL:
+        if self.image and (stages & L.STAGE_ALL) == L.STAGE_ALL:
             stages |= L.STAGE_IMG
         ap = C.c_void_p(active.data_ptr()) if active is not None else None
         L.check(self.lib.hope_env_reset_obs(self.h, ap, stages, C.byref(self._out), self._stream()),
@@ -87,7 +87,7 @@ class ParkingBatch:
     def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False):
         """actions: [N, 2] (steer, speed) in [-1, 1] on this device.  auto_reset=True: finished scenes restart inside
         the step (their lidar / action_mask / target are the new episode's first observation)."""
-        if self.image and stages == L.STAGE_ALL:
+        if self.image and (stages & L.STAGE_ALL) == L.STAGE_ALL:
             stages |= L.STAGE_IMG                    # USE_IMG (configs.py:100): the image is part of the observation
         if auto_reset:
             stages |= L.AUTO_RESET

@@ -8,9 +8,11 @@
 so that the reference's callers (train_HOPE_sac.py:114-118,183-213; train_HOPE_ppo.py; eval_utils.py:16-84)
 can drive it.  Old-gym API: reset -> obs ; step -> (obs, reward, done, info).
 
-Not provided (out of this path's scope): the pygame/cv2 image observation
-(`obs['img']` is None and `use_img_observation` defaults to False) and `get_map_level` bucketing
-(`map.map_level` reports the generator level, 'dlp' for DLP cases).
+`use_img_observation=True` adds the bird's-eye image obs['img'] ((64, 64, 3) float64 in [0, 1] from the raw env,
+(3, 64, 64) after the wrapper; rendered on the GPU by k_bev_image).  It defaults to False here
+(the reference's USE_IMG default is True, configs.py:100) because its pixel parity with pygame / OpenCV is unpinned
+(oracle/hope_oracle_img.c).  Not provided: `get_map_level` bucketing (`map.map_level` reports the generator
+level, 'dlp' for DLP cases) and the pygame window (`render` returns None).
 """
 import math
 from collections import OrderedDict
@@ -133,20 +135,17 @@ class CarParking:
                  level='Normal'):
         import torch
         from .batch_env import ParkingBatch
-        if use_img_observation:
-            raise NotImplementedError("obs['img'] (pygame/cv2 BEV raster) is outside this library's scope; "
-                                      "construct with use_img_observation=False")
         self.verbose, self.fps = verbose, fps
         self.render_mode = 'human' if render_mode is None else render_mode
         self.use_lidar_observation, self.use_img_observation, self.use_action_mask = \
-            use_lidar_observation, False, use_action_mask
+            use_lidar_observation, bool(use_img_observation), use_action_mask
         self.level = level
         self.t = 0.0
         self.tgt_repr_size = 5
         self.rng = np.random.default_rng(seed)
         self._torch = torch
         self._batch = ParkingBatch(1, max_obstacles, device=device, obs_dtype=torch.float64,
-                                   action_dtype=torch.float64)
+                                   action_dtype=torch.float64, image=self.use_img_observation)
         self._pool = None
         self._dlp_path = None
         self.map = _Map(level)
@@ -156,6 +155,9 @@ class CarParking:
         self.observation_space = {}
         if use_action_mask:
             self.observation_space['action_mask'] = Box(0, 1, shape=(N_DISCRETE_ACTION,), dtype=np.float64)
+        if self.use_img_observation:                       # car_parking_base.py:87-93
+            self.observation_space['img'] = Box(0, 255, shape=(L.IMG_SIZE, L.IMG_SIZE, L.IMG_CHANNELS), dtype=np.uint8)
+            self.raw_img_shape = (256, 256, 3)
         if use_lidar_observation:
             self.observation_space['lidar'] = Box(0, LIDAR_RANGE, shape=(LIDAR_NUM,), dtype=np.float64)
         self.observation_space['target'] = Box(np.array([0, -1, -1, -1, -1]), np.array([MAX_DIST_TO_DEST, 1, 1, 1, 1]),
@@ -216,6 +218,8 @@ class CarParking:
         self.vehicle.box = self.vehicle.state.create_box()
         self.vehicle.trajectory.append(self.vehicle.state)
         observation = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
+        if self.use_img_observation:                       # processed_img / 255.0, (W, H, C)  observation_processor.py:14
+            observation['img'] = b.img[0].permute(1, 2, 0).cpu().numpy().astype(np.float64) / 255.0
         if self.use_lidar_observation:
             observation['lidar'] = b.lidar[0].cpu().numpy()
         if self.use_action_mask:
@@ -281,6 +285,9 @@ class CarParkingWrapper:                                  # :58-85 (gym.Wrapper 
         self.env = env
         self.reward_func, self.action_func, self.obs_func = reward_func, action_func, observation_func
         self.observation_shape = {k: env.observation_space[k].shape for k in env.observation_space}
+        if 'img' in self.observation_shape:                # env_wrapper.py:69-71
+            w, h, c = self.observation_shape['img']
+            self.observation_shape['img'] = (c, w, h)
 
     def __getattr__(self, name):
         if name.startswith('_'):

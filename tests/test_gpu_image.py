@@ -174,3 +174,33 @@ def test_image_stage_needs_the_image_flag():
     with pytest.raises(L.HopeError):
         env.reset_obs(stages=L.STAGE_ALL | L.STAGE_IMG)
     env.close()
+
+
+def test_dropin_env_returns_the_image_like_the_reference():
+    """CarParking(use_img_observation=True): obs['img'] is (64, 64, 3) float64 in [0, 1] from the raw env and (3, 64, 64)
+    after CarParkingWrapper (env_wrapper.py:52-55,68-71); values = oracle image / 255."""
+    from hope_amd.env import CarParking, CarParkingWrapper
+    from hope_amd.scenes import SceneSource, pack_scenes
+    from oracle import oracle as O
+    scene = SceneSource(levels=('Normal',), seed=23).draw()
+    raw = CarParking(render_mode='rgb_array', fps=100, verbose=False, use_img_observation=True, max_obstacles=32)
+    env = CarParkingWrapper(raw)
+    assert env.observation_shape['img'] == (3, 64, 64) and raw.observation_space['img'].shape == (64, 64, 3)
+    orc = O.BatchOracle(1, 32)
+    start, dest, bbox, verts, nob, nvert = pack_scenes([scene], 32)
+    orc.set_scenes([0], start, dest, bbox, verts, nvert, nob)
+    t = raw._batch.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    obs = raw.reset_to_scene(scene)
+    orc.reset_obs()
+    assert obs['img'].shape == (64, 64, 3) and obs['img'].dtype == np.float64
+    assert np.array_equal(obs['img'], orc.image()[0].transpose(1, 2, 0) / 255.0)
+    rng = np.random.default_rng(2)
+    for it in range(8):
+        a = rng.uniform(-1, 1, 2)
+        obs, reward, done, info = env.step(a)
+        orc.step(a[None])
+        assert list(obs.keys()) == ['img', 'lidar', 'target', 'action_mask'] and obs['img'].shape == (3, 64, 64)
+        assert np.array_equal(obs['img'], orc.image()[0] / 255.0)
+        assert 0.0 <= obs['img'].min() and obs['img'].max() <= 1.0
+    env.close()

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Reduces the rocprofv3 output directories written by tools/collect_profiles.sh to the small files kept under
+profiles/: kernel statistics (csv + top lines), per-dispatch PMC values of the hope kernels, and the per-launch
+memory-side traffic (tools/pmc_traffic.py)."""
+import csv
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep')
+
+
+def find(d, pat):
+    hits = glob.glob(os.path.join(d, '**', pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def kernel_stats(src_dir, out_csv, out_top):
+    f = find(src_dir, '*kernel_stats.csv')
+    if not f:
+        return
+    rows = list(csv.DictReader(open(f)))
+    with open(out_csv, 'w') as g:
+        w = csv.DictWriter(g, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+        w.writeheader()
+        for r in rows[:24]:
+            w.writerow(r)
+    with open(out_top, 'w') as g:
+        for r in rows[:10]:
+            g.write(f"{r['Name'][:70]:70s} calls={int(r['Calls']):4d} avg_ns={float(r['AverageNs']):12.0f} "
+                    f"max_ns={int(float(r['MaxNs'])):9d} pct={r['Percentage']}\n")
+
+
+def pmc(src_dir, counter, out_csv):
+    f = find(src_dir, '*counter_collection.csv')
+    if not f:
+        return None
+    with open(out_csv, 'w') as g:
+        g.write('Dispatch_Id,Kernel,Grid_Size,LDS_Block_Size,VGPR_Count,Counter_Name,Counter_Value_KiB\n')
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            k = next((k for k in KERNELS if k in r['Kernel_Name']), None)
+            if k:
+                g.write(f"{r['Dispatch_Id']},{k},{r['Grid_Size']},{r.get('LDS_Block_Size', '')},{r.get('VGPR_Count', '')},"
+                        f"{counter},{float(r['Counter_Value']):.6f}\n")
+    return f
+
+
+def main():
+    o, tag = sys.argv[1], sys.argv[2]
+    kernel_stats(os.path.join(o, 'kstats'), os.path.join(o, f'{tag}_kernel_stats.csv'), os.path.join(o, f'{tag}_kernel_stats_top.txt'))
+    kernel_stats(os.path.join(o, 'kstats_img'), os.path.join(o, f'{tag}_kernel_stats_image.csv'),
+                 os.path.join(o, f'{tag}_kernel_stats_image_top.txt'))
+    for v in ('', '_image'):
+        raw = {}
+        for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+            raw[c] = pmc(os.path.join(o, f'pmc{v}_{c}'), c, os.path.join(o, f'{tag}_pmc{v}_{c.lower()}.csv'))
+        if raw['FETCH_SIZE'] and raw['WRITE_SIZE']:
+            subprocess.check_call([sys.executable, os.path.join(HERE, 'pmc_traffic.py'), raw['FETCH_SIZE'], raw['WRITE_SIZE'],
+                                   os.path.join(o, f'{tag}_pmc_traffic{v}.json')], stdout=subprocess.DEVNULL)
+
+
+if __name__ == '__main__':
+    main()
