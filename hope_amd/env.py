@@ -11,7 +11,7 @@ can drive it.  Old-gym API: reset -> obs ; step -> (obs, reward, done, info).
 `use_img_observation=True` adds the bird's-eye image obs['img'] ((64, 64, 3) float64 in [0, 1] from the raw env,
 (3, 64, 64) after the wrapper; rendered on the GPU by k_bev_image).  It defaults to False here
 (the reference's USE_IMG default is True, configs.py:100) because its pixel parity with pygame / OpenCV is unpinned
-(oracle/hope_oracle_img.c).  Not provided: `get_map_level` bucketing (`map.map_level` reports the generator
+(DESIGN.md §3).  Not provided: `get_map_level` bucketing (`map.map_level` reports the generator
 level, 'dlp' for DLP cases) and the pygame window (`render` returns None).
 """
 import math
