@@ -12,8 +12,9 @@
 //      new this step (vehicle, newest trajectory entry; dest / start once per episode), its integer pixel corners and
 //      its scan-line spans under pygame's rule (lane = row).  A box keeps its spans for the 20 steps it stays in the
 //      trajectory ring, so they live in a per-scene table in HBM (7 KB/scene), indexed like the ring.
-//   k_bev_image (wave per scene, looping over its 16 tiles of 16 x 16 outputs so that the map, the box headers, the span
-//      tables and the obstacle pixels are fetched once and the waves live long enough to hide latency): the world pixels
+//   k_bev_image (4 waves per scene sharing the span tables, each looping over 4 of the 16 tiles of 16 x 16 outputs, so
+//      that the map, the box headers, the span tables and the obstacle pixels are fetched once per wave and the waves
+//      live long enough to hide latency): the world pixels
 //      a tile can touch form a window of at most 90 x 90 px, kept as one byte per pixel (palette id) in LDS.  Obstacles are converted to
 //      integer pixels lane-parallel (lane = obstacle), culled against the window with a ballot and rasterised with
 //      pygame's exact scan-line rule (lane = row; floor / ceil on alternate intersections; horizontal border pass);
@@ -41,6 +42,8 @@ constexpr int TILES = BEV_IMG / TILE_OUT;      // 4 x 4 tiles per scene
 constexpr int FB_DIM = 90;                     // window side: 61 crop px * sqrt(2) + rounding
 constexpr int FB_STRIDE = 92;                  // bytes per window row: 23 dwords (odd -> lane-per-row is conflict-free)
 constexpr int FB_BYTES = FB_DIM * FB_STRIDE;
+constexpr int FB_SLOT = (FB_BYTES + 72 + 15) / 16 * 16;   // window + 64 dummy bytes, 16-byte aligned
+constexpr int BEV_WAVES = 4;                   // waves per workgroup = per scene (they share the span tables)
 constexpr double RENDER_K = 12.0;              // K  configs.py:103
 constexpr int SRC_MAX = (WIN << 16) - 1;
 
@@ -342,12 +345,28 @@ __device__ __forceinline__ void table_span(const uint32_t* tab, int miny, int nr
     b = min((int)(sp >> 16) - 1, x_hi);
 }
 
-__global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
+// Ordering of one wave's own LDS traffic: the LDS unit executes a wave's instructions in order, so only the compiler
+// has to be kept from moving accesses across the phase boundaries (the workgroup's waves work on different windows)
+__device__ __forceinline__ void wave_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// wave 0: 5 1 4 0, wave 1: 6 2 7 3, wave 2: 9 8 13 12, wave 3: 10 11 14 15 -- every wave gets one of the 4 centre tiles
+// (where the trajectory boxes are), two edge tiles and one corner (one nibble per tile, first tile lowest)
+__device__ __forceinline__ int tile_of(int wave, int it) {
+    const unsigned t = wave == 0 ? 0x0415u : (wave == 1 ? 0x3726u : (wave == 2 ? 0xcd89u : 0xfebau));
+    return (t >> (4 * it)) & 15;
+}
+
+__global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
+    // LDS: palette (128 B) | span tables shared by the workgroup's waves (5.6 KB) | one window per wave (8.3 KB + 72)
     extern __shared__ __align__(16) uint8_t lds_raw[];
-    uint8_t* fb = lds_raw;
-    uint32_t* pal = (uint32_t*)(lds_raw + FB_BYTES + 72);                  // 64 dummy bytes (fill_span) after the window
+    uint32_t* pal = (uint32_t*)lds_raw;
     uint32_t* tabs = pal + 32;                                               // [N_TAB][TAB_ROWS]
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    uint8_t* fb = lds_raw + 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + wave * FB_SLOT;   // + 64 dummy bytes (fill_span)
     const int scene = scene_of_block(blockIdx.x, p.n);
     if (scene >= p.n) return;
     if (p.active && !p.active[scene]) return;
@@ -367,9 +386,10 @@ __global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
     const int n_box = (p.debug & 4) ? 0 : 3 + (traj_len > 1 ? m_traj : 0);
     {
         const uint4* src = (const uint4*)(scr + OFF_TAB);
-        for (int i = lane; i < N_TAB * TAB_ROWS / 4; i += WAVE) ((uint4*)tabs)[i] = src[i];
+        for (int i = threadIdx.x; i < N_TAB * TAB_ROWS / 4; i += BEV_WAVES * WAVE) ((uint4*)tabs)[i] = src[i];
     }
-    if (lane < 25) pal[lane] = palette(lane);
+    if (threadIdx.x < 25) pal[threadIdx.x] = palette(threadIdx.x);
+    __syncthreads();                                                         // the only workgroup-wide barrier
     // lane = box in draw order: start outline, dest, vehicle, trajectory oldest -> newest (:307-320)
     int bslot = 0, bid = 0, h_miny = 0, h_nrows = 0, h_flags = 0, h_minx = 0, h_maxx = 0, h_maxy = 0;
     if (lane < n_box) {
@@ -400,7 +420,8 @@ __global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
     }
     const int n_chunks = (n_obst + WAVE - 1) / WAVE;
 
-    for (int tile = 0; tile < TILES * TILES; tile++) {
+    for (int it = 0; it < TILES * TILES / BEV_WAVES; it++) {
+        const int tile = tile_of(wave, it);
         const int tx = tile & 3, ty = tile >> 2;
         // ---- world window of this tile: the map is affine, so the extremes are at the corner samples ----------------
         Window w;
@@ -422,12 +443,12 @@ __global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
         // pass 0 (rare): the rotate() background colour is the surface's top-left pixel -- rasterise a 1 x 1 window there
         for (int pass = need_bg ? 0 : 1; pass < 2; pass++) {
             const Window cw = pass == 0 ? Window{0, 0, 0, 0} : w;
-            wsync();                                                         // the previous tile's gather is done
+            wave_phase();                                                    // the previous tile's gather is done
             {   // surface.fill(BG_COLOR)
                 uint4* f4 = (uint4*)fb;
                 for (int i = lane; i < (FB_BYTES + 15) / 16; i += WAVE) f4[i] = make_uint4(0, 0, 0, 0);
             }
-            wsync();
+            wave_phase();
             const bool live = cw.x0 <= cw.x1 && cw.y0 <= cw.y1 && !(p.debug & 1);
             if (live) {
                 for (int c = 0; c < n_chunks; c++) {
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
                     }
                 }
             }
-            wsync();
+            wave_phase();
             if (pass == 0) bg_id = fb[0];
         }
 
@@ -569,13 +590,13 @@ __global__ __launch_bounds__(64) void k_bev_image(BevParams p) {
 
 }  // namespace
 
-size_t bev_lds_bytes() { return FB_BYTES + 72 + 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t); }
+size_t bev_lds_bytes() { return 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * FB_SLOT; }
 
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer) {
     if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
     hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
-    const dim3 grid(p.n), block(WAVE);
+    const dim3 grid(p.n), block(BEV_WAVES * WAVE);
     if (timer) timer->begin(HOPE_K_IMAGE, stream);
     hipLaunchKernelGGL(k_bev_image, grid, block, bev_lds_bytes(), stream, p);
     if (timer) timer->end(stream);
