@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--unique', type=int, default=2048, help='distinct generated scenes (tiled to --scenes)')
     ap.add_argument('--image', action='store_true', help="also render obs['img'] (USE_IMG, configs.py:100) every step")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-scenes', type=int, default=192)
+    ap.add_argument('--cpu-scenes', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=12)
     ap.add_argument('--seed', type=int, default=42)
     return ap.parse_args()

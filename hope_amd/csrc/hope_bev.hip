@@ -519,19 +519,17 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                         nminy = __builtin_amdgcn_readlane(h_miny, l + 1); nnrows = __builtin_amdgcn_readlane(h_nrows, l + 1);
                         ntab = tabs + (__builtin_amdgcn_readlane(bslot, l + 1) - 1) * TAB_ROWS;
                     }
-#pragma unroll
-                    for (int ps = 0; ps < 2; ps++) {
-                        const int y = cw.y0 + WAVE * ps + lane;
-                        if (qminy + qnrows - 1 < cw.y0 + WAVE * ps || qminy > min(cw.y1, cw.y0 + WAVE * ps + WAVE - 1)) continue;   // uniform
+                    {   // lane = row of the BOX (at most 64): one pass whatever the window rows it touches
+                        const int y = qminy + lane;
                         int xa = 1, xb = 0, sa = INT_MAX, sb = INT_MIN;
-                        if (y <= cw.y1) {
+                        if (lane < qnrows && y >= cw.y0 && y <= cw.y1) {
                             table_span(tab, qminy, qnrows, y, cw.x0, cw.x1, xa, xb);
                             if (has_next) {
                                 table_span(ntab, nminy, nnrows, y, cw.x0, cw.x1, sa, sb);
                                 if (sa > sb) { sa = INT_MAX; sb = INT_MIN; }
                             }
                         }
-                        uint8_t* row = fb + (WAVE * ps + lane) * FB_STRIDE - cw.x0;
+                        uint8_t* row = fb + __mul24(y - cw.y0, FB_STRIDE) - cw.x0;
                         uint8_t* dummy = fb + FB_BYTES + lane;
                         if (has_next) {                                      // left and right of the successor's span
                             fill_span(row, dummy, qid, xa, min(xb, sa - 1));
