@@ -36,6 +36,11 @@ constexpr int NCAND = 46;
 
 enum { TS = 0, TL = 1, TR = 2 };
 
+// lane l's value of a wave-uniformly indexed double (l must be wave-uniform)
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 __device__ __forceinline__ double py_mod(double v, double w) {   // Python float %
     double m = hm_fmod(v, w);
     if (m != 0) { if ((w < 0) != (m < 0)) m += w; } else m = copysign(0.0, w);
@@ -438,15 +443,27 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
         code = pack_types(t0, t1, t2_, t3, t4, n);
     }
 
-    // ---- set_path (:57-76) replayed in call order ---------------------------------------------------
-    unsigned long long okmask = __ballot(ok);
-    unsigned long long kept = 0;
+    // ---- set_path (:57-76) -------------------------------------------------------------------------------
+    // kept[c] = ok[c] and no EARLIER KEPT path with the same word has sum(old - new) <= 0.01 (:63-66) and L < 1000 (:70).
+    // Only candidates that share their word with another candidate can interact, so every lane first computes its own
+    // L (parallel) and whether it has such a twin; the order-dependent replay then runs over the twins only.
     double myL = 0;
-    for (int c = 0; c < NCAND; c++) {
-        if (!((okmask >> c) & 1)) continue;
-        const int code_c = __shfl(code, c);
-        const int n_c = __shfl(wn, c);
-        const double c0 = __shfl(l0, c), c1 = __shfl(l1, c), c2 = __shfl(l2, c), c3 = __shfl(l3, c), c4 = __shfl(l4, c);
+    myL = myL + fabs(l0); myL = myL + fabs(l1); myL = myL + fabs(l2);
+    if (wn > 3) myL = myL + fabs(l3);
+    if (wn > 4) myL = myL + fabs(l4);
+    const unsigned long long okmask = __ballot(ok);
+    bool twin = false;
+    for (unsigned long long mm = okmask; mm; mm &= mm - 1) {
+        const int c = __builtin_ctzll(mm);
+        twin = twin || (c != lane && code == __builtin_amdgcn_readlane(code, c));
+    }
+    const unsigned long long twins = __ballot(ok && twin);
+    unsigned long long kept = __ballot(ok && !twin && !(myL >= MAX_LENGTH));
+    for (unsigned long long mm = twins; mm; mm &= mm - 1) {            // call order
+        const int c = __builtin_ctzll(mm);
+        const int code_c = __builtin_amdgcn_readlane(code, c);
+        const int n_c = __builtin_amdgcn_readlane(wn, c);
+        const double c0 = readlane_d(l0, c), c1 = readlane_d(l1, c), c2 = readlane_d(l2, c), c3 = readlane_d(l3, c), c4 = readlane_d(l4, c);
         bool dup = false;
         if (((kept >> lane) & 1) && code == code_c) {
             double s = 0;                                  // sum([x - y ...]) left to right (:65)
@@ -456,13 +473,8 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
             dup = s <= 0.01;
         }
         if (__any(dup)) continue;
-        double L = 0;
-        L = L + fabs(c0); L = L + fabs(c1); L = L + fabs(c2);
-        if (n_c > 3) L = L + fabs(c3);
-        if (n_c > 4) L = L + fabs(c4);
-        if (L >= MAX_LENGTH) continue;                     // :70
+        if (readlane_d(myL, c) >= MAX_LENGTH) continue;    // :70
         kept |= 1ull << c;
-        if (lane == c) myL = L;
     }
     const int n_paths = __popcll(kept);
     if (lane == 0) p.rs_nwords[slot] = n_paths;
@@ -470,44 +482,58 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 
     // ---- path.L / maxc (calc_all_paths :52) and heapdict pop order ----------------------------------
     const double myLm = myL / MAXC;
-    if ((kept >> lane) & 1) scr[RSA_LM + lane] = myLm;
-    __syncthreads();
-    if (lane == 0) {
-        double* pr = scr + RSA_PR;
-        int hn = 0;
-        for (int c = 0; c < NCAND; c++) {                 // costQueue[path] = path.L in path order (:432-433)
-            if (!((kept >> c) & 1)) continue;
-            int i = hn++;
-            pr[i] = scr[RSA_LM + c]; hid[i] = c;
-            while (i) {                                   // _decrease_key: swap unless parent < child
-                int parent = (i - 1) >> 1;
-                if (pr[parent] < pr[i]) break;
-                double tp = pr[i]; pr[i] = pr[parent]; pr[parent] = tp;
-                int ti = hid[i]; hid[i] = hid[parent]; hid[parent] = ti;
-                i = parent;
-            }
-        }
-        int no = 0;
-        while (hn > 0) {                                  // popitem
-            order[hid[0]] = no++;
-            if (hn == 1) { hn = 0; break; }
-            hn--;
-            pr[0] = pr[hn]; hid[0] = hid[hn];
-            int i = 0;
-            for (;;) {                                    // _min_heapify
-                int l = (i << 1) + 1, r = (i + 1) << 1, low;
-                if (l < hn && pr[l] < pr[i]) low = l; else low = i;
-                if (r < hn && pr[r] < pr[low]) low = r;
-                if (low == i) break;
-                double tp = pr[i]; pr[i] = pr[low]; pr[low] = tp;
-                int ti = hid[i]; hid[i] = hid[low]; hid[low] = ti;
-                i = low;
-            }
-        }
+    const bool mine = (kept >> lane) & 1;
+    // heapdict pops distinct priorities in ascending order whatever the heap looked like, so the pop rank is a count;
+    // only equal priorities (twin words) depend on the heap's history and need the replay
+    int rank = 0;
+    bool tie = false;
+    for (unsigned long long mm = kept; mm; mm &= mm - 1) {
+        const int c = __builtin_ctzll(mm);
+        const double Lc = readlane_d(myLm, c);
+        rank += Lc < myLm;
+        tie = tie || (c != lane && Lc == myLm);
     }
-    __syncthreads();
+    if (__any(mine && tie)) {
+        if (mine) scr[RSA_LM + lane] = myLm;
+        __syncthreads();
+        if (lane == 0) {
+            double* pr = scr + RSA_PR;
+            int hn = 0;
+            for (int c = 0; c < NCAND; c++) {                 // costQueue[path] = path.L in path order (:432-433)
+                if (!((kept >> c) & 1)) continue;
+                int i = hn++;
+                pr[i] = scr[RSA_LM + c]; hid[i] = c;
+                while (i) {                                   // _decrease_key: swap unless parent < child
+                    int parent = (i - 1) >> 1;
+                    if (pr[parent] < pr[i]) break;
+                    double tp = pr[i]; pr[i] = pr[parent]; pr[parent] = tp;
+                    int ti = hid[i]; hid[i] = hid[parent]; hid[parent] = ti;
+                    i = parent;
+                }
+            }
+            int no = 0;
+            while (hn > 0) {                                  // popitem
+                order[hid[0]] = no++;
+                if (hn == 1) { hn = 0; break; }
+                hn--;
+                pr[0] = pr[hn]; hid[0] = hid[hn];
+                int i = 0;
+                for (;;) {                                    // _min_heapify
+                    int l = (i << 1) + 1, r = (i + 1) << 1, low;
+                    if (l < hn && pr[l] < pr[i]) low = l; else low = i;
+                    if (r < hn && pr[r] < pr[low]) low = r;
+                    if (low == i) break;
+                    double tp = pr[i]; pr[i] = pr[low]; pr[low] = tp;
+                    int ti = hid[i]; hid[i] = hid[low]; hid[low] = ti;
+                    i = low;
+                }
+            }
+        }
+        __syncthreads();
+        rank = order[lane];
+    }
     if ((kept >> lane) & 1) {                             // lane c writes its word at its pop rank
-        RsWord* w = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE + order[lane];
+        RsWord* w = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE + rank;
         w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
         w->Lm = myLm; w->code = code; w->n = wn;
     }
