@@ -245,6 +245,14 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 // ------------------------------------------------------------------------------------------------------------
 constexpr int KIN_SCENES_PER_BLOCK = WAVE / 4;
 
+// value of lane J of the caller's quad (DPP quad_perm [J,J,J,J])
+template <int J>
+__device__ __forceinline__ double quad_bcast(double v) {
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), J * 0x55, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), J * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, const void* actions, const uint8_t* active,
                                                   uint32_t stages, double* kin) {
@@ -267,7 +275,6 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
     steer = clipd(steer, STEER_LO, STEER_HI);
     const double dh = speed * hm_tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
     double* out = buf + ls * KIN_WORDS;
-    const int qbase = lane & ~3;
     for (int i = 0; i < q; i++) h = h + dh;                  // lane q starts at micro-step q
     for (int r = 0; r < NUM_STEP * MINI_ITER / 4; r++) {     // round r: micro-steps 4r .. 4r+3, one per lane
         double s_, c_;
@@ -278,11 +285,11 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
         }
         const double tx = speed * c_ * STEP_LENGTH / MINI_ITER;
         const double ty = speed * s_ * STEP_LENGTH / MINI_ITER;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {                        // x += ..., y += ... in micro-step order (vehicle.py:90-91)
-            x += __shfl(tx, qbase + j);
-            y += __shfl(ty, qbase + j);
-        }
+        // x += ..., y += ... in micro-step order (vehicle.py:90-91): quad broadcasts through DPP (no LDS round trip)
+        x += quad_bcast<0>(tx); y += quad_bcast<0>(ty);
+        x += quad_bcast<1>(tx); y += quad_bcast<1>(ty);
+        x += quad_bcast<2>(tx); y += quad_bcast<2>(ty);
+        x += quad_bcast<3>(tx); y += quad_bcast<3>(ty);
         h = h + dh; h = h + dh; h = h + dh; h = h + dh;      // four steps of the sequential chain
     }
     if (q == 0) {                                            // after micro-step 199: the 10th sub-step pose
