@@ -172,6 +172,21 @@ def main():
                 traffic = json.load(open(pmc))['kernels'][dom]['hbm_bytes']
             except Exception:
                 traffic = None
+        # the box's own streaming ceiling next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB
+        copy_gbps = None
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            tc = time.perf_counter()
+            for _ in range(10):
+                dst.copy_(src)
+            torch.cuda.synchronize(dev)
+            copy_gbps = 10 * 2 * src.numel() * 4 / (time.perf_counter() - tc) / 1e9
+            del src, dst
+        except Exception:
+            pass
         result = {
             'metric': 'parallel env steps/sec (full CarParking step incl. obs + RS search)', 'value': value,
             'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -183,6 +198,7 @@ def main():
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'kernel': dom, 'largest_by_time': largest,
+                         'measured_copy_GBps': copy_gbps,
                          'kernel_ms': dom_ms, 'kernel_launches': dom_launches,
                          'algorithmic_bytes_per_launch': bytes_avg_launch,
                          'algorithmic_bytes_per_bench_step': bytes_per_launch,

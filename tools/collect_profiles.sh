@@ -22,9 +22,18 @@ for V in "" "_image"; do
     rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   done
 done
+# derived busy / utilisation metrics (list VALU-busy and LDS-bank-conflict next to the HBM fraction)
+for V in "" "_image"; do
+  FLAG=""; [ -n "$V" ] && FLAG="--image"
+  I=0
+  for C in "VALUBusy SALUBusy" "LDSBankConflict MemUnitBusy" "OccupancyPercent VALUUtilization"; do
+    I=$((I+1))
+    rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --no-cpu-baseline > /dev/null 2>&1
+  done
+done
 python $R/tools/reduce_profiles.py $O $TAG
 py $R/tools/stage_times.py --scenes 32768 > $O/${TAG}_stage_times.txt
 py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
 py $R/examples/rollout_demo.py --scenes 65536 --steps 50 > $O/${TAG}_rollout_demo.txt
-rm -rf $O/kstats $O/kstats_img $O/pmc_* $O/pmc*_FETCH_SIZE $O/pmc*_WRITE_SIZE
+rm -rf $O/kstats $O/kstats_img $O/pmc_* $O/pmc*_FETCH_SIZE $O/pmc*_WRITE_SIZE $O/busy*
 ls -la $O

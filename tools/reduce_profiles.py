@@ -49,8 +49,33 @@ def pmc(src_dir, counter, out_csv):
     return f
 
 
+def busy(o, v, out_txt):
+    """derived metrics (percent), averaged over the launches of the second half of the run (steady state)"""
+    import collections
+    acc = collections.defaultdict(list)
+    for d in sorted(glob.glob(os.path.join(o, f'busy{v}_[0-9]'))):
+        f = find(d, '*counter_collection.csv')
+        if not f:
+            continue
+        rows = list(csv.DictReader(open(f)))
+        for r in rows[len(rows) // 2:]:
+            k = next((k for k in KERNELS if k in r['Kernel_Name']), None)
+            if k:
+                acc[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
+    if not acc:
+        return
+    names = sorted({c for _, c in acc})
+    with open(out_txt, 'w') as g:
+        g.write(f"{'kernel':16s}" + ''.join(f'{n:>18s}' for n in names) + '   (percent, rocprofv3 derived metrics)\n')
+        for k in KERNELS:
+            if any((k, n) in acc for n in names):
+                g.write(f'{k:16s}' + ''.join(f"{sum(acc[(k, n)]) / max(len(acc[(k, n)]), 1):18.2f}" for n in names) + '\n')
+
+
 def main():
     o, tag = sys.argv[1], sys.argv[2]
+    busy(o, '', os.path.join(o, f'{tag}_pmc_busy.txt'))
+    busy(o, '_image', os.path.join(o, f'{tag}_pmc_busy_image.txt'))
     kernel_stats(os.path.join(o, 'kstats'), os.path.join(o, f'{tag}_kernel_stats.csv'), os.path.join(o, f'{tag}_kernel_stats_top.txt'))
     kernel_stats(os.path.join(o, 'kstats_img'), os.path.join(o, f'{tag}_kernel_stats_image.csv'),
                  os.path.join(o, f'{tag}_kernel_stats_image_top.txt'))
