@@ -27,7 +27,8 @@ struct RsParams {
     const double* state;      // [n][ST_WORDS]
     const int32_t* rs_count;  // [1]
     const int32_t* rs_list;   // [n]
-    RsWord* rs_words;         // [n][RS_WORDS_PER_SCENE] ordered (pop order) words of the queued scenes
+    RsWord* rs_words;         // [n][RS_WORDS_PER_SCENE] kept words of the queued scenes, indexed by candidate call index
+    uint8_t* rs_order;        // [n][RS_WORDS_PER_SCENE] heapdict pop order: call index of the k-th popped word
     int32_t* rs_nwords;       // [n]
     int8_t* rs_word;          // [n][8]
     void* rs_lengths;         // real [n][5]

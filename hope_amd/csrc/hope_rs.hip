@@ -297,21 +297,47 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
 }
 
 // ================================================================================================
-// Kernel A: generate_path + set_path + heapdict order  ->  ordered word list per queued scene
+// Kernel A: generate_path + set_path + heapdict order  ->  word list + pop order per queued scene
 // ================================================================================================
-// The 46 solver calls run one per lane.  Instead of twelve divergent solver bodies, the lanes share the
-// expensive steps: one hm_sincos(phi'), one (hypot, atan2) of the solver's polar argument, one asin/acos,
-// one second atan2, then short per-family tails -- the arithmetic of each solver is unchanged.
-constexpr int RSA_LM = 0, RSA_PR = 64, RSA_WORDS = 128;     // LDS doubles, then ints hid[64], order[64]
+// FOUR LANES PER SCENE (16 scenes per wave).  generate_path tries 12 solver families, each in the four
+// reflections q = 0..3 of (:152-185 etc.; SCS only q = 0, 2): lane q of a quad evaluates reflection q, and all lanes
+// of the wave run the SAME family at the same time -- no divergence between solver bodies, which a
+// lane-per-candidate layout pays for twelve times over.  set_path's order-dependent de-dup (:57-76) only ever
+// compares words of equal type sequence, and those are known statically: (g, q) with (g, q ^ 1), LRL with the
+// "backwards" LRL of the next family, LRLRn with LRLRp -- a handful of quad broadcasts per family instead of a
+// replay over all candidates.  heapdict's array heap (push order = path order, non-strict sift-up, strict sift-down)
+// is replayed per scene by lane 0 of the quad as the words are kept; the pop order goes to rs_order.
+constexpr int RSA_SCENES = WAVE / 4;
+
+template <int J>
+__device__ __forceinline__ double quad_get(double v) {
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), J * 0x55, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), J * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ int quad_get(int v) { return __builtin_amdgcn_mov_dpp(v, J * 0x55, 0xf, 0xf, true); }
+
+// sum([x - y for x, y in zip(old.lengths, new.lengths)]) <= 0.01 (:63-66), left to right over n segments
+__device__ __forceinline__ bool rs_dup(int n, double o0, double o1, double o2, double o3, double o4, double c0, double c1,
+                                       double c2, double c3, double c4) {
+    double s = 0;
+    s = s + (o0 - c0); s = s + (o1 - c1); s = s + (o2 - c2);
+    if (n > 3) s = s + (o3 - c3);
+    if (n > 4) s = s + (o4 - c4);
+    return s <= 0.01;
+}
 
 __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
-    __shared__ double scr[RSA_WORDS];
-    __shared__ int hid[64];
-    __shared__ int order[64];
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= *p.rs_count) return;
-    const int scene = p.rs_list[blockIdx.x];
-    const int slot = p.slot_base + p.slot_dir * (int)blockIdx.x;
+    __shared__ double pr[RSA_SCENES][NCAND];                  // heap priorities per scene
+    __shared__ unsigned char hid[RSA_SCENES][NCAND + 2];      // heap ids (candidate call index)
+    const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
+    const int qi = blockIdx.x * RSA_SCENES + ls;
+    const int count = *p.rs_count;
+    if ((int)blockIdx.x * RSA_SCENES >= count) return;
+    const bool live = qi < count;
+    const int scene = p.rs_list[live ? qi : 0];
+    const int slot = p.slot_base + p.slot_dir * (live ? qi : 0);
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double* st = p.state + (size_t)scene * ST_WORDS;
     const double q0x = st[0], q0y = st[1], q0w = st[2];
@@ -326,101 +352,37 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
         X = (c * dx + s * dy) * MAXC;
         Y = (-s * dx + c * dy) * MAXC;
     }
-    double l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0;
-    int code = 0, wn = 0;
-    bool ok = false;
-    if (lane < NCAND) {
-        int g, q;
-        cand_decode(lane, g, q);
-        double bx = X, by = Y;
-        if (g == 4 || g == 9 || g == 10) {               // "backwards" (:206-207, :376-377)
-            bx = X * hm_cos(PHI) + Y * hm_sin(PHI);
-            by = X * hm_sin(PHI) - Y * hm_cos(PHI);
-        }
+    const double XB = X * hm_cos(PHI) + Y * hm_sin(PHI);    // "backwards" (:206-207, :376-377)
+    const double YB = X * hm_sin(PHI) - Y * hm_cos(PHI);
+
+    RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
+    int hn = 0;                                               // heap size (meaningful on lane 0 of the quad)
+    double p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // previous family: my reflection's lengths, kept flag
+    bool pk = false;
+    const double hp = 0.5 * PI;
+
+    for (int g = 0; g < 12; g++) {
+        const bool back = (g == 4 || g == 9 || g == 10);
+        const double bx = back ? XB : X, by = back ? YB : Y;
         const double sx = (q & 1) ? -bx : bx;
         const double sy = (q & 2) ? -by : by;
         const double sp = (q == 1 || q == 2) ? -PHI : PHI;
         double t = 0, u = 0, v = 0;
-        if (g == 0) {
-            ok = rs_SLS(sx, sy, sp, t, u, v);
-        } else {
-            double s_, c_;
-            hm_sincos(sp, &s_, &c_);
-            const bool plus = (g == 2 || g == 5 || g == 6 || g == 8 || g == 10 || g == 11);
-            const double xi = plus ? sx + s_ : sx - s_;
-            const double eta = plus ? sy - 1.0 - c_ : sy - 1.0 + c_;
-            const bool isLRLR = (g == 5 || g == 6);
-            const bool isLRSR = (g == 8 || g == 10);
-            double r = 0, th = 0;
-            if (!isLRLR) {                                // R(.,.) (:571-578); LRSR uses R(-eta, xi) (:314)
-                double ra = isLRSR ? -eta : xi, rb = isLRSR ? xi : eta;
-                r = hm_hypot(ra, rb);
-                th = hm_atan2(rb, ra);
-            }
-            bool alive = true, needC = false;
-            double cy = 0, cx = 1, vv = 0, t2 = 0;
-            if (g == 1) {                                 // LSL :79-87
-                t = th; u = r; alive = t >= 0.0;
-            } else if (g == 2) {                          // LSR :90-103
-                double u1 = r * r;
-                alive = u1 >= 4.0;
-                if (alive) { u = sqrt(u1 - 4.0); cy = 2.0; cx = u; needC = true; }
-            } else if (g == 3 || g == 4) {                // LRL :106-117
-                alive = r <= 4.0;
-                if (alive) u = -2.0 * hm_asin(0.25 * r);
-            } else if (isLRSR) {                          // LRSR :311-323
-                alive = r >= 2.0;
-                if (alive) { t = th; u = 2.0 - r; v = rs_M(t + 0.5 * PI - sp); }
-            } else if (g == 7 || g == 9) {                // LRSL :326-339
-                alive = r >= 2.0;
-                if (alive) { double rr = sqrt(r * r - 4.0); u = 2.0 - rr; cy = rr; cx = -2.0; needC = true; }
-            } else if (g == 11) {                         // LRSLR :414-429
-                alive = r >= 2.0;
-                if (alive) {
-                    u = 4.0 - sqrt(r * r - 4.0);
-                    alive = u <= 0.0;
-                    if (alive) { cy = (4.0 - u) * xi - 2.0 * eta; cx = -2.0 * xi + (u - 4.0) * eta; needC = true; }
-                }
-            } else {                                      // LRLRn :246-257 / LRLRp :260-272 + calc_tauOmega :228-243
-                if (g == 5) {
-                    double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
-                    alive = rho <= 1.0;
-                    if (alive) { u = hm_acos(rho); vv = -u; }
-                } else {
-                    double rho = (20.0 - xi * xi - eta * eta) / 16.0;
-                    alive = 0.0 <= rho && rho <= 1.0;
-                    if (alive) { u = -hm_acos(rho); alive = u >= -0.5 * PI; vv = u; }
-                }
-                if (alive) {
-                    double delta = rs_M(u - vv);
-                    double su, cu, sd, cd;
-                    hm_sincos(u, &su, &cu);
-                    hm_sincos(delta, &sd, &cd);
-                    double A = su - sd;
-                    double B = cu - cd - 1.0;
-                    cy = eta * A - xi * B; cx = xi * A + eta * B; needC = true;
-                    t2 = 2.0 * (cd - hm_cos(vv) - cu) + 3.0;
-                }
-            }
-            double th2 = 0;
-            if (alive && needC) th2 = hm_atan2(cy, cx);
-            if (alive) {
-                if (g == 1) { v = rs_M(sp - t); ok = v >= 0.0; }
-                else if (g == 2) { t = rs_M(th + th2); v = rs_M(t - sp); ok = t >= 0.0 && v >= 0.0; }
-                else if (g == 3 || g == 4) { t = rs_M(th + 0.5 * u + PI); v = rs_M(sp - t + u); ok = t >= 0.0 && u <= 0.0; }
-                else if (isLRSR) { ok = t >= 0.0 && u <= 0.0 && v <= 0.0; }
-                else if (g == 7 || g == 9) { t = rs_M(th + th2); v = rs_M(sp - 0.5 * PI - t); ok = t >= 0.0 && u <= 0.0 && v <= 0.0; }
-                else if (g == 11) { t = rs_M(th2); v = rs_M(t - sp); ok = t >= 0.0 && v >= 0.0; }
-                else {
-                    t = t2 < 0 ? rs_M(th2 + PI) : rs_M(th2);
-                    v = rs_M(t - u + vv - sp);
-                    ok = (g == 5) ? (t >= 0.0 && v <= 0.0) : (t >= 0.0 && v >= 0.0);
-                }
-            }
+        bool ok = false;
+        switch (g) {                                          // wave-uniform
+            case 0: ok = (q == 0 || q == 2) && rs_SLS(sx, sy, sp, t, u, v); break;   // SCS (:120-130): q = 0, 2 only
+            case 1: ok = rs_LSL(sx, sy, sp, t, u, v); break;
+            case 2: ok = rs_LSR(sx, sy, sp, t, u, v); break;
+            case 3: case 4: ok = rs_LRL(sx, sy, sp, t, u, v); break;
+            case 5: ok = rs_LRLRn(sx, sy, sp, t, u, v); break;
+            case 6: ok = rs_LRLRp(sx, sy, sp, t, u, v); break;
+            case 7: case 9: ok = rs_LRSL(sx, sy, sp, t, u, v); break;
+            case 8: case 10: ok = rs_LRSR(sx, sy, sp, t, u, v); break;
+            default: ok = rs_LRSLR(sx, sy, sp, t, u, v); break;
         }
-        const double hp = 0.5 * PI;
+        ok = ok && live;
         int t0 = TL, t1 = TS, t2_ = TL, t3 = 0, t4 = 0, n = 3;
-        l0 = t; l1 = u; l2 = v;
+        double l0 = t, l1 = u, l2 = v, l3 = 0, l4 = 0;
         switch (g) {
             case 0: t0 = TS; t1 = TL; t2_ = TS; break;
             case 1: t0 = TL; t1 = TS; t2_ = TL; break;
@@ -439,103 +401,86 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
         if (q & 2) { t0 = mirror_type(t0); t1 = mirror_type(t1); t2_ = mirror_type(t2_); t3 = mirror_type(t3); t4 = mirror_type(t4); }
         if (n < 4) { t3 = 0; l3 = 0; }
         if (n < 5) { t4 = 0; l4 = 0; }
-        wn = n;
-        code = pack_types(t0, t1, t2_, t3, t4, n);
-    }
+        const int code = pack_types(t0, t1, t2_, t3, t4, n);
+        double L = 0;                                         // :68-71
+        L = L + fabs(l0); L = L + fabs(l1); L = L + fabs(l2);
+        if (n > 3) L = L + fabs(l3);
+        if (n > 4) L = L + fabs(l4);
 
-    // ---- set_path (:57-76) -------------------------------------------------------------------------------
-    // kept[c] = ok[c] and no EARLIER KEPT path with the same word has sum(old - new) <= 0.01 (:63-66) and L < 1000 (:70).
-    // Only candidates that share their word with another candidate can interact, so every lane first computes its own
-    // L (parallel) and whether it has such a twin; the order-dependent replay then runs over the twins only.
-    double myL = 0;
-    myL = myL + fabs(l0); myL = myL + fabs(l1); myL = myL + fabs(l2);
-    if (wn > 3) myL = myL + fabs(l3);
-    if (wn > 4) myL = myL + fabs(l4);
-    const unsigned long long okmask = __ballot(ok);
-    bool twin = false;
-    for (unsigned long long mm = okmask; mm; mm &= mm - 1) {
-        const int c = __builtin_ctzll(mm);
-        twin = twin || (c != lane && code == __builtin_amdgcn_readlane(code, c));
-    }
-    const unsigned long long twins = __ballot(ok && twin);
-    unsigned long long kept = __ballot(ok && !twin && !(myL >= MAX_LENGTH));
-    for (unsigned long long mm = twins; mm; mm &= mm - 1) {            // call order
-        const int c = __builtin_ctzll(mm);
-        const int code_c = __builtin_amdgcn_readlane(code, c);
-        const int n_c = __builtin_amdgcn_readlane(wn, c);
-        const double c0 = readlane_d(l0, c), c1 = readlane_d(l1, c), c2 = readlane_d(l2, c), c3 = readlane_d(l3, c), c4 = readlane_d(l4, c);
+        // ---- set_path: earlier KEPT words with my type sequence ------------------------------------------------
+        // previous family (LRL before backwards-LRL, LRLRn before LRLRp): its reflections (q & 2) and (q & 2) + 1
         bool dup = false;
-        if (((kept >> lane) & 1) && code == code_c) {
-            double s = 0;                                  // sum([x - y ...]) left to right (:65)
-            s = s + (l0 - c0); s = s + (l1 - c1); s = s + (l2 - c2);
-            if (n_c > 3) s = s + (l3 - c3);
-            if (n_c > 4) s = s + (l4 - c4);
-            dup = s <= 0.01;
+        if (g == 4 || g == 6) {                               // wave-uniform
+            const double a0 = (q & 2) ? quad_get<2>(p0) : quad_get<0>(p0), a1 = (q & 2) ? quad_get<2>(p1) : quad_get<0>(p1);
+            const double a2 = (q & 2) ? quad_get<2>(p2) : quad_get<0>(p2), a3 = (q & 2) ? quad_get<2>(p3) : quad_get<0>(p3);
+            const int ak = (q & 2) ? quad_get<2>((int)pk) : quad_get<0>((int)pk);
+            const double b0 = (q & 2) ? quad_get<3>(p0) : quad_get<1>(p0), b1 = (q & 2) ? quad_get<3>(p1) : quad_get<1>(p1);
+            const double b2 = (q & 2) ? quad_get<3>(p2) : quad_get<1>(p2), b3 = (q & 2) ? quad_get<3>(p3) : quad_get<1>(p3);
+            const int bk = (q & 2) ? quad_get<3>((int)pk) : quad_get<1>((int)pk);
+            dup = (ak && rs_dup(n, a0, a1, a2, a3, 0, l0, l1, l2, l3, l4)) || (bk && rs_dup(n, b0, b1, b2, b3, 0, l0, l1, l2, l3, l4));
         }
-        if (__any(dup)) continue;
-        if (readlane_d(myL, c) >= MAX_LENGTH) continue;    // :70
-        kept |= 1ull << c;
+        // even reflections first (no predecessor inside the family), then the odd ones against (g, q - 1)
+        bool kept = ok && !dup && !(L >= MAX_LENGTH) && !(q & 1);
+        {
+            const double e0 = (q & 2) ? quad_get<2>(l0) : quad_get<0>(l0), e1 = (q & 2) ? quad_get<2>(l1) : quad_get<0>(l1);
+            const double e2 = (q & 2) ? quad_get<2>(l2) : quad_get<0>(l2), e3 = (q & 2) ? quad_get<2>(l3) : quad_get<0>(l3);
+            const double e4 = (q & 2) ? quad_get<2>(l4) : quad_get<0>(l4);
+            const int ek = (q & 2) ? quad_get<2>((int)kept) : quad_get<0>((int)kept);
+            if (q & 1) kept = ok && !dup && !(ek && rs_dup(n, e0, e1, e2, e3, e4, l0, l1, l2, l3, l4)) && !(L >= MAX_LENGTH);
+        }
+        const int cidx = g == 0 ? (q >> 1) : 2 + 4 * (g - 1) + q;   // call index of this candidate
+        const double Lm = L / MAXC;                            // path.L / maxc (calc_all_paths :52)
+        if (kept) {
+            RsWord* w = words + cidx;
+            w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
+            w->Lm = Lm; w->code = code; w->n = n;
+        }
+        // ---- costQueue[path] = path.L in path order (:432-433): lane 0 of the quad pushes the kept ones -----------
+        {
+            const int k0 = quad_get<0>((int)kept), k1 = quad_get<1>((int)kept), k2 = quad_get<2>((int)kept), k3 = quad_get<3>((int)kept);
+            const double m0 = quad_get<0>(Lm), m1 = quad_get<1>(Lm), m2 = quad_get<2>(Lm), m3 = quad_get<3>(Lm);
+            if (q == 0) {
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const int kk = qq == 0 ? k0 : (qq == 1 ? k1 : (qq == 2 ? k2 : k3));
+                    if (!kk) continue;
+                    const double pv = qq == 0 ? m0 : (qq == 1 ? m1 : (qq == 2 ? m2 : m3));
+                    int i = hn++;
+                    pr[ls][i] = pv; hid[ls][i] = (unsigned char)(g == 0 ? (qq >> 1) : 2 + 4 * (g - 1) + qq);
+                    while (i) {                               // _decrease_key: swap unless parent < child
+                        const int parent = (i - 1) >> 1;
+                        if (pr[ls][parent] < pr[ls][i]) break;
+                        const double tp = pr[ls][i]; pr[ls][i] = pr[ls][parent]; pr[ls][parent] = tp;
+                        const unsigned char ti = hid[ls][i]; hid[ls][i] = hid[ls][parent]; hid[ls][parent] = ti;
+                        i = parent;
+                    }
+                }
+            }
+        }
+        p0 = l0; p1 = l1; p2 = l2; p3 = l3; pk = kept;
     }
-    const int n_paths = __popcll(kept);
-    if (lane == 0) p.rs_nwords[slot] = n_paths;
-    if (n_paths == 0) return;                              // find_rs_path :427-428
 
-    // ---- path.L / maxc (calc_all_paths :52) and heapdict pop order ----------------------------------
-    const double myLm = myL / MAXC;
-    const bool mine = (kept >> lane) & 1;
-    // heapdict pops distinct priorities in ascending order whatever the heap looked like, so the pop rank is a count;
-    // only equal priorities (twin words) depend on the heap's history and need the replay
-    int rank = 0;
-    bool tie = false;
-    for (unsigned long long mm = kept; mm; mm &= mm - 1) {
-        const int c = __builtin_ctzll(mm);
-        const double Lc = readlane_d(myLm, c);
-        rank += Lc < myLm;
-        tie = tie || (c != lane && Lc == myLm);
-    }
-    if (__any(mine && tie)) {
-        if (mine) scr[RSA_LM + lane] = myLm;
-        __syncthreads();
-        if (lane == 0) {
-            double* pr = scr + RSA_PR;
-            int hn = 0;
-            for (int c = 0; c < NCAND; c++) {                 // costQueue[path] = path.L in path order (:432-433)
-                if (!((kept >> c) & 1)) continue;
-                int i = hn++;
-                pr[i] = scr[RSA_LM + c]; hid[i] = c;
-                while (i) {                                   // _decrease_key: swap unless parent < child
-                    int parent = (i - 1) >> 1;
-                    if (pr[parent] < pr[i]) break;
-                    double tp = pr[i]; pr[i] = pr[parent]; pr[parent] = tp;
-                    int ti = hid[i]; hid[i] = hid[parent]; hid[parent] = ti;
-                    i = parent;
-                }
-            }
-            int no = 0;
-            while (hn > 0) {                                  // popitem
-                order[hid[0]] = no++;
-                if (hn == 1) { hn = 0; break; }
-                hn--;
-                pr[0] = pr[hn]; hid[0] = hid[hn];
-                int i = 0;
-                for (;;) {                                    // _min_heapify
-                    int l = (i << 1) + 1, r = (i + 1) << 1, low;
-                    if (l < hn && pr[l] < pr[i]) low = l; else low = i;
-                    if (r < hn && pr[r] < pr[low]) low = r;
-                    if (low == i) break;
-                    double tp = pr[i]; pr[i] = pr[low]; pr[low] = tp;
-                    int ti = hid[i]; hid[i] = hid[low]; hid[low] = ti;
-                    i = low;
-                }
+    // ---- heapdict pop order ---------------------------------------------------------------------------------------
+    if (q == 0 && live) {
+        p.rs_nwords[slot] = hn;
+        unsigned char* ord = p.rs_order + (size_t)slot * RS_WORDS_PER_SCENE;
+        int no = 0;
+        while (hn > 0) {                                      // popitem
+            ord[no++] = hid[ls][0];
+            if (hn == 1) { hn = 0; break; }
+            hn--;
+            pr[ls][0] = pr[ls][hn]; hid[ls][0] = hid[ls][hn];
+            int i = 0;
+            for (;;) {                                        // _min_heapify
+                const int l = (i << 1) + 1, r = (i + 1) << 1;
+                int low = (l < hn && pr[ls][l] < pr[ls][i]) ? l : i;
+                if (r < hn && pr[ls][r] < pr[ls][low]) low = r;
+                if (low == i) break;
+                const double tp = pr[ls][i]; pr[ls][i] = pr[ls][low]; pr[ls][low] = tp;
+                const unsigned char ti = hid[ls][i]; hid[ls][i] = hid[ls][low]; hid[ls][low] = ti;
+                i = low;
             }
         }
-        __syncthreads();
-        rank = order[lane];
-    }
-    if ((kept >> lane) & 1) {                             // lane c writes its word at its pop rank
-        RsWord* w = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE + rank;
-        w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
-        w->Lm = myLm; w->code = code; w->n = wn;
     }
 }
 
@@ -588,7 +533,7 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     double min_path_len = -1;
     int found = -1;
     for (int idx = 1; idx <= n_paths; idx++) {
-        const RsWord* W = words + (idx - 1);
+        const RsWord* W = words + p.rs_order[(size_t)slot * RS_WORDS_PER_SCENE + idx - 1];   // idx-th popped word
         const double Lm = W->Lm;
         if (min_path_len < 0) min_path_len = Lm;
         if (Lm > 1.6 * min_path_len && idx > 2) break;    // :443
@@ -739,7 +684,7 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     if (found < 0) return;
 
     // ---- output: PATH.ctypes / PATH.lengths (metres) of the first collision-free path ----------------
-    const RsWord* W = words + found;
+    const RsWord* W = words + p.rs_order[(size_t)slot * RS_WORDS_PER_SCENE + found];
     const int code = W->code, nseg = W->n;
     if (lane < 5) {
         double lm = lane < nseg ? W->len[lane] / MAXC : 0.0;      // path.lengths = [l / maxc ...] (:51)
@@ -769,7 +714,7 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     }
     // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
     if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
-    hipLaunchKernelGGL(k_rs_words, dim3(p.max_queue), dim3(WAVE), 0, stream, p);
+    hipLaunchKernelGGL(k_rs_words, dim3((p.max_queue + RSA_SCENES - 1) / RSA_SCENES), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
     static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
