@@ -246,3 +246,25 @@ def test_batch_oracle_tracks_the_trajectory_like_vehicle_py():
     img = orc.image()
     assert img.shape == (4, 3, 64, 64) and img.dtype == np.uint8
     assert (img[:, :, 32, 32] == np.array([10, 10, 200])).all()      # newest trajectory box covers the centre
+
+
+def test_image_oracle_regression_hashes():
+    """guards the oracle itself against accidental edits (it is the checker of tests/test_gpu_image.py): images of 6
+    seeded mixed scenes after 1, 6 and 24 random steps (hope_math build; the same arithmetic as the HIP path)"""
+    import hashlib
+    from hope_amd.scenes import SceneSource, pack_scenes
+    src = SceneSource(seed=123)
+    scenes = [src.draw() for _ in range(6)]
+    start, dest, bbox, verts, nob, nvert = pack_scenes(scenes, 128)
+    orc = O.BatchOracle(6, 128)
+    orc.set_scenes(np.arange(6), start, dest, bbox, verts, nvert, nob)
+    orc.reset_obs(with_rs=False)
+    rng = np.random.default_rng(9)
+    got = []
+    for it in range(24):
+        orc.step(rng.uniform(-1, 1, (6, 2)), with_rs=False)
+        if it in (0, 5, 23):
+            got.append(hashlib.sha256(orc.image().tobytes()).hexdigest())
+    assert got == ['878a38e87d132f13373469c5b16a352e264e6d4eb888a5210b0cfa508aa9a728',
+                   '65a611dc552bdb5983c4a2be71000d95f24acb3c5848894a31d4b891a1cc04e1',
+                   'e55e0297f0dcf6c578c36af1335e12f65f406d1e09bcebafb7e065ca6ea58a7c']
