@@ -5,6 +5,8 @@ Plain torch tensor code (any device); no custom kernels -- these are a few eleme
   mask_action_probs /
   choose_action        <-> ActionMask.choose_action  src/model/action_mask.py:199-227
   BatchedStateNorm     <-> StateNorm                 src/model/state_norm.py:7-46
+  batched_gae          <-> PPO.update's GAE loop     src/model/agent/ppo_agent.py:258-273
+  RolloutStorage       <-> ReplayMemory              src/model/replay_memory.py:6-49
 """
 import math
 
@@ -166,3 +168,81 @@ class BatchedStateNorm:
             self.S[k] = self.S[k] + bS + delta ** 2 * (n0 * m / (n0 + m))
             self.std[k] = torch.sqrt(self.S[k] / (n0 + m))
         self.n_state = n0 + m
+
+
+# ---- PPO / SAC storage over [N, T] -----------------------------------------------------------
+def batched_gae(reward, value, next_value, done, gamma=0.98, lam=0.95, use_gae=True):
+    """Advantages of PPO.update (src/model/agent/ppo_agent.py:258-273) for N parallel scenes at once.
+
+    The reference keeps ONE env's transitions in time order and runs
+        delta = r + gamma * (1 - done) * V(s') - V(s);  gae = delta + gamma * lambda * gae * (1 - done)   (backwards)
+    so with N scenes the recurrence runs along T independently per row.  reward / value / next_value / done: [N, T]
+    (done as 0/1).  The accumulation is done in float64 like the reference's Python-float loop and returned in
+    value's dtype.  Returns (adv [N, T], delta [N, T])."""
+    r, v, nv, d = (x.to(torch.float64) for x in (reward, value, next_value, done))
+    delta = (r + gamma * (1 - d) * nv - v).to(value.dtype).to(torch.float64)       # deltas are float32 tensors there
+    if not use_gae:
+        return delta.to(value.dtype), delta.to(value.dtype)
+    adv = torch.zeros_like(delta)
+    gae = torch.zeros(delta.shape[0], dtype=torch.float64, device=delta.device)
+    for t in range(delta.shape[1] - 1, -1, -1):
+        gae = delta[:, t] + gamma * lam * gae * (1.0 - d[:, t])
+        adv[:, t] = gae
+    return adv.to(value.dtype), delta.to(value.dtype)
+
+
+class RolloutStorage:
+    """Device-resident [N, T] ring of transitions: the batched stand-in for ReplayMemory (src/model/replay_memory.py)
+    as both agents use it -- PPO reads everything in time order (get_items(arange), ppo_agent.py:241), SAC samples
+    uniformly (sample(batch_size), sac_agent.py) with next_state = None at episode ends / at the newest entry
+    (:27-30), which is reported here as `next_valid`."""
+
+    def __init__(self, n, horizon, obs_shapes, device='cpu', action_dim=2, extra=('log_prob',)):
+        self.n, self.T, self.device = n, horizon, torch.device(device)
+        self.obs = {k: torch.zeros((n, horizon) + tuple(s), dtype=torch.uint8 if k == 'img' else torch.float32, device=self.device)
+                    for k, s in obs_shapes.items()}
+        self.action = torch.zeros((n, horizon, action_dim), dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros((n, horizon), dtype=torch.float32, device=self.device)
+        self.done = torch.zeros((n, horizon), dtype=torch.float32, device=self.device)
+        self.extra = {k: torch.zeros((n, horizon, action_dim), dtype=torch.float32, device=self.device) for k in extra}
+        self.head, self.size = 0, 0
+
+    def push(self, obs, action, reward, done, **extra):
+        """one step of all N scenes (ReplayMemory.push :12-15)"""
+        t = self.head
+        for k in self.obs:
+            self.obs[k][:, t] = obs[k].to(self.obs[k].dtype)
+        self.action[:, t] = action
+        self.reward[:, t] = reward
+        self.done[:, t] = done.to(torch.float32)
+        for k, v in extra.items():
+            self.extra[k][:, t] = v
+        self.head = (t + 1) % self.T
+        self.size = min(self.size + 1, self.T)
+
+    def _time_index(self):
+        """column indices oldest -> newest"""
+        return (torch.arange(self.size, device=self.device) + (self.head - self.size)) % self.T
+
+    def ordered(self):
+        """everything in time order, [N, size, ...] (PPO); next-observation of column j is column j + 1"""
+        idx = self._time_index()
+        out = {'obs': {k: v[:, idx] for k, v in self.obs.items()}, 'action': self.action[:, idx],
+               'reward': self.reward[:, idx], 'done': self.done[:, idx]}
+        out.update({k: v[:, idx] for k, v in self.extra.items()})
+        return out
+
+    def sample(self, batch_size, generator=None):
+        """uniform transitions over (scene, time) like ReplayMemory.sample (:33-35).  next_valid is False where the
+        reference returns next_state None: episode end or newest entry (:27-28)."""
+        idx = self._time_index()
+        s = torch.randint(self.n, (batch_size,), device=self.device, generator=generator)
+        j = torch.randint(self.size, (batch_size,), device=self.device, generator=generator)
+        t = idx[j]
+        nxt = idx[torch.clamp(j + 1, max=self.size - 1)]
+        next_valid = (j < self.size - 1) & (self.done[s, t] == 0)
+        return {'obs': {k: v[s, t] for k, v in self.obs.items()}, 'next_obs': {k: v[s, nxt] for k, v in self.obs.items()},
+                'next_valid': next_valid, 'action': self.action[s, t], 'reward': self.reward[s, t], 'done': self.done[s, t]}
+
+    def clear(self):
+        self.head, self.size = 0, 0

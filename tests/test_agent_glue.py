@@ -71,3 +71,47 @@ def test_state_norm_matches_reference_recurrence(gold):
     m = sb.mean['target'].clone()
     sb.update({'lidar': lid[:5], 'target': tgt[:5]})
     assert torch.equal(m, sb.mean['target'])
+
+
+def test_batched_gae_equals_the_reference_loop_per_scene():
+    """ppo_agent.py:258-273 restated literally (one env, time order, Python-float recurrence) vs batched_gae rows"""
+    import torch
+    from hope_amd.agent_glue import batched_gae
+    rng = np.random.default_rng(0)
+    N, T, gamma, lam = 7, 33, 0.98, 0.95
+    r = rng.normal(size=(N, T)).astype(np.float32)
+    v = rng.normal(size=(N, T)).astype(np.float32)
+    nv = rng.normal(size=(N, T)).astype(np.float32)
+    d = (rng.random((N, T)) < 0.1).astype(np.float32)
+    adv, delta = batched_gae(torch.tensor(r), torch.tensor(v), torch.tensor(nv), torch.tensor(d), gamma, lam)
+    for i in range(N):
+        deltas = torch.tensor(r[i]) + gamma * (1 - torch.tensor(d[i])) * torch.tensor(nv[i]) - torch.tensor(v[i])
+        gae, out = 0, []
+        for dl, dn in zip(reversed(deltas.flatten().numpy().astype(np.float64)), reversed(d[i].astype(np.float64))):
+            gae = dl + gamma * lam * gae * (1.0 - dn)
+            out.append(gae)
+        out.reverse()
+        want = torch.FloatTensor(out)
+        assert torch.allclose(adv[i], want, rtol=0, atol=1e-6)
+        assert torch.allclose(delta[i], deltas, rtol=0, atol=1e-6)
+
+
+def test_rollout_storage_order_and_next_state_semantics():
+    import torch
+    from hope_amd.agent_glue import RolloutStorage
+    st = RolloutStorage(3, 4, {'lidar': (5,), 'target': (2,)})
+    for t in range(6):                                   # wraps: only the last 4 steps stay
+        obs = {'lidar': torch.full((3, 5), float(t)), 'target': torch.full((3, 2), float(t))}
+        st.push(obs, torch.full((3, 2), float(t)), torch.full((3,), float(t)), torch.tensor([0, 0, t == 4]),
+                log_prob=torch.zeros(3, 2))
+    o = st.ordered()
+    assert o['reward'][0].tolist() == [2.0, 3.0, 4.0, 5.0] and o['obs']['lidar'][1, :, 0].tolist() == [2.0, 3.0, 4.0, 5.0]
+    g = torch.Generator().manual_seed(0)
+    b = st.sample(256, generator=g)
+    newest = b['reward'] == 5.0
+    ended = (b['done'] == 1)
+    assert (b['next_valid'] == ~(newest | ended)).all()
+    ok = b['next_valid']
+    assert (b['next_obs']['lidar'][ok][:, 0] == b['obs']['lidar'][ok][:, 0] + 1).all()
+    st.clear()
+    assert st.size == 0
