@@ -619,18 +619,22 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
                 }
                 // `pd += d` chain (sequential rounding kept): every lane walks it, lane j keeps the value after
                 // j additions; the walk stops at the first block of 8 whose last value already left the segment
+                // (lane j = 8 b + r takes the value at the start of block b from the common walk and adds d another r times
+                // itself: the same additions in the same order, without a select per step)
                 double mine = pd, t = pd, last = pd;
                 int ncap = 0;
                 for (int j0 = 0; j0 < WAVE; j0 += 8) {
+                    if ((lane >> 3) == (j0 >> 3)) mine = t;
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        if (lane == j0 + jj) mine = t;
-                        last = t;
-                        t = t + d;
-                    }
+                    for (int jj = 0; jj < 7; jj++) t = t + d;
+                    last = t;
+                    t = t + d;
                     ncap = j0 + 8;
                     if (__any(fabs(last) > fabs(l))) break;
                 }
+#pragma unroll
+                for (int k = 0; k < 7; k++)
+                    if (k < (lane & 7)) mine = mine + d;
                 const bool in_seg = lane < ncap && fabs(mine) <= fabs(l);
                 const unsigned long long valid = (ncap == WAVE) ? ~0ull : ((1ull << ncap) - 1);
                 const unsigned long long fail = ~__ballot(in_seg) & valid;
