@@ -209,6 +209,31 @@ __device__ __forceinline__ void interpolate(double l, int m, double ox, double o
     }
 }
 
+// wave-wide float min / max without LDS round trips: DPP butterflies inside each row of 16 lanes, then the four row
+// results through readlane
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    v = fminf(v, dpp_f<0xB1>(v));        // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_f<0x4E>(v));        // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_f<0x141>(v));       // row_half_mirror
+    v = fminf(v, dpp_f<0x140>(v));       // row_mirror
+    const int i = __float_as_int(v);
+    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fminf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    const int i = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
+
 // is_traj_valid for the (up to 64) poses held one per lane: returns true on a lane whose pose is out of the
 // map box or whose hull meets an obstacle edge (line-line intersection inside both edge boxes, no tolerance).
 // Obstacles are culled per call: the union box of the active lanes' hulls is wave-reduced, one lane per
@@ -238,13 +263,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
     // union box of the pass: float, rounded outwards (only used to cull whole obstacles, so a superset is exact)
     float ulox = active ? __double2float_rd(hminx) : INFINITY, uhix = active ? __double2float_ru(hmaxx) : -INFINITY;
     float uloy = active ? __double2float_rd(hminy) : INFINITY, uhiy = active ? __double2float_ru(hmaxy) : -INFINITY;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        ulox = fminf(ulox, __shfl_xor(ulox, off));
-        uhix = fmaxf(uhix, __shfl_xor(uhix, off));
-        uloy = fminf(uloy, __shfl_xor(uloy, off));
-        uhiy = fmaxf(uhiy, __shfl_xor(uhiy, off));
-    }
+    ulox = wave_min_f(ulox); uhix = wave_max_f(uhix); uloy = wave_min_f(uloy); uhiy = wave_max_f(uhiy);
     const double uminx = ulox, umaxx = uhix, uminy = uloy, umaxy = uhiy;
     int nc = 0;
     for (int base = 0; base < n_obst; base += WAVE) {
@@ -573,8 +592,8 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
             for (int i = 0; i < 5; i++) {
                 if (i < nseg) {
                     const int m = type_of(code, i);
-                    const double c_oy = __shfl(cv, i), s_oy = __shfl(sv, i);
-                    const double sl = __shfl(sv, 5 + i), cl = __shfl(cv, 5 + i);
+                    const double c_oy = readlane_d(cv, i), s_oy = readlane_d(sv, i);
+                    const double sl = readlane_d(sv, 5 + i), cl = readlane_d(cv, 5 + i);
                     if (lane == 0) {
                         double* sp_ = segp + RSB_SEGW * i;
                         sp_[0] = ox; sp_[1] = oy; sp_[2] = hy[i]; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_oy; sp_[6] = -s_oy;
