@@ -245,6 +245,14 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 // ------------------------------------------------------------------------------------------------------------
 constexpr int KIN_SCENES_PER_BLOCK = WAVE / 4;
 
+// DPP move of a double (two 32-bit moves), e.g. CTRL = quad_perm
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // value of lane J of the caller's quad (DPP quad_perm [J,J,J,J])
 template <int J>
 __device__ __forceinline__ double quad_bcast(double v) {
@@ -597,8 +605,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             int e2 = (e & ~3) | ((e + 1) & 3);
             dd = origin_seg_dist(tile[2 * e], tile[2 * e + 1], tile[2 * e2], tile[2 * e2 + 1]);
         }
-        dd = fmin(dd, __shfl_xor(dd, 1));
-        dd = fmin(dd, __shfl_xor(dd, 2));
+        dd = fmin(dd, dpp_d<0xB1>(dd));                      // quad_perm [1,0,3,2]
+        dd = fmin(dd, dpp_d<0x4E>(dd));                      // quad_perm [2,3,0,1]
         if (e < n_slots && (e & 3) == 0) keep[e >> 2] = dd < LIDAR_RANGE;
     }
     wsync();
@@ -668,10 +676,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                     lo = ((ilo % NBEAM) + NBEAM) % NBEAM;
                 }
             }
-            int kmax = cnt;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
-            for (int k = 0; k < kmax; k++) {
+            for (int k = 0; __any(k < cnt); k++) {
                 const bool c = k < cnt;
                 const unsigned long long m = __ballot(c);
                 if (c) {
