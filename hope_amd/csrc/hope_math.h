@@ -6,8 +6,10 @@
  * use different libm's (OCML on the GPU, glibc in the oracle, numpy's SIMD loops in the reference) disagree on
  * ~3e-5 of the searches purely through the last bit of sin/cos/atan2.  These functions use ONLY operations IEEE-754
  * defines exactly (+ - * / sqrt, rint, trunc, fabs, copysign, ldexp, fma), in a fixed order, with contraction off
- * (-ffp-contract=off on both compilers): the same source gives the same bits on gfx950 and on x86-64, so device
- * and oracle agree bit-for-bit and every remaining difference is a bug.
+ * (-ffp-contract=off on both compilers; every fused multiply-add is an EXPLICIT fma(), v_fma_f64 on gfx950 and
+ * vfmadd / glibc's correctly rounded fma() on x86-64): the same source gives the same bits on both, so device and
+ * oracle agree bit-for-bit and every remaining difference is a bug.  The polynomials are Horner chains of fma: half
+ * the instructions of separate multiplies and adds, and one rounding less per step.
  *
  * Accuracy: <= ~2 ulp on the ranges the env uses (|x| < 1e5 for sin/cos); validated against libm in
  * tests/test_math.py.  They are NOT bit-identical to any libm -- nothing can be, the reference's own numbers
@@ -33,39 +35,39 @@
 HM_FN double hm_ksin(double r) {
     const double z = r * r;
     double p = 1.9572941063391263e-20;
-    p = p * z + -8.22063524662433e-18;
-    p = p * z + 2.8114572543455206e-15;
-    p = p * z + -7.647163731819816e-13;
-    p = p * z + 1.6059043836821613e-10;
-    p = p * z + -2.505210838544172e-08;
-    p = p * z + 2.7557319223985893e-06;
-    p = p * z + -0.0001984126984126984;
-    p = p * z + 0.008333333333333333;
-    p = p * z + -0.16666666666666666;
-    return r + r * (z * p);
+    p = fma(p, z, -8.22063524662433e-18);
+    p = fma(p, z, 2.8114572543455206e-15);
+    p = fma(p, z, -7.647163731819816e-13);
+    p = fma(p, z, 1.6059043836821613e-10);
+    p = fma(p, z, -2.505210838544172e-08);
+    p = fma(p, z, 2.7557319223985893e-06);
+    p = fma(p, z, -0.0001984126984126984);
+    p = fma(p, z, 0.008333333333333333);
+    p = fma(p, z, -0.16666666666666666);
+    return fma(r, z * p, r);
 }
 HM_FN double hm_kcos(double r) {
     const double z = r * r;
     double p = -8.896791392450574e-22;
-    p = p * z + 4.110317623312165e-19;
-    p = p * z + -1.5619206968586225e-16;
-    p = p * z + 4.779477332387385e-14;
-    p = p * z + -1.1470745597729725e-11;
-    p = p * z + 2.08767569878681e-09;
-    p = p * z + -2.755731922398589e-07;
-    p = p * z + 2.48015873015873e-05;
-    p = p * z + -0.001388888888888889;
-    p = p * z + 0.041666666666666664;
+    p = fma(p, z, 4.110317623312165e-19);
+    p = fma(p, z, -1.5619206968586225e-16);
+    p = fma(p, z, 4.779477332387385e-14);
+    p = fma(p, z, -1.1470745597729725e-11);
+    p = fma(p, z, 2.08767569878681e-09);
+    p = fma(p, z, -2.755731922398589e-07);
+    p = fma(p, z, 2.48015873015873e-05);
+    p = fma(p, z, -0.001388888888888889);
+    p = fma(p, z, 0.041666666666666664);
     const double hz = 0.5 * z;
-    return (1.0 - hz) + z * (z * p);
+    return fma(z, z * p, 1.0 - hz);
 }
 /* |x| = k*pi/2 + r, |r| <= pi/4 (Cody-Waite, pi/2 in three parts; k*part exact for |k| < 2^20) */
 HM_FN void hm_sincos(double x, double* s, double* c) {
     const double ax = fabs(x);
     const double kd = rint(ax * 0.6366197723675814);
-    double r = ax - kd * 1.5707963267341256;
-    r = r - kd * 6.077100506303966e-11;
-    r = r - kd * 2.0222662487959506e-21;
+    double r = fma(-kd, 1.5707963267341256, ax);
+    r = fma(-kd, 6.077100506303966e-11, r);
+    r = fma(-kd, 2.0222662487959506e-21, r);
     const int q = (int)((long long)kd & 3);
     const double ks = hm_ksin(r), kc = hm_kcos(r);
     double ss = (q & 1) ? kc : ks;
@@ -84,21 +86,21 @@ HM_FN double hm_tan(double x) { double s, c; hm_sincos(x, &s, &c); return s / c;
 HM_FN double hm_katan(double t) {
     const double z = t * t;
     double p = -0.03225806451612903;
-    p = p * z + 0.034482758620689655;
-    p = p * z + -0.037037037037037035;
-    p = p * z + 0.04;
-    p = p * z + -0.043478260869565216;
-    p = p * z + 0.047619047619047616;
-    p = p * z + -0.05263157894736842;
-    p = p * z + 0.058823529411764705;
-    p = p * z + -0.06666666666666667;
-    p = p * z + 0.07692307692307693;
-    p = p * z + -0.09090909090909091;
-    p = p * z + 0.1111111111111111;
-    p = p * z + -0.14285714285714285;
-    p = p * z + 0.2;
-    p = p * z + -0.3333333333333333;
-    return t + t * (z * p);
+    p = fma(p, z, 0.034482758620689655);
+    p = fma(p, z, -0.037037037037037035);
+    p = fma(p, z, 0.04);
+    p = fma(p, z, -0.043478260869565216);
+    p = fma(p, z, 0.047619047619047616);
+    p = fma(p, z, -0.05263157894736842);
+    p = fma(p, z, 0.058823529411764705);
+    p = fma(p, z, -0.06666666666666667);
+    p = fma(p, z, 0.07692307692307693);
+    p = fma(p, z, -0.09090909090909091);
+    p = fma(p, z, 0.1111111111111111);
+    p = fma(p, z, -0.14285714285714285);
+    p = fma(p, z, 0.2);
+    p = fma(p, z, -0.3333333333333333);
+    return fma(t, z * p, t);
 }
 /* atan(a) for a >= 0 */
 HM_FN double hm_atan_pos(double a) {
@@ -142,23 +144,23 @@ HM_FN double hm_fmod(double x, double y) {
 /* ---- exp, tanh ------------------------------------------------------------------------------------------------ */
 HM_FN double hm_exp(double x) {
     const double kd = rint(x * 1.4426950408889634);
-    double r = x - kd * 0.6931471803691238;
-    r = r - kd * 1.9082149288430703e-10;
-    r = r - kd * 4.275175589747649e-20;
+    double r = fma(-kd, 0.6931471803691238, x);
+    r = fma(-kd, 1.9082149288430703e-10, r);
+    r = fma(-kd, 4.275175589747649e-20, r);
     double p = 1.1470745597729725e-11;
-    p = p * r + 1.6059043836821613e-10;
-    p = p * r + 2.08767569878681e-09;
-    p = p * r + 2.505210838544172e-08;
-    p = p * r + 2.755731922398589e-07;
-    p = p * r + 2.7557319223985893e-06;
-    p = p * r + 2.48015873015873e-05;
-    p = p * r + 0.0001984126984126984;
-    p = p * r + 0.001388888888888889;
-    p = p * r + 0.008333333333333333;
-    p = p * r + 0.041666666666666664;
-    p = p * r + 0.16666666666666666;
-    p = p * r + 0.5;
-    const double e = 1.0 + (r + r * (r * p));
+    p = fma(p, r, 1.6059043836821613e-10);
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    const double e = 1.0 + fma(r, r * p, r);
     return ldexp(e, (int)kd);
 }
 HM_FN double hm_tanh(double x) {
@@ -167,15 +169,15 @@ HM_FN double hm_tanh(double x) {
     if (ax < 0.15) {                                 /* the env only needs |x| <= 0.101 (t / 2000, t <= 202) */
         const double z = ax * ax;
         double p = -0.00023912911424355248;
-        p = p * z + 0.000590027440945586;
-        p = p * z + -0.0014558343870513183;
-        p = p * z + 0.003592128036572481;
-        p = p * z + -0.008863235529902197;
-        p = p * z + 0.021869488536155203;
-        p = p * z + -0.05396825396825397;
-        p = p * z + 0.13333333333333333;
-        p = p * z + -0.3333333333333333;
-        v = ax + ax * (z * p);
+        p = fma(p, z, 0.000590027440945586);
+        p = fma(p, z, -0.0014558343870513183);
+        p = fma(p, z, 0.003592128036572481);
+        p = fma(p, z, -0.008863235529902197);
+        p = fma(p, z, 0.021869488536155203);
+        p = fma(p, z, -0.05396825396825397);
+        p = fma(p, z, 0.13333333333333333);
+        p = fma(p, z, -0.3333333333333333);
+        v = fma(ax, z * p, ax);
     } else if (ax > 22.0) v = 1.0;
     else {
         const double e = hm_exp(2.0 * ax);
