@@ -45,6 +45,7 @@ struct hope_env {
     double* beam_ab = nullptr;
     int32_t* rs_count = nullptr;
     int32_t* rs_list = nullptr;
+    uint8_t* rs_flag = nullptr;
     double* kin = nullptr;
     double* traj = nullptr;        // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory
     int32_t* traj_len = nullptr;   // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
@@ -64,8 +65,8 @@ struct hope_env {
     struct EvPair { hipEvent_t a, b; int kind; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0};
-    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0};
+    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 static hipEvent_t get_event(hope_env* h) {
@@ -185,6 +186,49 @@ __global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, dou
     }
 }
 
+// Reeds-Shepp work queues: the flagged scenes of each tile class (blockIdx.y), compacted.  Each block scans its share
+// of the class's scene list (thread = a few consecutive entries, block-wide exclusive scan) and reserves one
+// contiguous range of the queue with a single atomicAdd.
+constexpr int COMPACT_BLOCKS = 16, COMPACT_THREADS = 1024;
+__global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list0, int n0, const int32_t* list1, int n1,
+                                                                 const uint8_t* flag, const uint8_t* active, int32_t* rs_list,
+                                                                 int stride, int32_t* rs_count) {
+    __shared__ int wsum[COMPACT_THREADS / WAVE];
+    __shared__ int base;
+    const int c = blockIdx.y;
+    const int32_t* list = c ? list1 : list0;
+    const int n = c ? n1 : n0;
+    int32_t* out = rs_list + (size_t)c * stride;
+    const int per_block = (n + COMPACT_BLOCKS - 1) / COMPACT_BLOCKS;
+    const int b0 = blockIdx.x * per_block, b1 = min(n, b0 + per_block);
+    const int per = (per_block + COMPACT_THREADS - 1) / COMPACT_THREADS;
+    const int a = b0 + threadIdx.x * per, b = min(b1, a + per);
+    int cnt = 0;
+    for (int i = a; i < b; i++) {
+        const int s = list[i];
+        cnt += flag[s] && (!active || active[s]);
+    }
+    // exclusive scan over the block: inside the wave by shuffles, across the 16 waves through LDS
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == WAVE - 1) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < COMPACT_THREADS / WAVE; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+    if (threadIdx.x == 0) base = total ? atomicAdd(rs_count + c, total) : 0;
+    __syncthreads();
+    int o = base + woff + incl - cnt;
+    for (int i = a; i < b; i++) {
+        const int s = list[i];
+        if (flag[s] && (!active || active[s])) out[o++] = s;
+    }
+}
+
 // one block per uploaded scene: copy its obstacle tile
 __global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const double* verts_in, double* verts,
                                   int max_obst) {
@@ -247,6 +291,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
     ALLOC(h->rs_count, 2 * sizeof(int32_t));
     ALLOC(h->rs_list, 2 * N * sizeof(int32_t));
+    ALLOC(h->rs_flag, N);
     ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
     ALLOC(h->cls_list[0], N * sizeof(int32_t));
     ALLOC(h->cls_list[1], N * sizeof(int32_t));
@@ -271,6 +316,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->state, 0, N * ST_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_count, 0, 2 * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->rs_flag, 0, N));
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -288,7 +334,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->rs_order, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->rs_order, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -420,8 +466,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.scene_list = h->cls_list[c];
         p.n_list = h->cls_count[c];
-        p.rs_count = h->rs_count + c;
-        p.rs_list = h->rs_list + (size_t)c * h->n;
+        p.rs_flag = h->rs_flag;
         const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
         if (tm) tm->begin(HOPE_K_STEP, s);
@@ -433,6 +478,10 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     }
     HIPCHK(hipGetLastError());
     if ((stages & HOPE_STAGE_RS) && out->rs_word) {
+        if (tm) tm->begin(HOPE_K_RS_COMPACT, s);
+        hipLaunchKernelGGL(k_rs_compact, dim3(COMPACT_BLOCKS, n_cls), dim3(COMPACT_THREADS), 0, s, h->cls_list[0], h->cls_count[0],
+                           h->cls_list[1], h->cls_count[1], h->rs_flag, active, h->rs_list, h->n, h->rs_count);
+        if (tm) tm->end(s);
         for (int c = 0; c < n_cls; c++) {
             if (h->cls_count[c] == 0) continue;
             RsParams r;

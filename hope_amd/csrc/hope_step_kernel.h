@@ -42,8 +42,7 @@ struct StepParams {
     const double* hull_base;  // [NBEAM]
     const double* beam_ab;    // [NBEAM][2]
     hope_step_out out;
-    int32_t* rs_count;        // [1] scenes of THIS tile class queued for the Reeds-Shepp kernels
-    int32_t* rs_list;         // [n] queue of this tile class
+    uint8_t* rs_flag;         // [n] 1: the scene passes the Reeds-Shepp gate this step (k_rs_compact builds the queues)
 };
 
 // LDS per wave (doubles): tile 8*tile_cap | region A [320] | hb[10] cb[10] sb[10] px[10] py[10] | dest box[8] |
@@ -558,12 +557,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             int8_t* w = p.out.rs_word + 8 * (size_t)scene;
             w[0] = w[1] = w[2] = w[3] = w[4] = HOPE_RS_NONE; w[5] = 0; w[6] = 0; w[7] = 0;
         }
-        if ((p.stages & HOPE_STAGE_RS) && t > 1 && rs_status == HOPE_STATUS_CONTINUE) {    // gate :293-294
+        if (p.stages & HOPE_STAGE_RS) {                                                    // gate :293-294
+            // (one global atomicAdd per scene on a single queue counter cost ~45 us per 32 768 scenes: every XCD's
+            // atomics meet at the memory side; a flag and a compaction pass do not)
             double ddx = x - destx, ddy = y - desty;
-            if (sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST) {
-                int slot = atomicAdd(p.rs_count, 1);
-                p.rs_list[slot] = scene;
-            }
+            p.rs_flag[scene] = t > 1 && rs_status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
         }
     }
     if (p.out.rs_lengths && lane < 5) ((OT*)p.out.rs_lengths)[5 * (size_t)scene + lane] = (OT)0;

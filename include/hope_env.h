@@ -162,7 +162,8 @@ int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
 #define HOPE_K_RS_VALIDATE 3   /* k_rs_validate  (wave per queued scene; per tile class)     */
 #define HOPE_K_IMAGE 4         /* k_bev_image    (wave per scene tile: 16 per scene)         */
 #define HOPE_K_IMAGE_PREP 5    /* k_bev_prep     (wave per scene: map + new boxes' spans)    */
-#define HOPE_N_KERNELS 6
+#define HOPE_K_RS_COMPACT 6    /* k_rs_compact   (Reeds-Shepp work queues from per-scene flags) */
+#define HOPE_N_KERNELS 7
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
 

@@ -199,6 +199,7 @@ def test_restart_and_profile_api():
     assert km['k_kinematics'][1] == 5 and km['k_env_step'][1] in (7, 14)
     assert km['k_rs_validate'][1] in (7, 14) and km['k_rs_words'][1] in (7, 14) and all(v[0] > 0 for k, v in km.items() if not k.startswith('k_bev'))
     assert km['k_bev_image'] == (0.0, 0) and km['k_bev_prep'] == (0.0, 0)      # handle created without image=True
+    assert km['k_rs_compact'][1] == 7                                          # one queue-compaction launch per call
     assert all(v == (0.0, 0) for v in env.kernel_ms().values())
     # state upload round trip
     env.upload_state(pose=pose, t=t, accum=acc)
