@@ -444,7 +444,6 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
-    if (stages & HOPE_STAGE_RS) HIPCHK(hipMemsetAsync(h->rs_count, 0, 2 * sizeof(int32_t), s));
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 block(WAVE);
     const bool prof = h->flags & HOPE_F_PROFILE;
@@ -461,12 +460,15 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     // one launch per tile class: scenes with few obstacles get a small LDS tile and therefore more resident
     // waves; a wave whose scene belongs to the other class exits at once
     const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
+    bool zeroed = false;
     for (int c = 0; c < n_cls; c++) {
         if (h->cls_count[c] == 0) continue;
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.scene_list = h->cls_list[c];
         p.n_list = h->cls_count[c];
         p.rs_flag = h->rs_flag;
+        p.rs_count_zero = ((stages & HOPE_STAGE_RS) && !zeroed) ? h->rs_count : nullptr;   // cleared by the step's first launch
+        zeroed = true;
         const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
         if (tm) tm->begin(HOPE_K_STEP, s);
