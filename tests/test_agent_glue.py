@@ -115,3 +115,26 @@ def test_rollout_storage_order_and_next_state_semantics():
     assert (b['next_obs']['lidar'][ok][:, 0] == b['obs']['lidar'][ok][:, 0] + 1).all()
     st.clear()
     assert st.size == 0
+
+
+def test_load_reference_checkpoint_without_the_reference_on_the_path():
+    """tests/golden/ref_checkpoint.pt pickles the reference's own model.state_norm.StateNorm by module path
+    (make_checkpoint.py); hope_amd.checkpoint reads it with `model` NOT importable"""
+    import os
+    import sys
+    import torch
+    from conftest import GOLD
+    from hope_amd.checkpoint import load_hope_checkpoint
+    assert 'model' not in sys.modules and not any(p.endswith('reference/src') for p in sys.path)
+    ck = load_hope_checkpoint(os.path.join(GOLD, 'ref_checkpoint.pt'))
+    e = np.load(os.path.join(GOLD, 'ref_checkpoint_expect.npz'))
+    assert set(ck['state_dicts']) == {'actor_net', 'critic_net1'}
+    assert np.array_equal(ck['state_dicts']['actor_net']['weight'].numpy(), e['actor_weight'])
+    assert ck['log_std'].shape == (1, 2)
+    sn = ck['state_norm']
+    assert sn.n_state == int(e['n_state']) and sn.modal == ('lidar', 'target')
+    assert np.allclose(sn.mean['lidar'].numpy(), e['mean_lidar']) and np.allclose(sn.std['target'].numpy(), e['std_target'])
+    obs = {'lidar': torch.ones(2, 120), 'target': torch.zeros(2, 5), 'action_mask': torch.ones(2, 42)}
+    out = sn.normalize(obs)
+    assert np.allclose(out['lidar'][0].numpy(), (1.0 - e['mean_lidar']) / (e['std_lidar'] + 1e-8), atol=1e-6)
+    assert torch.equal(out['action_mask'], obs['action_mask'])
