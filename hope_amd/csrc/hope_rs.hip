@@ -673,7 +673,10 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
                 } else pd = t;                                // all 64 inside: keep walking
             }
             wsync();
-            const int n = nq;
+            // only whole waves of samples are tested while the path goes on; the remainder (< 64) stays queued and is
+            // topped up by the next segments, so every pass but the path's last runs with all 64 lanes busy
+            const int n_all = nq;
+            const int n = finished ? n_all : (n_all & ~(WAVE - 1));
             // coarse pass: every `stride`-th sample with stride = ceil(n / 64), i.e. as dense as one full-wave pass
             // allows (a fixed stride of 8 left 3/4 of the lanes idle on a 130-sample window)
             const int stride = (n + WAVE - 1) / WAVE;
@@ -699,7 +702,15 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
                     break;
                 }
             }
-            nq = 0;
+            {   // carry the untested tail to the front of the queue
+                const int rem = n_all - n;
+                double cd = 0;
+                unsigned char cs = 0;
+                if (lane < rem) { cd = qpd[n + lane]; cs = qseg[n + lane]; }
+                wsync();
+                if (lane < rem) { qpd[lane] = cd; qseg[lane] = cs; }
+                nq = rem;
+            }
             wsync();
         }
         if (!invalid) { found = idx - 1; break; }
