@@ -623,7 +623,8 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
         // of generate_local_course.
         // window size: generate <= 130 samples, test them, continue (measured best of 66/130/258/512: larger windows
         // lose the early exit on invalid paths, smaller ones pay more partially filled passes)
-        const int win = (obs_f64 >> 12) ? (obs_f64 >> 12) : 130;
+        // (at least 129: the generator must always be able to bring the queue to a whole wave of 64 samples)
+        const int win = (obs_f64 >> 12) ? min(max(obs_f64 >> 12, 129), RSB_QCAP - WAVE - 1) : 130;
         int i = 0;
         bool seg_open = false, finished = false;
         double pd = 0, ll = 0.0, lprev = 0.0, d = 0, l = 0;
