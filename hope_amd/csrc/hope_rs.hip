@@ -513,12 +513,15 @@ constexpr int RSB_QCAP = 512;
 __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= *p.rs_count) return;
+    const int count = *p.rs_count;
+    if ((int)blockIdx.x >= count) return;
     if (obs_f64 & 0x400) return;                          // profiling switch: words kernel only
-    const int slot = p.slot_base + p.slot_dir * (int)blockIdx.x;
+    // the queue is sorted by scene: spread neighbouring (similar) scenes over the XCDs like the step kernel does
+    const int qidx = scene_of_block(blockIdx.x, count);
+    const int slot = p.slot_base + p.slot_dir * qidx;
     const int n_paths = p.rs_nwords[slot];
     if (n_paths == 0) return;
-    const int scene = p.rs_list[blockIdx.x];
+    const int scene = p.rs_list[qidx];
     const int n_obst = p.n_obst[scene];
     double* tile = lds;
     double* obb = lds + 8 * p.tile_cap;
