@@ -111,6 +111,11 @@ class ParkingBatch:
         L.check(self.lib.hope_env_kernel_ms(self.h, ms.ctypes.data, cnt.ctypes.data, int(reset)), 'hope_env_kernel_ms')
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(L.KERNELS)}
 
+    def profile_kernels(self, names=None):
+        """time only the listed kernels (names from _lib.KERNELS; None = all) -- every event pair costs launch latency"""
+        mask = 0xffffffff if names is None else sum(1 << L.KERNELS.index(k) for k in names)
+        L.check(self.lib.hope_env_profile_kernels(self.h, mask), 'hope_env_profile_kernels')
+
     def obs(self):
         return {'img': self.img, 'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
 

@@ -31,6 +31,7 @@ static int fail(int code, const std::string& msg) {
 struct hope_env {
     int n = 0, max_obst = 0, device = 0;
     uint32_t flags = 0;
+    uint32_t profile_mask = ~0u;   // HOPE_F_PROFILE: kernels (bit = HOPE_K_*) whose launches are bracketed by events
     bool have_tables = false, have_scenes = false;
     char arch[64] = {0};
     // device memory
@@ -79,14 +80,17 @@ struct EventTimer : LaunchTimer {
     hope_env* h;
     hipEvent_t a = nullptr, b = nullptr;
     int kind = 0;
-    bool failed = false;
+    bool failed = false, skip = false;
     explicit EventTimer(hope_env* h_) : h(h_) {}
     void begin(int k, hipStream_t s) override {
         kind = k;
+        skip = !((h->profile_mask >> k) & 1u);
+        if (skip) return;
         a = get_event(h); b = get_event(h);
         if (!a || !b || hipEventRecord(a, s) != hipSuccess) failed = true;
     }
     void end(hipStream_t s) override {
+        if (skip) return;
         if (failed || hipEventRecord(b, s) != hipSuccess) { failed = true; return; }
         h->pending.push_back({a, b, kind});
     }
@@ -533,6 +537,13 @@ int hope_env_kernel_ms(hope_env_t* h, double* ms, int64_t* launches, int reset) 
         if (launches) launches[k] = h->launches[k];
         if (reset) { h->ms[k] = 0; h->launches[k] = 0; }
     }
+    return HOPE_OK;
+}
+
+int hope_env_profile_kernels(hope_env_t* h, uint32_t kernel_mask) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_profile_kernels: null handle");
+    if (!(h->flags & HOPE_F_PROFILE)) return fail(HOPE_ESTATE, "hope_env_profile_kernels: handle was not created with HOPE_F_PROFILE");
+    h->profile_mask = kernel_mask;
     return HOPE_OK;
 }
 

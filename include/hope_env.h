@@ -166,6 +166,9 @@ int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
 #define HOPE_N_KERNELS 7
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
+/* Restricts the event bracketing to the kernels whose bit (1 << HOPE_K_*) is set; default all.  An event pair costs
+ * a few microseconds of launch latency, so a throughput measurement times only the kernel it reports on. */
+int hope_env_profile_kernels(hope_env_t *h, uint32_t kernel_mask);
 
 /* ---- state access (host-sync; tests, checkpointing) ------------------------------------------ */
 int hope_env_download_state(hope_env_t *h, double *pose /*[N][3]*/, int32_t *t /*[N]*/,
