@@ -204,3 +204,35 @@ def test_dropin_env_returns_the_image_like_the_reference():
         assert np.array_equal(obs['img'], orc.image()[0] / 255.0)
         assert 0.0 <= obs['img'].min() and obs['img'].max() <= 1.0
     env.close()
+
+
+def test_image_with_more_than_128_obstacles():
+    """max_obstacles > 128: the obstacles beyond the two register-resident chunks are converted again per tile"""
+    from hope_amd.scenes import Scene
+    rng = np.random.default_rng(4)
+    n = 150
+    verts = np.zeros((n, 4, 2))
+    k = 0
+    for gx in range(15):
+        for gy in range(10):
+            cx, cy = -14 + 2.0 * gx, -9 + 2.0 * gy
+            if abs(cx) < 4 and abs(cy) < 3:
+                cx += 30                                     # keep the start area free
+            a = rng.uniform(0, np.pi)
+            R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+            verts[k] = np.array([cx, cy]) + (np.array([[-0.5, -0.3], [0.5, -0.3], [0.5, 0.3], [-0.5, 0.3]]) @ R.T)
+            k += 1
+    scenes = [Scene(start=np.array([0.0, 0.0, h]), dest=np.array([3.0, 6.5, 1.0]), bbox=np.array([-20.0, 20.0, -20.0, 20.0]),
+                    verts=verts.copy(), nvert=np.full(n, 4, np.int32), level='Normal') for h in (0.2, 1.7, -2.4)]
+    env, orc = make_img_pair(scenes, max_obst=160)
+    env.reset_obs(); orc.reset_obs()
+    assert_images_equal(env, orc, '150 obstacles reset')
+    for it in range(4):
+        act = rng.uniform(-1, 1, (3, 2))
+        env.step(torch.from_numpy(act).to(env.device)); o = orc.step(act)
+        torch.cuda.synchronize()
+        assert np.array_equal(env.status.cpu().numpy(), o['status'])
+        assert_images_equal(env, orc, f'150 obstacles step {it}')
+    img = env.img.cpu().numpy()
+    assert (img == 150).any()                               # obstacles are visible
+    env.close()
