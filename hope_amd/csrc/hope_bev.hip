@@ -556,21 +556,37 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         const bool row_out0 = (unsigned)(4 * v + 1 + m.roy) >= (unsigned)WIN, row_out1 = (unsigned)(4 * v + 2 + m.roy) >= (unsigned)WIN;
         uint32_t ids[4] = {0, 0, 0, 0};                                       // 4 palette ids per output, one byte each
         const int dxx4 = m.dxx << 2, dyx4 = m.dyx << 2;
+        // the usual tile lies completely inside `rotate` and inside the source: no border tests, no clamps
+        const int rxa = 4 * TILE_OUT * tx + 1 + m.rox, rxb = rxa + 4 * TILE_OUT - 3, rya = 4 * TILE_OUT * ty + 1 + m.roy, ryb = rya + 4 * TILE_OUT - 3;
+        const bool plain = !need_bg && rxa >= 0 && rxb < WIN && rya >= 0 && ryb < WIN;      // wave-uniform
+        if (plain) {
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
+            for (int jj = 0; jj < 4; jj++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int ax_ = 4 * jj + (s & 1), ay_ = s >> 1;               // crop offset from the lane's first sample
-                const int dx = dxb + ((s & 1) ? m.dxx : 0) + (ay_ ? m.dxy : 0), dy = dyb + ((s & 1) ? m.dyx : 0) + (ay_ ? m.dyy : 0);
-                const bool white = (unsigned)(4 * u0 + 1 + ax_ + m.rox) >= (unsigned)WIN || (ay_ ? row_out1 : row_out0);
-                const bool outside = (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
-                const int sx = min(max(dx >> 16, w.x0), wx1), sy = min(max(dy >> 16, w.y0), wy1);
-                int id = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0];
-                id = outside ? bg_id : id;                                    // rotate()'s bgcolor
-                id = white ? 0 : id;                                          // observation.fill(BG_COLOR) -> black later
-                ids[jj] |= (uint32_t)id << (8 * s);
+                for (int s = 0; s < 4; s++) {
+                    const int dx = dxb + ((s & 1) ? m.dxx : 0) + ((s >> 1) ? m.dxy : 0), dy = dyb + ((s & 1) ? m.dyx : 0) + ((s >> 1) ? m.dyy : 0);
+                    const int id = fb[__mul24((dy >> 16) - w.y0, FB_STRIDE) + (dx >> 16) - w.x0];
+                    ids[jj] |= (uint32_t)id << (8 * s);
+                }
+                dxb += dxx4; dyb += dyx4;                                     // next output: 4 crop pixels to the right
             }
-            dxb += dxx4; dyb += dyx4;                                         // next output: 4 crop pixels to the right
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int ax_ = 4 * jj + (s & 1), ay_ = s >> 1;           // crop offset from the lane's first sample
+                    const int dx = dxb + ((s & 1) ? m.dxx : 0) + (ay_ ? m.dxy : 0), dy = dyb + ((s & 1) ? m.dyx : 0) + (ay_ ? m.dyy : 0);
+                    const bool white = (unsigned)(4 * u0 + 1 + ax_ + m.rox) >= (unsigned)WIN || (ay_ ? row_out1 : row_out0);
+                    const bool outside = (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
+                    const int sx = min(max(dx >> 16, w.x0), wx1), sy = min(max(dy >> 16, w.y0), wy1);
+                    int id = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0];
+                    id = outside ? bg_id : id;                                // rotate()'s bgcolor
+                    id = white ? 0 : id;                                      // observation.fill(BG_COLOR) -> black later
+                    ids[jj] |= (uint32_t)id << (8 * s);
+                }
+                dxb += dxx4; dyb += dyx4;
+            }
         }
         uint32_t out_r = 0, out_g = 0, out_b = 0;
 #pragma unroll
