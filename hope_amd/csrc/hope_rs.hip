@@ -624,10 +624,11 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
         // obstacle has long runs of bad samples -- so a strided subset that fills one wave goes first and only clean
         // windows pay for the remaining samples.  Exact: all of them are real samples
         // of generate_local_course.
-        // window size: generate <= 130 samples, test them, continue (measured best of 66/130/258/512: larger windows
-        // lose the early exit on invalid paths, smaller ones pay more partially filled passes)
-        // (at least 129: the generator must always be able to bring the queue to a whole wave of 64 samples)
-        const int win = (obs_f64 >> 12) ? min(max(obs_f64 >> 12, 129), RSB_QCAP - WAVE - 1) : 130;
+        // window size 128: the generator runs while fewer than 64 samples are queued, so every test is one whole wave
+        // (64 samples in path order) as early as possible -- invalid paths mostly hit something within their first
+        // metres (measured 128 / 130 / 160 / 194 / 258: 0.645 / 0.659 / 0.689 / 0.759 / 0.778 ms).  At least 128: the
+        // generator must always be able to bring the queue to a whole wave.
+        const int win = (obs_f64 >> 12) ? min(max(obs_f64 >> 12, 128), RSB_QCAP - WAVE - 1) : 128;
         int i = 0;
         bool seg_open = false, finished = false;
         double pd = 0, ll = 0.0, lprev = 0.0, d = 0, l = 0;
