@@ -234,6 +234,14 @@ __device__ __forceinline__ float wave_max_f(float v) {
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
 }
 
+__device__ __forceinline__ double wave_min_d(double v) {
+    v = fmin(v, __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true)));
+    v = fmin(v, __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xf, 0xf, true)));
+    v = fmin(v, __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x141, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), 0x141, 0xf, 0xf, true)));
+    v = fmin(v, __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x140, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), 0x140, 0xf, 0xf, true)));
+    return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
+}
+
 // is_traj_valid for the (up to 64) poses held one per lane: returns true on a lane whose pose is out of the
 // map box or whose hull meets an obstacle edge (line-line intersection inside both edge boxes, no tolerance).
 // Obstacles are culled per call: the union box of the active lanes' hulls is wave-reduced, one lane per
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 // Kernel B: find_rs_path's main loop (:436-450) over the ordered words
 // ================================================================================================
 // LDS (doubles): tile 8*M | obstacle boxes 4*M | segment params 5 x 8 | sample queue pd[512] | ints: cand[M] | bytes: seg[512]
-constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_WORDS = 562;
+constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_BAD = 562, RSB_WORDS = 568;
 constexpr int RSB_QCAP = 512;
 
 __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) {
@@ -554,6 +562,13 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     const RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
     double min_path_len = -1;
     int found = -1;
+    // Every path starts at the same pose, and the samples of its FIRST segment depend only on that segment's type and
+    // direction: pd = d, 2d, ... from the origin (0, 0, 0).  So a first-segment sample found in collision condemns every
+    // later word that starts with the same type and direction and is long enough to contain it (|l0| >= |pd|, the
+    // generator's own inclusion test) -- those words are skipped without being sampled.  bad1[type * 2 + forward].
+    double* bad1 = scr + RSB_BAD;                         // LDS, wave-uniform
+    if (lane < 6) bad1[lane] = INFINITY;
+    wsync();
     for (int idx = 1; idx <= n_paths; idx++) {
         const RsWord* W = words + p.rs_order[(size_t)slot * RS_WORDS_PER_SCENE + idx - 1];   // idx-th popped word
         const double Lm = W->Lm;
@@ -564,6 +579,8 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
         double len[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) len[i] = W->len[i];
+        const int cls1 = type_of(code, 0) * 2 + (len[0] > 0.0 ? 1 : 0);
+        if (!(obs_f64 & 0x800) && fabs(len[0]) >= bad1[cls1]) continue;    // contains a sample already known to collide
 
         // generate_local_course (:452-507).  Samples are queued as (pd, segment) and collision-tested 64 at a
         // time, so short segments share a pass.  Sample 0 (the start pose, local (0,0,0)) = segment 0 at pd = 0.
@@ -702,7 +719,13 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
                 const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
                 const double wy = -s_q * px + c_q * py + q0y;
                 const double wyaw = pi_2_pi(pyaw + q0w);
-                if (!(obs_f64 & 0x100) && __any(pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane))) {
+                const bool hit = !(obs_f64 & 0x100) && pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane);
+                if (__any(hit)) {
+                    // remember the nearest colliding sample of the FIRST segment (re-read from the queue: rare path)
+                    const double mine1 = (hit && active && qseg[idx] == 0) ? fabs(qpd[idx]) : INFINITY;
+                    const double v = fmin(bad1[cls1], wave_min_d(mine1));
+                    wsync();
+                    if (lane < 6 && (lane == cls1 || v == 0.0)) bad1[lane] = fmin(bad1[lane], v);   // the start pose (pd = 0) is in every path
                     invalid = true;
                     break;
                 }
