@@ -257,8 +257,10 @@ def test_active_mask_leaves_scenes_untouched():
 
 
 def test_parity_stress_8k_scenes():
-    """larger randomized sweep (8192 mixed scenes x 20 steps, full step incl. RS) to surface rare knife-edge
-    disagreements between OCML and glibc; the oracle runs on all host cores (OpenMP build)."""
+    """larger randomized sweep (8192 mixed scenes x 20 steps, full step incl. RS, ~84 k RS searches): every output
+    exact.  (The classifier of the reference's ill-conditioned cases, rs_illcond.py, dates from when the kernels used
+    OCML and the oracle glibc; it now only produces the diagnostics if something does differ.)  The oracle runs on all
+    host cores (OpenMP build)."""
     from hope_amd import ParkingBatch
     from hope_amd.scenes import SceneSource, pack_scenes
     from oracle import oracle as O
@@ -316,7 +318,7 @@ def test_parity_stress_8k_scenes():
     print('stress:', s, 'rs evaluated', evaluated, 'ill-conditioned disagreements', excused, 'unexplained', unexplained)
     assert s['status_mismatch'] == 0 and s['mask_mismatch'] == 0
     assert not unexplained
-    assert excused <= max(3, evaluated // 2000)             # rare: < 0.05 % of the RS searches
+    assert excused == 0      # shared deterministic math: not even the reference's ill-conditioned cases may differ
     assert s['pose_err'] <= TOL64 and s['lidar_err'] <= TOL64 and s['reward_err'] <= TOL64 and s['rs_len_err'] <= TOL64
     s['seen'] = sorted(seen)
     assert set(s['seen']) >= {1, 2, 3}
