@@ -159,6 +159,11 @@ __device__ __forceinline__ int scene_of_block(int b, int n) {
     return b ^ ((b >> 3) & 7);
 }
 
+// lane l's value of a double (l must be wave-uniform): two v_readlane, no LDS round trip
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 // wave-uniform LDS synchronisation for a one-wave workgroup
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 

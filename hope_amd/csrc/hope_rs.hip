@@ -36,11 +36,6 @@ constexpr int NCAND = 46;
 
 enum { TS = 0, TL = 1, TR = 2 };
 
-// lane l's value of a wave-uniformly indexed double (l must be wave-uniform)
-__device__ __forceinline__ double readlane_d(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
 __device__ __forceinline__ double py_mod(double v, double w) {   // Python float %
     double m = hm_fmod(v, w);
     if (m != 0) { if ((w < 0) != (m < 0)) m += w; } else m = copysign(0.0, w);

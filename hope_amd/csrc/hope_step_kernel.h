@@ -484,9 +484,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             double dist_diff = sqrt(ddx * ddx + ddy * ddy);
             double pdx = prev_x - destx, pdy = prev_y - desty;
             double prev_dist_diff = sqrt(pdx * pdx + pdy * pdy);
-            double ad = hm_acos(hm_cos(h - desth));
+            // acos(cos(.)) of the current and the previous heading difference: one evaluation, two lanes
+            const double fold = hm_acos(hm_cos((lane & 1) ? prev_h - desth : h - desth));
+            double ad = readlane_d(fold, 0);
             ad = ad < PI / 2 ? ad : PI - ad;
-            double pad = hm_acos(hm_cos(prev_h - desth));
+            double pad = readlane_d(fold, 1);
             pad = pad < PI / 2 ? pad : PI - pad;
             const double dnorm = sc[SC_DNORM];
             ri2 = prev_dist_diff / dnorm - dist_diff / dnorm;
@@ -571,17 +573,22 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (!(p.stages & HOPE_STAGE_OBS)) return;
 
     // ---- target representation (_get_targt_repr :372-381; 5th entry is cos again) ---------------
-    if (p.out.target && lane == 0) {
+    if (p.out.target) {
         double rdx = destx - x, rdy = desty - y;
         double rel_distance = sqrt(rdx * rdx + rdy * rdy);
         double rel_angle = hm_atan2(rdy, rdx) - h;
         double rel_dest_heading = desth - h;
-        OT* tg = (OT*)p.out.target + 5 * (size_t)scene;
-        tg[0] = (OT)rel_distance;
-        tg[1] = (OT)hm_cos(rel_angle);
-        tg[2] = (OT)hm_sin(rel_angle);
-        tg[3] = (OT)hm_cos(rel_dest_heading);
-        tg[4] = (OT)hm_cos(rel_dest_heading);
+        double sv, cv;                                        // both angles through one sincos: lane 0 / lane 1
+        hm_sincos((lane & 1) ? rel_dest_heading : rel_angle, &sv, &cv);
+        const double cd = readlane_d(cv, 1);
+        if (lane == 0) {
+            OT* tg = (OT*)p.out.target + 5 * (size_t)scene;
+            tg[0] = (OT)rel_distance;
+            tg[1] = (OT)cv;
+            tg[2] = (OT)sv;
+            tg[3] = (OT)cd;
+            tg[4] = (OT)cd;
+        }
     }
 
     // ---- lidar (lidar_simulator.py:31-135) -----------------------------------------------------------
