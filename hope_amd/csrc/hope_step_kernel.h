@@ -480,19 +480,17 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         if (status == HOPE_STATUS_CONTINUE) {
             if (!have_ua) { ua = overlap_area(box, dbox, scr + LDS_SH, lane); have_ua = true; }
             ri0 = -hm_tanh((double)t / (10 * TOLERANT_TIME));
-            double ddx = x - destx, ddy = y - desty;
-            double dist_diff = sqrt(ddx * ddx + ddy * ddy);
-            double pdx = prev_x - destx, pdy = prev_y - desty;
-            double prev_dist_diff = sqrt(pdx * pdx + pdy * pdy);
-            // acos(cos(.)) of the current and the previous heading difference: one evaluation, two lanes
-            const double fold = hm_acos(hm_cos((lane & 1) ? prev_h - desth : h - desth));
-            double ad = readlane_d(fold, 0);
-            ad = ad < PI / 2 ? ad : PI - ad;
-            double pad = readlane_d(fold, 1);
-            pad = pad < PI / 2 ? pad : PI - pad;
+            // current (lane 0) and previous (lane 1) pose share every expensive step: one sqrt, one acos(cos(.)), two
+            // divisions instead of two of each
+            const bool prv = lane & 1;
+            const double ddx = (prv ? prev_x : x) - destx, ddy = (prv ? prev_y : y) - desty;
             const double dnorm = sc[SC_DNORM];
-            ri2 = prev_dist_diff / dnorm - dist_diff / dnorm;
-            ri3 = pad / PI - ad / PI;
+            const double dq = sqrt(ddx * ddx + ddy * ddy) / dnorm;               // dist / max(|dest - start|, 10)
+            double fold = hm_acos(hm_cos((prv ? prev_h : h) - desth));
+            fold = fold < PI / 2 ? fold : PI - fold;
+            const double aq = fold / PI;
+            ri2 = readlane_d(dq, 1) - readlane_d(dq, 0);
+            ri3 = readlane_d(aq, 1) - readlane_d(aq, 0);
             double bur = ua / (2 * dest_area - ua);
             if (bur < accum) bur = 0;
             else { double pa = accum; accum = bur; bur -= pa; }
