@@ -71,18 +71,18 @@ __device__ bool rs_SLS(double x, double y, double phi, double& t, double& u, dou
     }
     return false;
 }
-__device__ bool rs_LSL(double x, double y, double phi, double& t, double& u, double& v) {   // :79-87
+__device__ __forceinline__ bool rs_LSL(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) {   // :79-87
     double uu, tt;
-    rs_R(x - hm_sin(phi), y - 1.0 + hm_cos(phi), uu, tt);
+    rs_R(x - sphi, y - 1.0 + cphi, uu, tt);
     if (tt >= 0.0) {
         double vv = rs_M(phi - tt);
         if (vv >= 0.0) { t = tt; u = uu; v = vv; return true; }
     }
     return false;
 }
-__device__ bool rs_LSR(double x, double y, double phi, double& t, double& u, double& v) {   // :90-103
+__device__ __forceinline__ bool rs_LSR(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) {   // :90-103
     double u1, t1;
-    rs_R(x + hm_sin(phi), y - 1.0 - hm_cos(phi), u1, t1);
+    rs_R(x + sphi, y - 1.0 - cphi, u1, t1);
     u1 = u1 * u1;
     if (u1 >= 4.0) {
         double uu = sqrt(u1 - 4.0);
@@ -93,9 +93,9 @@ __device__ bool rs_LSR(double x, double y, double phi, double& t, double& u, dou
     }
     return false;
 }
-__device__ bool rs_LRL(double x, double y, double phi, double& t, double& u, double& v) {   // :106-117
+__device__ __forceinline__ bool rs_LRL(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) {   // :106-117
     double u1, t1;
-    rs_R(x - hm_sin(phi), y - 1.0 + hm_cos(phi), u1, t1);
+    rs_R(x - sphi, y - 1.0 + cphi, u1, t1);
     if (u1 <= 4.0) {
         double uu = -2.0 * hm_asin(0.25 * u1);
         double tt = rs_M(t1 + 0.5 * uu + PI);
@@ -104,17 +104,20 @@ __device__ bool rs_LRL(double x, double y, double phi, double& t, double& u, dou
     }
     return false;
 }
-__device__ void calc_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega) {
+__device__ __forceinline__ void calc_tauOmega(double u, double v, double xi, double eta, double phi, double& tau, double& omega) {
     double delta = rs_M(u - v);                                                             // :228-243
-    double A = hm_sin(u) - hm_sin(delta);
-    double B = hm_cos(u) - hm_cos(delta) - 1.0;
+    double su, cu, sd, cd;
+    hm_sincos(u, &su, &cu);
+    hm_sincos(delta, &sd, &cd);
+    double A = su - sd;
+    double B = cu - cd - 1.0;
     double t1 = hm_atan2(eta * A - xi * B, xi * A + eta * B);
-    double t2 = 2.0 * (hm_cos(delta) - hm_cos(v) - hm_cos(u)) + 3.0;
+    double t2 = 2.0 * (cd - cu - cu) + 3.0;          // cos(v) = cos(u): v = +-u and hm_cos is exactly even
     if (t2 < 0) tau = rs_M(t1 + PI); else tau = rs_M(t1);
     omega = rs_M(tau - u + v - phi);
 }
-__device__ bool rs_LRLRn(double x, double y, double phi, double& t, double& u, double& v) { // :246-257
-    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi);
+__device__ __forceinline__ bool rs_LRLRn(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) { // :246-257
+    double xi = x + sphi, eta = y - 1.0 - cphi;
     double rho = 0.25 * (2.0 + sqrt(xi * xi + eta * eta));
     if (rho <= 1.0) {
         double uu = hm_acos(rho), tt, vv;
@@ -123,8 +126,8 @@ __device__ bool rs_LRLRn(double x, double y, double phi, double& t, double& u, d
     }
     return false;
 }
-__device__ bool rs_LRLRp(double x, double y, double phi, double& t, double& u, double& v) { // :260-272
-    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi);
+__device__ __forceinline__ bool rs_LRLRp(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) { // :260-272
+    double xi = x + sphi, eta = y - 1.0 - cphi;
     double rho = (20.0 - xi * xi - eta * eta) / 16.0;
     if (0.0 <= rho && rho <= 1.0) {
         double uu = -hm_acos(rho);
@@ -136,8 +139,8 @@ __device__ bool rs_LRLRp(double x, double y, double phi, double& t, double& u, d
     }
     return false;
 }
-__device__ bool rs_LRSR(double x, double y, double phi, double& t, double& u, double& v) {  // :311-323
-    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi), rho, theta;
+__device__ __forceinline__ bool rs_LRSR(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) {  // :311-323
+    double xi = x + sphi, eta = y - 1.0 - cphi, rho, theta;
     rs_R(-eta, xi, rho, theta);
     if (rho >= 2.0) {
         double tt = theta, uu = 2.0 - rho, vv = rs_M(tt + 0.5 * PI - phi);
@@ -145,8 +148,8 @@ __device__ bool rs_LRSR(double x, double y, double phi, double& t, double& u, do
     }
     return false;
 }
-__device__ bool rs_LRSL(double x, double y, double phi, double& t, double& u, double& v) {  // :326-339
-    double xi = x - hm_sin(phi), eta = y - 1.0 + hm_cos(phi), rho, theta;
+__device__ __forceinline__ bool rs_LRSL(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) {  // :326-339
+    double xi = x - sphi, eta = y - 1.0 + cphi, rho, theta;
     rs_R(xi, eta, rho, theta);
     if (rho >= 2.0) {
         double r = sqrt(rho * rho - 4.0);
@@ -157,8 +160,8 @@ __device__ bool rs_LRSL(double x, double y, double phi, double& t, double& u, do
     }
     return false;
 }
-__device__ bool rs_LRSLR(double x, double y, double phi, double& t, double& u, double& v) { // :414-429
-    double xi = x + hm_sin(phi), eta = y - 1.0 - hm_cos(phi), rho, theta;
+__device__ __forceinline__ bool rs_LRSLR(double x, double y, double phi, double sphi, double cphi, double& t, double& u, double& v) { // :414-429
+    double xi = x + sphi, eta = y - 1.0 - cphi, rho, theta;
     rs_R(xi, eta, rho, theta);
     if (rho >= 2.0) {
         double uu = 4.0 - sqrt(rho * rho - 4.0);
@@ -194,8 +197,10 @@ __device__ __forceinline__ void interpolate(double l, int m, double ox, double o
         py = oy + l / MAXC * s_oy;
         pyaw = oyaw;
     } else {
-        double ldx = hm_sin(l) / MAXC;
-        double ldy = (m == TL) ? (1.0 - hm_cos(l)) / MAXC : (1.0 - hm_cos(l)) / (-MAXC);
+        double sl, cl;
+        hm_sincos(l, &sl, &cl);
+        double ldx = sl / MAXC;
+        double ldy = (m == TL) ? (1.0 - cl) / MAXC : (1.0 - cl) / (-MAXC);
         double gdx = c_noy * ldx + s_noy * ldy;          // hm_cos(-oyaw)*ldx + hm_sin(-oyaw)*ldy
         double gdy = -s_noy * ldx + c_noy * ldy;
         px = ox + gdx;
@@ -374,8 +379,10 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
         X = (c * dx + s * dy) * MAXC;
         Y = (-s * dx + c * dy) * MAXC;
     }
-    const double XB = X * hm_cos(PHI) + Y * hm_sin(PHI);    // "backwards" (:206-207, :376-377)
-    const double YB = X * hm_sin(PHI) - Y * hm_cos(PHI);
+    double sPHI, cPHI;                                        // hm_sincos is exactly odd / even: serves -PHI too
+    hm_sincos(PHI, &sPHI, &cPHI);
+    const double XB = X * cPHI + Y * sPHI;                    // "backwards" (:206-207, :376-377)
+    const double YB = X * sPHI - Y * cPHI;
 
     RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
     int hn = 0;                                               // heap size (meaningful on lane 0 of the quad)
@@ -389,18 +396,19 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
         const double sx = (q & 1) ? -bx : bx;
         const double sy = (q & 2) ? -by : by;
         const double sp = (q == 1 || q == 2) ? -PHI : PHI;
+        const double ssp = (q == 1 || q == 2) ? -sPHI : sPHI, csp = cPHI;
         double t = 0, u = 0, v = 0;
         bool ok = false;
         switch (g) {                                          // wave-uniform
             case 0: ok = (q == 0 || q == 2) && rs_SLS(sx, sy, sp, t, u, v); break;   // SCS (:120-130): q = 0, 2 only
-            case 1: ok = rs_LSL(sx, sy, sp, t, u, v); break;
-            case 2: ok = rs_LSR(sx, sy, sp, t, u, v); break;
-            case 3: case 4: ok = rs_LRL(sx, sy, sp, t, u, v); break;
-            case 5: ok = rs_LRLRn(sx, sy, sp, t, u, v); break;
-            case 6: ok = rs_LRLRp(sx, sy, sp, t, u, v); break;
-            case 7: case 9: ok = rs_LRSL(sx, sy, sp, t, u, v); break;
-            case 8: case 10: ok = rs_LRSR(sx, sy, sp, t, u, v); break;
-            default: ok = rs_LRSLR(sx, sy, sp, t, u, v); break;
+            case 1: ok = rs_LSL(sx, sy, sp, ssp, csp, t, u, v); break;
+            case 2: ok = rs_LSR(sx, sy, sp, ssp, csp, t, u, v); break;
+            case 3: case 4: ok = rs_LRL(sx, sy, sp, ssp, csp, t, u, v); break;
+            case 5: ok = rs_LRLRn(sx, sy, sp, ssp, csp, t, u, v); break;
+            case 6: ok = rs_LRLRp(sx, sy, sp, ssp, csp, t, u, v); break;
+            case 7: case 9: ok = rs_LRSL(sx, sy, sp, ssp, csp, t, u, v); break;
+            case 8: case 10: ok = rs_LRSR(sx, sy, sp, ssp, csp, t, u, v); break;
+            default: ok = rs_LRSLR(sx, sy, sp, ssp, csp, t, u, v); break;
         }
         ok = ok && live;
         int t0 = TL, t1 = TS, t2_ = TL, t3 = 0, t4 = 0, n = 3;
