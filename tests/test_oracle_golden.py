@@ -197,3 +197,47 @@ def test_target_reward_wrapper(gold):
                                   g['union_area'][i], float(g['dest_area']), g['accum_in'][i])
         assert np.abs(out - g['reward_list'][i]).max() < 1e-13
         assert abs(acc - g['accum_out'][i]) < 1e-15
+
+
+def test_find_rs_path_genuine_heapdict(gold, dlp):
+    """the same 160 searches, reference run with the GENUINE heapdict 1.0.1 (pure python, found under /opt/conda in the
+    build container) instead of tests/golden/refstubs/heapdict.py: pop order of equal-length words is the real one."""
+    s, h = gold('rs_search.npz'), gold('rs_search_heapdict.npz')
+    assert bool(h['identical_to_stub_run'])
+    for ri in range(len(s['case'])):
+        keep = s['keep'][s['keep_off'][ri]:s['keep_off'][ri + 1]]
+        v, nv = case_obstacles(dlp, int(s['case'][ri]), keep)
+        r = O.find_rs_path(s['pose'][ri], s['dest'][ri], v, nv, s['bbox'][ri])
+        assert r['found'] == bool(h['found'][ri]) and r['n_tested'] == int(h['n_tested'][ri]), ri
+        if r['found']:
+            assert np.array_equal(r['ctypes'], h['ctypes'][ri]), ri
+            assert np.abs(r['lengths'] - h['lengths'][ri]).max() < 1e-9
+
+
+def test_step_driver_control_flow(gold):
+    """CarParking.step / _check_status / get_reward / Vehicle.step / retreat executed from the reference's own source
+    (tests/golden/make_golden_r2.py gold_step_driver; only the GEOS predicates were answered by this oracle's
+    restatement): sub-step order, arrive-before-collide, retreat, status priority, t, reward gating, accumulator and
+    trajectory bookkeeping of the oracle's batch step must equal the reference's control flow on every step."""
+    g = gold('step_driver.npz')
+    n, mo = g['start'].shape[0], g['verts'].shape[1]
+    orc = O.BatchOracle(n, mo)
+    orc.set_scenes(np.arange(n), g['start'], g['dest'], g['bbox'], g['verts'], g['nvert'], g['n_obst'])
+    orc.t[:] = g['t0']
+    seen = set()
+    for k in range(g['actions'].shape[0] + 1):
+        o = orc.reset_obs(with_rs=False) if k == 0 else orc.step(g['actions'][k - 1], with_rs=False)
+        assert np.array_equal(o['status'], g['status'][k]), (k, np.nonzero(o['status'] != g['status'][k])[0])
+        assert np.array_equal(orc.t, g['t'][k])
+        assert np.abs(orc.pose - g['pose'][k]).max() < 1e-11, k
+        assert np.abs(o['reward_info'] - g['reward_info'][k]).max() < 1e-11, k
+        assert np.abs(orc.accum - g['accum'][k]).max() < 1e-12, k
+        tl = np.array([len(t) for t in orc.traj])
+        assert np.array_equal(np.minimum(tl, 21), np.minimum(g['traj_len'][k], 21)), k
+        if k > 0:                                   # a step that kept no sub-step leaves the trajectory alone
+            assert np.array_equal(o['substeps'] > 0, g['traj_len'][k] > g['traj_len'][k - 1]), k
+        seen |= set(o['status'].tolist())
+    assert seen == {1, 2, 3, 4, 5}
+    # the RS gate fired exactly where the reference's did (t > 1, CONTINUE, within RS_MAX_DIST)
+    d = np.hypot(g['pose'][..., 0] - g['dest'][None, :, 0], g['pose'][..., 1] - g['dest'][None, :, 1])
+    assert np.array_equal(g['rs_called'] > 0, (g['t'] > 1) & (g['status'] == 1) & (d < 10.0))
