@@ -30,7 +30,19 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--scenes', type=int, default=65536, help='scenes per GPU')
+    ap.add_argument('--scenes', type=int, default=65536, help='scenes per GPU (weak scaling) or in total (strong scaling)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: --scenes per GPU (default); strong: --scenes in total, split over the ranks '
+                         "(BASELINE config 4: 65 536 scenes over 8 GPUs = 8 192 per GPU)")
+    ap.add_argument('--policy', default='none', choices=['none', 'hope'],
+                    help="hope: drive the env with the reference-shaped transformer policy (hope_amd.policy) instead of "
+                         'random actions; value = env+agent steps/s (BASELINE configs 4 and 5)')
+    ap.add_argument('--algo', default='rollout', choices=['rollout', 'sac', 'ppo'],
+                    help='with --policy hope: rollout = inference only (config 4), sac = + SAC updates, ppo = PPO '
+                         'collect/update loop with RCCL gradient all-reduce (config 5)')
+    ap.add_argument('--horizon', type=int, default=8, help='PPO steps per update / SAC ring depth')
+    ap.add_argument('--mini-batch', type=int, default=16384, help='PPO mini-batch / SAC batch (transitions per rank)')
+    ap.add_argument('--mini-epoch', type=int, default=2, help='PPO epochs per update (reference: 10)')
     ap.add_argument('--max-obst', type=int, default=128)
     ap.add_argument('--mix', default='mixed', choices=['mixed', 'dlp', 'normal'])
     ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
@@ -90,6 +102,10 @@ def main():
     from hope_amd.scenes import pack_scenes
 
     N = args.scenes
+    if args.scaling == 'strong':
+        from hope_amd.dist import shard_range
+        lo, hi = shard_range(args.scenes, rank, world)
+        N = hi - lo
     rng = np.random.default_rng(args.seed + rank)
     uniq = make_scenes(min(N, args.unique), args.mix, rng)
     start, dest, bbox, verts, nob, nvert = pack_scenes(uniq, args.max_obst)
@@ -122,12 +138,28 @@ def main():
         # episode turnover is fused into the step (HOPE_AUTO_RESET = step + restart(done) + reset_obs(active=done))
         env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
 
+    trainer = None
+    if args.policy == 'hope':
+        # BASELINE configs 4 / 5: the transformer policy (stock PyTorch-ROCm) drives the env; gradients of the update
+        # are all-reduced in one fused bucket (hope_amd.dist) -- RCCL over xGMI when world > 1
+        from hope_amd import agents as A
+        from hope_amd.rollout import PPOTrainer, SACTrainer
+        torch.manual_seed(args.seed)                                  # identical initial weights on every rank
+        if args.algo == 'ppo':
+            agent = A.BatchedPPO(device=dev, use_img=args.image, mini_batch=args.mini_batch, mini_epoch=args.mini_epoch)
+            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank)
+        else:
+            agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
+            trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac')
+        one_step = lambda i: trainer.step()  # noqa: E731
+
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY
     # launch costs ~4 % of the step in launch latency (16 event records per step), so the other kernels are timed in a
     # short separate pass after it (ms_per_bench_step_by_kernel)
     dom = 'k_bev_image' if args.image else 'k_env_step'
     env.profile_kernels([dom])
-    env.reset_obs(stages=stages)
+    if trainer is None:
+        env.reset_obs(stages=stages)
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(dev)
@@ -159,7 +191,7 @@ def main():
 
     result = None
     if rank == 0:
-        total_scenes = N * world
+        total_scenes = N * world if args.scaling == 'weak' else args.scenes
         value = total_scenes * args.steps / elapsed
         # HIP events recorded by the library on the launch stream: around every launch of the roofline kernel inside the
         # timed region (dom_stats), around every launch of every kernel in the short pass after it (kstats).
@@ -200,7 +232,7 @@ def main():
         result = {
             'metric': 'parallel env steps/sec (full CarParking step incl. obs + RS search)', 'value': value,
             'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
@@ -214,7 +246,18 @@ def main():
                          'algorithmic_bytes_per_bench_step': bytes_per_launch,
                          'ms_per_bench_step_by_kernel': per_step, 'breakdown_steps': n_break},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if trainer is not None:
+            from hope_amd.policy import count_parameters
+            result['metric'] = 'env+agent steps/sec (full CarParking step + HOPE transformer policy' + \
+                {'rollout': ', inference only)', 'sac': ' + SAC updates)', 'ppo': ' + PPO updates)'}[args.algo]
+            result['config']['workload'] = result['config']['workload'].replace('random actions U[-1,1]^2', 'actions from the policy / RS replay')
+            result['config'].update({'policy': 'HopeNet (MultiObsEmbedding shape), random init', 'algo': args.algo,
+                                     'actor_params': count_parameters(trainer.agent.actor), 'use_img': bool(args.image),
+                                     'horizon': args.horizon, 'mini_batch': args.mini_batch,
+                                     'mini_epoch': args.mini_epoch if args.algo == 'ppo' else None,
+                                     'updates_in_run': trainer.updates, 'allreduce_bytes_total': trainer.agent.allreduce_bytes,
+                                     'rollout': trainer.stats()})
+        if not args.no_cpu_baseline and world == 1 and trainer is None:
             result['cpu_baseline'] = cpu_baseline(args, uniq, stages)
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,8 @@ class ParkingBatch:
             raise L.HopeError('ParkingBatch needs a HIP device (torch.cuda.is_available() is False); no CPU fallback')
         self.lib = L.load_library()
         self.device = torch.device(device)
+        if self.device.index is None:              # 'cuda' -> the current device, so that tensor.device == self.device
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.n, self.max_obst = int(n_scenes), int(max_obstacles)
         assert obs_dtype in (torch.float32, torch.float64) and action_dtype in (torch.float32, torch.float64)
         self.obs_dtype, self.action_dtype = obs_dtype, action_dtype
@@ -116,8 +118,13 @@ class ParkingBatch:
         mask = 0xffffffff if names is None else sum(1 << L.KERNELS.index(k) for k in names)
         L.check(self.lib.hope_env_profile_kernels(self.h, mask), 'hope_env_profile_kernels')
 
-    def obs(self):
-        return {'img': self.img, 'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
+    def obs(self, clone=False):
+        """the observation dict in the reference's key order (car_parking_base.py:399-407).  The tensors are this
+        object's persistent output buffers: the next step()/reset_obs() overwrites them IN PLACE (asynchronously), so
+        `obs = env.obs(); env.step(a); next_obs = env.obs()` aliases obs and next_obs -- pass clone=True (or copy what
+        you keep before stepping, as hope_amd.rollout does) when both are needed."""
+        o = {'img': self.img, 'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
+        return {k: (v.clone() if (clone and v is not None) else v) for k, v in o.items()}
 
     # -- state -------------------------------------------------------------------------------------
     def download_state(self):

@@ -1,10 +1,17 @@
-"""Batched rollout loop over N scenes: the N >> 1 counterpart of the episode loop in
-src/train/train_HOPE_ppo.py:177-213 / src/evaluation/eval_utils.py:16-84 with the hybrid controller of
-src/model/agent/parking_agent.py (replay a found Reeds-Shepp path, otherwise ask the policy).
+"""Batched rollout / training loops over N scenes: the N >> 1 counterparts of the episode loops in
+src/train/train_HOPE_ppo.py:177-213, src/train/train_HOPE_sac.py:177-221 and src/evaluation/eval_utils.py:16-84, with
+the hybrid controller of src/model/agent/parking_agent.py (replay a found Reeds-Shepp path, otherwise ask the policy).
 
-The policy network itself is out of this library's scope (it runs on stock PyTorch-ROCm); `StandInPolicy` is a
-small random-init MLP with the same inputs / outputs (lidar 120 + target 5 + action_mask 42 -> Gaussian over
-(steer, speed)) so that the loop can be exercised and timed end to end.
+  HopeRollout.collect_step   one env step of every scene: state-norm -> actor -> mask-weighted / Gaussian action (or the
+                             planner's) -> ParkingBatch.step(auto_reset) -> storage -> planner bookkeeping
+  PPOTrainer                 BASELINE config 5 (train_HOPE_ppo.py): T steps of all scenes, then BatchedPPO.update
+  SACTrainer                 BASELINE config 4 / train_HOPE_sac.py: [N, T] ring replay, one BatchedSAC.update every
+                             `update_every` steps once the ring holds `warmup` columns
+  BatchedRollout             round-1 loop with a stand-in MLP policy (kept for the examples)
+
+`env` is a `hope_amd.ParkingBatch` (HIP path) or anything with the same attributes (tests use a CPU fake).
+ParkingBatch's observation tensors are persistent buffers that the next step overwrites in place, so every loop
+copies what it keeps BEFORE stepping.
 """
 import torch
 
@@ -62,3 +69,157 @@ class BatchedRollout:
         ep = int(self.episodes.sum().item())
         return {'steps': self.steps, 'episodes': ep, 'success_rate': float(self.successes.sum().item()) / max(ep, 1),
                 'executing_rs': float(self.planner.executing.float().mean().item())}
+
+
+class TransitionRing:
+    """[N, T] device ring of (normalised obs, action, log_prob, reward, done): the batched ReplayMemory
+    (src/model/replay_memory.py:6-49).  A column is written in two halves -- what the agent saw and did before the env
+    step, what the env answered after it."""
+
+    def __init__(self, n, horizon, keys, device, img_shape=(3, 64, 64)):
+        self.n, self.T, self.device = n, horizon, torch.device(device)
+        shp = {'lidar': (120,), 'target': (5,), 'action_mask': (42,), 'img': tuple(img_shape)}
+        self.obs = {k: torch.zeros((n, horizon) + shp[k], dtype=torch.uint8 if k == 'img' else torch.float32, device=self.device)
+                    for k in keys}
+        self.action = torch.zeros((n, horizon, 2), dtype=torch.float32, device=self.device)
+        self.log_prob = torch.zeros((n, horizon, 2), dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros((n, horizon), dtype=torch.float32, device=self.device)
+        self.done = torch.zeros((n, horizon), dtype=torch.float32, device=self.device)
+        self.head, self.size = 0, 0
+
+    def write_before(self, nobs, action, log_prob):
+        t = self.head
+        for k, buf in self.obs.items():
+            buf[:, t].copy_(nobs[k])
+        self.action[:, t].copy_(action)
+        self.log_prob[:, t].copy_(log_prob)
+
+    def write_after(self, reward, done):
+        t = self.head
+        self.reward[:, t].copy_(reward)
+        self.done[:, t].copy_(done)
+        self.head = (t + 1) % self.T
+        self.size = min(self.size + 1, self.T)
+
+    def columns(self):
+        """column indices oldest -> newest"""
+        return (torch.arange(self.size, device=self.device) + (self.head - self.size)) % self.T
+
+    def ordered(self):
+        idx = self.columns()
+        if self.size == self.T and self.head == 0:                      # the PPO case: no gather needed
+            return self.obs, self.action, self.reward, self.done, self.log_prob
+        return ({k: v[:, idx] for k, v in self.obs.items()}, self.action[:, idx], self.reward[:, idx], self.done[:, idx],
+                self.log_prob[:, idx])
+
+    def sample(self, batch_size, last_obs, generator=None):
+        """uniform (scene, time) transitions like ReplayMemory.sample (:33-35); the observation after the newest column
+        is `last_obs` (the one the agent is about to act on)."""
+        idx = self.columns()
+        s = torch.randint(self.n, (batch_size,), device=self.device, generator=generator)
+        j = torch.randint(self.size, (batch_size,), device=self.device, generator=generator)
+        t = idx[j]
+        newest = j == self.size - 1
+        tn = idx[torch.clamp(j + 1, max=self.size - 1)]
+        nxt = {}
+        for k, v in self.obs.items():
+            a = v[s, tn]
+            m = newest.view((-1,) + (1,) * (a.dim() - 1))
+            nxt[k] = torch.where(m, last_obs[k][s].to(a.dtype), a)
+        return {'obs': {k: v[s, t] for k, v in self.obs.items()}, 'next_obs': nxt, 'action': self.action[s, t],
+                'reward': self.reward[s, t], 'done': self.done[s, t]}
+
+    def clear(self):
+        self.head, self.size = 0, 0
+
+
+class HopeRollout:
+    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True):
+        self.env, self.agent, self.use_mask = env, agent, use_mask
+        dev = env.device
+        self.ring = TransitionRing(env.n, horizon, agent.keys, dev)
+        self.planner = G.BatchedRsPlanner(env.n, device=dev) if use_planner else None
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.episodes = torch.zeros((), dtype=torch.int64, device=dev)
+        self.successes = torch.zeros((), dtype=torch.int64, device=dev)
+        self.reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.steps = 0
+        env.reset_obs()
+        agent.observe(self._raw_obs())
+
+    def _raw_obs(self):
+        e = self.env
+        o = {'lidar': e.lidar, 'target': e.target, 'action_mask': e.action_mask}
+        if 'img' in self.agent.keys:
+            o['img'] = e.img
+        return o
+
+    @torch.no_grad()
+    def collect_step(self, random_action=False):
+        env, agent = self.env, self.agent
+        planned, executing = self.planner.get_actions() if self.planner is not None else (None, None)
+        action, log_prob, nobs = agent.act(self._raw_obs(), self.use_mask, self.gen, planned, executing)
+        if random_action:                             # train_HOPE_sac.py:196-198: uniform exploration while the memory fills
+            rnd = torch.rand(action.shape, device=action.device, generator=self.gen) * 2 - 1
+            action = rnd if executing is None else torch.where(executing.unsqueeze(1), action, rnd)
+            mean = agent.policy_mean(nobs)
+            from .policy import gaussian_log_prob
+            log_prob = gaussian_log_prob(mean, agent.log_std.expand_as(mean), action)
+        self.ring.write_before(nobs, action, log_prob)              # copies: env.step overwrites the buffers in place
+        env.step(action.to(env.action_dtype).contiguous(), auto_reset=True)
+        self.ring.write_after(env.reward, env.done)
+        agent.observe(self._raw_obs())                              # push_memory: state_norm(next_obs, update=True)
+        done = env.done.bool()
+        self.episodes += done.sum()
+        self.successes += (env.status == 2).sum()
+        self.reward_sum += env.reward.sum(dtype=torch.float64)
+        if self.planner is not None:
+            self.planner.reset(done)                                # ParkingAgent.reset at episode end
+            self.planner.set_paths(env.rs_word, env.rs_lengths)     # info['path_to_dest'] -> set_planner_path
+        self.steps += 1
+
+    def last_obs(self):
+        """normalised observation the agent will act on next (value bootstrap / newest next_obs)"""
+        return self.agent._norm_obs(self._raw_obs())
+
+    def stats(self):
+        ep = int(self.episodes.item())
+        return {'steps': self.steps, 'episodes': ep, 'success_rate': float(self.successes.item()) / max(ep, 1),
+                'mean_reward': float(self.reward_sum.item()) / max(self.steps * self.env.n, 1)}
+
+
+class PPOTrainer(HopeRollout):
+    """train_HOPE_ppo.py:177-213: act -> step -> push; when the buffer is full (`horizon` steps of all scenes,
+    the batched `len(memory) % batch_size == 0`) run PPO.update and clear."""
+
+    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True):
+        super().__init__(env, agent, horizon, use_mask=True, seed=seed, use_planner=use_planner)
+        self.updates = 0
+
+    def step(self):
+        self.collect_step()
+        if self.ring.size == self.ring.T:
+            obs, action, reward, done, log_prob = self.ring.ordered()
+            losses = self.agent.update(obs, action, reward, done, log_prob, self.last_obs(), generator=self.gen)
+            self.ring.clear()
+            self.updates += 1
+            return losses
+        return None
+
+
+class SACTrainer(HopeRollout):
+    """train_HOPE_sac.py:177-221: uniform random actions until the memory is full, then the policy (plain Gaussian
+    sample, no action mask), one SAC update every `update_every` env steps on a uniform batch from the ring."""
+
+    def __init__(self, env, agent, horizon=8, update_every=10, seed=0, use_planner=True, learn=True):
+        super().__init__(env, agent, horizon, use_mask=False, seed=seed, use_planner=use_planner)
+        self.update_every, self.learn, self.updates = update_every, learn, 0
+
+    def step(self):
+        self.collect_step(random_action=self.learn and self.ring.size < self.ring.T)
+        if self.learn and self.ring.size == self.ring.T and self.steps % self.update_every == 0:
+            batch = self.ring.sample(self.agent.batch_size, self.last_obs(), self.gen)
+            self.updates += 1
+            return self.agent.update(batch)
+        return None

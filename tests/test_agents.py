@@ -204,3 +204,76 @@ def test_ppo_update_two_ranks_equals_one_process():
         assert nbytes == 2 * nparam * 4                               # one fused bucket per mini-batch, every epoch
         assert (np.abs(pa - exp_a) / np.maximum(np.abs(exp_a[:, 1:2]), 1.0)).max() < 2e-4
         assert (np.abs(pc - exp_c) / np.maximum(np.abs(exp_c[:, 1:2]), 1.0)).max() < 2e-4
+
+
+# ---- the training loops on a CPU stand-in env (tests/fake_env.py drives the C oracle) --------------------------------
+def _small_scenes(n, seed=3):
+    from hope_amd.scenes import SceneSource
+    src = SceneSource(levels=('Normal', 'Complex', 'Extrem'), seed=seed)
+    return [src.draw() for _ in range(n)]
+
+
+def test_ppo_trainer_loop_cpu():
+    from fake_env import OracleEnv
+    from hope_amd.rollout import PPOTrainer
+    torch.manual_seed(0)
+    env = OracleEnv(_small_scenes(12))
+    ag = A.BatchedPPO(device='cpu', use_img=False, lr=1e-4, mini_batch=24, mini_epoch=2)
+    tr = PPOTrainer(env, ag, horizon=4, seed=1)
+    before = probe(ag.actor).numpy().copy()
+    out = [tr.step() for _ in range(8)]
+    assert [o is not None for o in out] == [False, False, False, True] * 2 and tr.updates == 2
+    assert np.isfinite(out[3]).all() and np.isfinite(out[7]).all()
+    assert np.abs(probe(ag.actor).numpy() - before).max() > 0           # the actor moved
+    assert tr.ring.size == 0 and ag.state_norm.n_state == 1 + 12 * 8 + 11   # first sample + every later observation
+    s = tr.stats()
+    assert s['steps'] == 8 and np.isfinite(s['mean_reward'])
+
+
+def test_sac_trainer_loop_cpu():
+    from fake_env import OracleEnv
+    from hope_amd.rollout import SACTrainer
+    torch.manual_seed(0)
+    env = OracleEnv(_small_scenes(8))
+    ag = A.BatchedSAC(device='cpu', use_img=False, lr=1e-4, batch_size=16)
+    tr = SACTrainer(env, ag, horizon=3, update_every=2, seed=1)
+    out = [tr.step() for _ in range(8)]
+    assert tr.updates == 3 and [o is not None for o in out] == [False, False, False, True, False, True, False, True]
+    assert all(np.isfinite(o).all() for o in out if o is not None)
+    # ring semantics: newest column's next-observation is the observation the agent acts on next
+    b = tr.ring.sample(64, tr.last_obs(), tr.gen)
+    assert b['obs']['lidar'].shape == (64, 120) and b['next_obs']['action_mask'].shape == (64, 42)
+
+
+def _loop_rank(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from fake_env import OracleEnv
+    from hope_amd.dist import shard_range
+    from hope_amd.rollout import PPOTrainer
+    torch.manual_seed(0)                                             # identical initial weights on every rank
+    ag = A.BatchedPPO(device='cpu', use_img=False, lr=1e-4, mini_batch=16, mini_epoch=1)
+    scenes = _small_scenes(8)
+    lo, hi = shard_range(len(scenes), rank, world)
+    tr = PPOTrainer(OracleEnv(scenes[lo:hi]), ag, horizon=4, seed=10 + rank)
+    for _ in range(4):
+        tr.step()
+    q.put((rank, probe(ag.actor).numpy(), probe(ag.critic).numpy(), tr.updates))
+    dist.destroy_process_group()
+
+
+def test_ppo_trainer_two_ranks_stay_in_sync():
+    """BASELINE config 5's structure on CPU: scenes sharded over 2 ranks, different rollouts, ONE fused gradient
+    all-reduce per mini-batch -> both ranks hold identical weights after the update."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_loop_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    [p.join(60) for p in ps]
+    assert res[0][3] == res[1][3] == 1
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

@@ -1,0 +1,156 @@
+"""-m gpu: the agent side of BASELINE configs 4 and 5 on the MI355X.
+
+  * the reference-generated vectors of tests/test_agents.py and tests/test_agent_glue.py, evaluated on `cuda`;
+  * BatchedRsPlanner fed with rs_word / rs_lengths as the HIP kernels write them;
+  * config 4's loop (SAC-style rollout with the transformer policy) at 8 192 scenes and config 5's loop (PPO, a few
+    updates) on one GPU, driving the HIP env through the C ABI;
+  * the same PPO loop as 2 ranks sharing the one GPU (gloo), gradients all-reduced: ranks stay bit-identical.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def test_policy_forward_and_updates_match_reference_on_gpu():
+    import test_agents as TA
+    TA.check_policy_forward('cuda', 2e-4)          # fp32 GEMMs on the GPU re-associate sums
+    TA.check_ppo_update('cuda', 1, tol=3e-3)
+    TA.check_ppo_update('cuda', 2, tol=3e-3)
+    TA.check_sac_update('cuda', tol=3e-3)
+
+
+def test_agent_glue_reference_vectors_on_gpu(gold):
+    import test_agent_glue as TG
+    g = gold('agent_glue.npz')
+    TG.check_rs_planner(g, 'cuda')
+    TG.check_choose_action(g, 'cuda')
+    TG.check_state_norm(g, 'cuda')
+
+
+def make_env(n, seed=5, image=False, levels=('Normal', 'Complex', 'Extrem', 'dlp'), near=True, unique=512):
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import SceneSource
+    rng = np.random.default_rng(seed)
+    src = SceneSource(levels=levels, seed=seed)
+    uniq = [src.draw() for _ in range(min(n, unique))]
+    if near:                                      # a third of the scenes start within RS range of the slot
+        for s in uniq[::3]:
+            r, a = rng.uniform(3.0, 9.0), rng.uniform(0, 2 * np.pi)
+            s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.4])
+    scenes = [uniq[i % len(uniq)] for i in range(n)]
+    env = ParkingBatch(n, 128, image=image)
+    for a in range(0, n, 4096):
+        env.set_scenes(np.arange(a, min(n, a + 4096)), scenes[a:a + 4096])
+    return env, scenes
+
+
+def test_rs_planner_on_kernel_words():
+    """f-4: rs_word / rs_lengths exactly as k_rs_validate writes them -> BatchedRsPlanner.expand == the reference's
+    RsPlanner.set_rs_path rule restated per scene in python (parking_agent.py:12-41)."""
+    from hope_amd import agent_glue as G
+    env, _ = make_env(2048, seed=9)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    env.reset_obs()
+    found_any = 0
+    for _ in range(6):
+        env.step(torch.rand((env.n, 2), device='cuda', generator=g) * 2 - 1)
+        word, lens = env.rs_word.clone(), env.rs_lengths.clone()
+        acts, cnt = G.BatchedRsPlanner.expand(word, lens)
+        w, l, acts, cnt = word.cpu().numpy(), lens.double().cpu().numpy(), acts.cpu().numpy(), cnt.cpu().numpy()
+        for i in np.nonzero(w[:, 6] > 0)[0][:200]:
+            exp = []
+            for c, x in zip(w[i, :int(w[i, 5])], l[i]):
+                steer, v = {1: 1.0, 0: 0.0, 2: -1.0}[int(c)], x / 1.25
+                if 1e-3 < abs(v) < 1:
+                    exp.append([steer, v])
+                elif abs(v) > 1:
+                    s = np.sign(v)
+                    while abs(v) > 1:
+                        exp.append([steer, s]); v -= s
+                    if abs(v) > 1e-3:
+                        exp.append([steer, v])
+            assert cnt[i] == len(exp) and np.allclose(acts[i, :cnt[i]], np.array(exp).reshape(-1, 2), atol=1e-12), i
+            found_any += 1
+    assert found_any > 50
+    env.close()
+
+
+def test_config4_sac_rollout_8192_scenes():
+    """BASELINE config 4 on one GPU's share: 8 192 scenes, transformer policy (909 778-parameter actor incl. the image
+    modality), SAC-style rollout with RS replay, replay ring, a few SAC updates."""
+    from hope_amd import agents as A, policy as P
+    from hope_amd.rollout import SACTrainer
+    torch.manual_seed(0)
+    env, _ = make_env(8192, image=True)
+    ag = A.BatchedSAC(device='cuda', use_img=True, batch_size=4096)
+    assert P.count_parameters(ag.actor) == 909778
+    tr = SACTrainer(env, ag, horizon=4, update_every=2, seed=3)
+    out = [tr.step() for _ in range(10)]
+    torch.cuda.synchronize()
+    assert tr.updates == 4 and all(np.isfinite(o).all() for o in out if o is not None)
+    s = tr.stats()
+    assert s['steps'] == 10 and np.isfinite(s['mean_reward']) and s['episodes'] > 0
+    assert float(tr.planner.executing.float().mean()) > 0            # some scenes replay a Reeds-Shepp path
+    assert ag.state_norm.n_state == 1 + 8192 * 10 + 8191
+    env.close()
+
+
+def test_config5_ppo_loop_one_gpu():
+    """BASELINE config 5 on one GPU's share: 16 384 env instances, PPO with the reference-shaped actor/critic,
+    horizon 4, two updates (clip, GAE per scene, critic target, fused-bucket all-reduce is a no-op at world 1)."""
+    from hope_amd import agents as A
+    from hope_amd.rollout import PPOTrainer
+    torch.manual_seed(0)
+    env, _ = make_env(16384)
+    ag = A.BatchedPPO(device='cuda', use_img=False, mini_batch=16384, mini_epoch=2)
+    w0 = ag.actor.embed_lidar[0].weight.detach().clone()
+    tr = PPOTrainer(env, ag, horizon=4, seed=3)
+    out = [tr.step() for _ in range(8)]
+    torch.cuda.synchronize()
+    assert tr.updates == 2 and np.isfinite(out[3]).all() and np.isfinite(out[7]).all()
+    assert float((ag.actor.embed_lidar[0].weight - w0).abs().max()) > 0
+    env.close()
+
+
+def _rank(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)                       # both ranks share the box's one GPU; gloo carries the collectives
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hope_amd import agents as A
+    from hope_amd.dist import shard_range
+    from hope_amd.rollout import PPOTrainer
+    from test_agents import probe
+    torch.manual_seed(0)
+    ag = A.BatchedPPO(device='cuda', use_img=False, mini_batch=2048, mini_epoch=1)
+    lo, hi = shard_range(2048, rank, world)
+    env, _ = make_env(hi - lo, seed=20 + rank)
+    tr = PPOTrainer(env, ag, horizon=4, seed=30 + rank)
+    for _ in range(4):
+        tr.step()
+    torch.cuda.synchronize()
+    q.put((rank, probe(ag.actor.cpu()).numpy(), probe(ag.critic.cpu()).numpy(), tr.updates, ag.allreduce_bytes))
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_ppo_loop_two_ranks_share_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda r: r[0])
+    [p.join(120) for p in ps]
+    assert res[0][3] == res[1][3] == 1 and res[0][4] > 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

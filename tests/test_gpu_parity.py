@@ -49,7 +49,9 @@ def compare(env, o, tol, stats, with_rs=False):
     torch.cuda.synchronize()
     st = env.status.cpu().numpy()
     stats['status_mismatch'] += int((st != o['status']).sum())
-    stats['mask_mismatch'] += int((np.abs(env.action_mask.double().cpu().numpy() - o['mask']) > 1e-6).any(axis=1).sum())
+    m = env.action_mask.cpu().numpy()
+    want = o['mask'] if m.dtype == np.float64 else o['mask'].astype(np.float32)      # float32 mode stores the rounded value
+    stats['mask_mismatch'] += int((m != want).any(axis=1).sum())
     stats['lidar_err'] = max(stats['lidar_err'], float(np.abs(env.lidar.double().cpu().numpy() - o['lidar']).max()))
     stats['target_err'] = max(stats['target_err'], float(np.abs(env.target.double().cpu().numpy() - o['target']).max()))
     stats['reward_err'] = max(stats['reward_err'], float(np.abs(env.reward.double().cpu().numpy() - o['reward']).max()))
