@@ -462,6 +462,10 @@ static double pt_seg_dist(double px, double py, double ax, double ay, double bx,
     return fabs(s) * sqrt(len2);
 }
 
+double orc_pt_seg_dist(double px, double py, double ax, double ay, double bx, double by) {
+    return pt_seg_dist(px, py, ax, ay, bx, by);
+}
+
 /* ===================================================================================== */
 /* lidar                                                                                 */
 /* ===================================================================================== */

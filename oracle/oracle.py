@@ -116,6 +116,13 @@ def segments_intersect(p1, p2, q1, q2):
     return bool(L.orc_segments_intersect(*map(float, (*p1, *p2, *q1, *q2))))
 
 
+def pt_seg_dist(p, a, b):
+    L = lib()
+    L.orc_pt_seg_dist.argtypes = [C.c_double] * 6
+    L.orc_pt_seg_dist.restype = C.c_double
+    return L.orc_pt_seg_dist(*map(float, (*p, *a, *b)))
+
+
 def ring_intersects(box, ring):
     ring = _f64(ring)
     nv = len(ring)
