@@ -50,7 +50,9 @@ class BatchedRsPlanner:
         types = rs_word[:, :5].to(torch.int64)
         used = types >= 0
         steer = torch.where(types == 1, 1.0, torch.where(types == 2, -1.0, 0.0)).to(torch.float64)   # L:1 S:0 R:-1
-        x = rs_lengths.to(torch.float64) / step_ratio
+        # a python-float divisor makes the GPU kernel multiply by the reciprocal (not correctly rounded): divide by a
+        # device tensor so that x equals the reference's `length / step_ratio` bit for bit on every device
+        x = rs_lengths.to(torch.float64) / torch.full((1,), float(step_ratio), dtype=torch.float64, device=dev)
         ax = x.abs()
         k = torch.where(ax > 1, torch.ceil(ax) - 1, torch.zeros_like(ax))             # unit actions
         rem = torch.where(ax > 1, torch.sign(x) * (ax - k), x)

@@ -17,10 +17,15 @@ Module attribute names are chosen so that `state_dict()` keys equal the referenc
 The policy is plain PyTorch by design (north_star: "the transformer + SAC/PPO policy runs on stock PyTorch-ROCm").
 """
 import math
+import os
 
-import torch
-import torch.nn as nn
-import torch.nn.functional as F
+# the image encoder's two small convolutions: take MIOpen's immediate-mode kernels instead of an exhaustive search at
+# first use (minutes on a fresh box for every new batch size)
+os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 LIDAR_NUM, TARGET_DIM, N_DISCRETE_ACTION = 120, 5, 42
 
