@@ -56,9 +56,7 @@ struct hope_env {
     int32_t* cls_list[2] = {nullptr, nullptr};
     int cls_count[2] = {0, 0};
     std::vector<int32_t> n_obst_host;
-    void* rs_words = nullptr;
-    uint8_t* rs_order = nullptr;
-    int32_t* rs_nwords = nullptr;
+    double* rs_rec = nullptr;
     // staging for set_scenes
     void* stage = nullptr;
     size_t stage_bytes = 0;
@@ -299,9 +297,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
     ALLOC(h->cls_list[0], N * sizeof(int32_t));
     ALLOC(h->cls_list[1], N * sizeof(int32_t));
-    ALLOC(h->rs_words, N * rs_words_bytes_per_scene());
-    ALLOC(h->rs_nwords, N * sizeof(int32_t));
-    ALLOC(h->rs_order, N * RS_WORDS_PER_SCENE);
+    ALLOC(h->rs_rec, N * rs_rec_bytes_per_scene());
     if (flags & HOPE_F_IMAGE) {
         ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
         ALLOC(h->traj_len, N * sizeof(int32_t));
@@ -338,7 +334,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_words, h->rs_nwords, h->rs_order, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_rec, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -498,7 +494,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
             r.slot_dir = (c == 0) ? 1 : -1;
             r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
             r.rs_count = h->rs_count + c; r.rs_list = h->rs_list + (size_t)c * h->n;
-            r.rs_words = (RsWord*)h->rs_words; r.rs_nwords = h->rs_nwords; r.rs_order = h->rs_order;
+            r.rs_rec = h->rs_rec;
             r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
             HIPCHK(launch_rs_search(r, s, tm));
         }

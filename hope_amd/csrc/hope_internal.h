@@ -12,8 +12,17 @@ struct RsWord {
     double Lm;       // path.L / maxc  [m]
     int code;        // packed segment types + count
     int n;
+    double pad;
 };
 constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generate_path
+// Per-search record, written by k_rs_words and read by k_rs_validate in ONE coalesced load (float64 words):
+//   [0] int2 (scene, n_obst)   [1] int2 (kept words, words the stop rule :443 lets find_rs_path test)
+//   [2..4] pose x, y, heading  [5..8] map box xmin, xmax, ymin, ymax   [9] unused
+//   [10..15] 48 bytes: push index of the k-th word heapdict pops (k < words to test)
+//   [16 + 8 i ..] word with push index i (RsWord)
+constexpr int RS_REC_HDR = 16;
+constexpr int RS_REC_ORDER = 10;
+constexpr int RS_REC_DOUBLES = RS_REC_HDR + 8 * RS_WORDS_PER_SCENE;
 
 struct RsParams {
     int n, max_obst;
@@ -27,9 +36,7 @@ struct RsParams {
     const double* state;      // [n][ST_WORDS]
     const int32_t* rs_count;  // [1]
     const int32_t* rs_list;   // [n]
-    RsWord* rs_words;         // [n][RS_WORDS_PER_SCENE] kept words of the queued scenes, indexed by candidate call index
-    uint8_t* rs_order;        // [n][RS_WORDS_PER_SCENE] heapdict pop order: call index of the k-th popped word
-    int32_t* rs_nwords;       // [n]
+    double* rs_rec;           // [n][RS_REC_DOUBLES] one record per queued scene (slot), see RS_REC_*
     int8_t* rs_word;          // [n][8]
     void* rs_lengths;         // real [n][5]
 };
@@ -61,7 +68,7 @@ struct LaunchTimer {
 // launches the Reeds-Shepp feasibility kernels over the scenes queued in rs_list (hope_rs.hip)
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);   // one tile class
 size_t rs_lds_bytes(int max_obst);
-size_t rs_words_bytes_per_scene();
+size_t rs_rec_bytes_per_scene();
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer);
 size_t bev_lds_bytes();
 

@@ -248,7 +248,7 @@ __device__ __forceinline__ double wave_min_d(double v) {
 // obstacle compares its precomputed box (obb, in LDS) with it, and only the survivors (cand[], usually 0-3)
 // are visited.  A pair whose boxes do not overlap cannot pass the reference's box tests, so this is exact.
 __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, double wyaw, const double* tile,
-                                          const double* obb, int* cand, int n_obst, double xmin, double xmax,
+                                          const float4* obb, int* cand, int n_obst, double xmin, double xmax,
                                           double ymin, double ymax, int lane) {
     bool bad = false;
     double vx[4], vy[4];
@@ -272,14 +272,13 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
     float ulox = active ? __double2float_rd(hminx) : INFINITY, uhix = active ? __double2float_ru(hmaxx) : -INFINITY;
     float uloy = active ? __double2float_rd(hminy) : INFINITY, uhiy = active ? __double2float_ru(hmaxy) : -INFINITY;
     ulox = wave_min_f(ulox); uhix = wave_max_f(uhix); uloy = wave_min_f(uloy); uhiy = wave_max_f(uhiy);
-    const double uminx = ulox, umaxx = uhix, uminy = uloy, umaxy = uhiy;
     int nc = 0;
     for (int base = 0; base < n_obst; base += WAVE) {
         int o = base + lane;
         bool near = false;
         if (o < n_obst) {
-            const double* bb = obb + 4 * o;
-            near = !(bb[0] > umaxx || bb[1] < uminx || bb[2] > umaxy || bb[3] < uminy);
+            const float4 bb = obb[o];                         // (xmin, xmax, ymin, ymax) rounded outwards: a superset
+            near = !(bb.x > uhix || bb.y < ulox || bb.z > uhiy || bb.w < uloy);
         }
         unsigned long long m = __ballot(near);
         if (near) cand[nc + __popcll(m & ((1ull << lane) - 1))] = o;
@@ -290,8 +289,8 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
     for (int ci = 0; ci < nc; ci++) {
         const int r = cand[ci];
         const double* o = tile + 8 * r;
-        const double* bb = obb + 4 * r;
-        bool near = active && !(bb[0] > hmaxx || bb[1] < hminx || bb[2] > hmaxy || bb[3] < hminy);
+        const float4 bb = obb[r];
+        bool near = active && !((double)bb.x > hmaxx || (double)bb.y < hminx || (double)bb.z > hmaxy || (double)bb.w < hminy);
         if (!__any(near)) continue;
         if (near) {
 #pragma unroll
@@ -384,8 +383,9 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     const double XB = X * cPHI + Y * sPHI;                    // "backwards" (:206-207, :376-377)
     const double YB = X * sPHI - Y * cPHI;
 
-    RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
-    int hn = 0;                                               // heap size (meaningful on lane 0 of the quad)
+    double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
+    RsWord* words = (RsWord*)(rec + RS_REC_HDR);              // stored by PUSH index (= order of being kept)
+    int hn = 0;                                               // words kept so far = heap size while pushing (all 4 lanes)
     double p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // previous family: my reflection's lengths, kept flag
     bool pk = false;
     const double hp = 0.5 * PI;
@@ -458,25 +458,25 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
             const int ek = (q & 2) ? quad_get<2>((int)kept) : quad_get<0>((int)kept);
             if (q & 1) kept = ok && !dup && !(ek && rs_dup(n, e0, e1, e2, e3, e4, l0, l1, l2, l3, l4)) && !(L >= MAX_LENGTH);
         }
-        const int cidx = g == 0 ? (q >> 1) : 2 + 4 * (g - 1) + q;   // call index of this candidate
         const double Lm = L / MAXC;                            // path.L / maxc (calc_all_paths :52)
-        if (kept) {
-            RsWord* w = words + cidx;
-            w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
-            w->Lm = Lm; w->code = code; w->n = n;
-        }
         // ---- costQueue[path] = path.L in path order (:432-433): lane 0 of the quad pushes the kept ones -----------
         {
             const int k0 = quad_get<0>((int)kept), k1 = quad_get<1>((int)kept), k2 = quad_get<2>((int)kept), k3 = quad_get<3>((int)kept);
             const double m0 = quad_get<0>(Lm), m1 = quad_get<1>(Lm), m2 = quad_get<2>(Lm), m3 = quad_get<3>(Lm);
+            if (kept) {                                       // my push index: kept words before me in call order
+                RsWord* w = words + hn + (q > 0 ? k0 : 0) + (q > 1 ? k1 : 0) + (q > 2 ? k2 : 0);
+                w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
+                w->Lm = Lm; w->code = code; w->n = n;
+            }
             if (q == 0) {
+                int hq = hn;
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) {
                     const int kk = qq == 0 ? k0 : (qq == 1 ? k1 : (qq == 2 ? k2 : k3));
                     if (!kk) continue;
                     const double pv = qq == 0 ? m0 : (qq == 1 ? m1 : (qq == 2 ? m2 : m3));
-                    int i = hn++;
-                    pr[ls][i] = pv; hid[ls][i] = (unsigned char)(g == 0 ? (qq >> 1) : 2 + 4 * (g - 1) + qq);
+                    int i = hq++;
+                    pr[ls][i] = pv; hid[ls][i] = (unsigned char)i;     // heap entries carry the push index
                     while (i) {                               // _decrease_key: swap unless parent < child
                         const int parent = (i - 1) >> 1;
                         if (pr[ls][parent] < pr[ls][i]) break;
@@ -486,16 +486,21 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
                     }
                 }
             }
+            hn += k0 + k1 + k2 + k3;
         }
         p0 = l0; p1 = l1; p2 = l2; p3 = l3; pk = kept;
     }
 
-    // ---- heapdict pop order ---------------------------------------------------------------------------------------
+    // ---- heapdict pop order, cut where find_rs_path's stop rule (:443) ends the search ------------------------------
     if (q == 0 && live) {
-        p.rs_nwords[slot] = hn;
-        unsigned char* ord = p.rs_order + (size_t)slot * RS_WORDS_PER_SCENE;
+        const int n_kept = hn;
+        unsigned char* ord = (unsigned char*)(rec + RS_REC_ORDER);
         int no = 0;
+        double lmin = 0;
         while (hn > 0) {                                      // popitem
+            const double lm = pr[ls][0];
+            if (no == 0) lmin = lm;
+            if (lm > 1.6 * lmin && no + 1 > 2) break;         // this word and every later one are never tested
             ord[no++] = hid[ls][0];
             if (hn == 1) { hn = 0; break; }
             hn--;
@@ -511,17 +516,25 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
                 i = low;
             }
         }
+        // header: everything k_rs_validate needs before it can stage the obstacle tile
+        ((int2*)rec)[0] = make_int2(scene, p.n_obst[scene]);
+        ((int2*)rec)[1] = make_int2(n_kept, no);
+        rec[2] = q0x; rec[3] = q0y; rec[4] = q0w;
+        rec[5] = sc[SC_BBOX]; rec[6] = sc[SC_BBOX + 1]; rec[7] = sc[SC_BBOX + 2]; rec[8] = sc[SC_BBOX + 3];
     }
 }
 
 // ================================================================================================
 // Kernel B: find_rs_path's main loop (:436-450) over the ordered words
 // ================================================================================================
-// LDS (doubles): tile 8*M | obstacle boxes 4*M | segment params 5 x 8 | sample queue pd[512] | ints: cand[M] | bytes: seg[512]
-constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_BAD = 562, RSB_WORDS = 568;
-constexpr int RSB_QCAP = 512;
+// LDS: tile 8*M doubles | obstacle boxes M float4 | scratch (doubles): segment params 5 x 10, sample queue pd[256], bad1[6+2],
+//      the head of the search record (header + 14 words) | ints: cand[M] | bytes: seg[256]
+constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_QCAP = 256, RSB_BAD = RSB_QPD + RSB_QCAP, RSB_REC = RSB_BAD + 8;
+constexpr int RSB_REC_WORDS = 14;                              // words of the record kept in LDS (two 512-byte loads)
+constexpr int RSB_WORDS = RSB_REC + RS_REC_HDR + 8 * RSB_REC_WORDS;
 
-__global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) {
+template <int OCC>
+__global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int count = *p.rs_count;
@@ -530,40 +543,42 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     // the queue is sorted by scene: spread neighbouring (similar) scenes over the XCDs like the step kernel does
     const int qidx = scene_of_block(blockIdx.x, count);
     const int slot = p.slot_base + p.slot_dir * qidx;
-    const int n_paths = p.rs_nwords[slot];
-    if (n_paths == 0) return;
-    const int scene = p.rs_list[qidx];
-    const int n_obst = p.n_obst[scene];
     double* tile = lds;
-    double* obb = lds + 8 * p.tile_cap;
-    double* scr = lds + 12 * p.tile_cap;
+    float4* obb = (float4*)(lds + 8 * p.tile_cap);
+    double* scr = lds + 10 * p.tile_cap;
     double* segp = scr + RSB_SEG;
     double* qpd = scr + RSB_QPD;
+    double* wl = scr + RSB_REC;                           // record head: header, pop order, first words
     int* cand = (int*)(scr + RSB_WORDS);
     unsigned char* qseg = (unsigned char*)(cand + ((p.tile_cap + 3) & ~3));
 
+    // ---- the search record: ONE coalesced 512-byte load brings the header, the pop order and the first 6 words ----
+    const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
+    const double r0 = rec[lane];
+    const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);      // words the stop rule lets the search test
+    if (n_paths == 0) return;
+    const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
+    const int n_obst = __builtin_amdgcn_readlane(__double2hiint(r0), 0);
+    wl[lane] = r0;
+    if (__builtin_amdgcn_readlane(__double2loint(r0), 1) > 6) wl[WAVE + lane] = rec[WAVE + lane];   // kept > 6: words with push index 6..13
     {
         const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
         double2* dst = (double2*)tile;
         for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
-        for (int o = lane; o < n_obst; o += WAVE) {           // obstacle boxes (xmin, xmax, ymin, ymax)
+        for (int o = lane; o < n_obst; o += WAVE) {           // obstacle boxes (xmin, xmax, ymin, ymax), rounded outwards
             const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
-            obb[4 * o] = fmin(fmin(v[0], v[2]), fmin(v[4], v[6]));
-            obb[4 * o + 1] = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
-            obb[4 * o + 2] = fmin(fmin(v[1], v[3]), fmin(v[5], v[7]));
-            obb[4 * o + 3] = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+            obb[o] = make_float4(__double2float_rd(fmin(fmin(v[0], v[2]), fmin(v[4], v[6]))),
+                                 __double2float_ru(fmax(fmax(v[0], v[2]), fmax(v[4], v[6]))),
+                                 __double2float_rd(fmin(fmin(v[1], v[3]), fmin(v[5], v[7]))),
+                                 __double2float_ru(fmax(fmax(v[1], v[3]), fmax(v[5], v[7]))));
         }
     }
-    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
-    const double* st = p.state + (size_t)scene * ST_WORDS;
-    const double q0x = st[0], q0y = st[1], q0w = st[2];
-    const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
+    const double q0x = readlane_d(r0, 2), q0y = readlane_d(r0, 3), q0w = readlane_d(r0, 4);
+    const double xmin = readlane_d(r0, 5), xmax = readlane_d(r0, 6), ymin = readlane_d(r0, 7), ymax = readlane_d(r0, 8);
     const double c_q = hm_cos(-q0w), s_q = hm_sin(-q0w);
     const double step = RS_STEP * MAXC;                   // step_size * maxc (:44)
     wsync();
 
-    const RsWord* words = p.rs_words + (size_t)slot * RS_WORDS_PER_SCENE;
-    double min_path_len = -1;
     int found = -1;
     // Every path starts at the same pose, and the samples of its FIRST segment depend only on that segment's type and
     // direction: pd = d, 2d, ... from the origin (0, 0, 0).  So a first-segment sample found in collision condemns every
@@ -572,16 +587,23 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     double* bad1 = scr + RSB_BAD;                         // LDS, wave-uniform
     if (lane < 6) bad1[lane] = INFINITY;
     wsync();
-    for (int idx = 1; idx <= n_paths; idx++) {
-        const RsWord* W = words + p.rs_order[(size_t)slot * RS_WORDS_PER_SCENE + idx - 1];   // idx-th popped word
-        const double Lm = W->Lm;
-        if (min_path_len < 0) min_path_len = Lm;
-        if (Lm > 1.6 * min_path_len && idx > 2) break;    // :443
+    const unsigned char* order = (const unsigned char*)(wl + RS_REC_ORDER);
+    for (int idx = 1; idx <= n_paths; idx++) {            // the stop rule (:443) is already applied: n_paths ends there
         if ((obs_f64 & 0x200) && idx > 1) break;          // profiling switch: first path only
-        const int code = W->code, nseg = W->n;
+        const int pi = order[idx - 1];                    // push index of the idx-th popped word
         double len[5];
+        int code, nseg;
+        if (pi < RSB_REC_WORDS) {                         // wave-uniform
+            const double* W = wl + RS_REC_HDR + 8 * pi;
 #pragma unroll
-        for (int i = 0; i < 5; i++) len[i] = W->len[i];
+            for (int i = 0; i < 5; i++) len[i] = W[i];
+            code = __double2loint(W[6]); nseg = __double2hiint(W[6]);
+        } else {
+            const double* W = rec + RS_REC_HDR + 8 * pi;
+#pragma unroll
+            for (int i = 0; i < 5; i++) len[i] = W[i];
+            code = __double2loint(W[6]); nseg = __double2hiint(W[6]);
+        }
         const int cls1 = type_of(code, 0) * 2 + (len[0] > 0.0 ? 1 : 0);
         if (!(obs_f64 & 0x800) && fabs(len[0]) >= bad1[cls1]) continue;    // contains a sample already known to collide
 
@@ -749,10 +771,12 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
     if (found < 0) return;
 
     // ---- output: PATH.ctypes / PATH.lengths (metres) of the first collision-free path ----------------
-    const RsWord* W = words + p.rs_order[(size_t)slot * RS_WORDS_PER_SCENE + found];
-    const int code = W->code, nseg = W->n;
+    const int pf = order[found];
+    const double* W = (pf < RSB_REC_WORDS) ? (const double*)(wl + RS_REC_HDR + 8 * pf) : rec + RS_REC_HDR + 8 * pf;
+    const double wlen = lane < 5 ? W[lane] : 0.0;
+    const int code = __double2loint(W[6]), nseg = __double2hiint(W[6]);
     if (lane < 5) {
-        double lm = lane < nseg ? W->len[lane] / MAXC : 0.0;      // path.lengths = [l / maxc ...] (:51)
+        double lm = lane < nseg ? wlen / MAXC : 0.0;              // path.lengths = [l / maxc ...] (:51)
         if (p.rs_lengths) {
             if (obs_f64 & 1) ((double*)p.rs_lengths)[5 * (size_t)scene + lane] = lm;
             else ((float*)p.rs_lengths)[5 * (size_t)scene + lane] = (float)lm;
@@ -766,15 +790,18 @@ __global__ __launch_bounds__(64, 3) void k_rs_validate(RsParams p, int obs_f64) 
 }  // namespace
 
 size_t rs_lds_bytes(int max_obst) {
-    return (size_t)(12 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP;
+    return (size_t)(10 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP;
 }
-size_t rs_words_bytes_per_scene() { return sizeof(RsWord) * RS_WORDS_PER_SCENE; }
+size_t rs_rec_bytes_per_scene() { return sizeof(double) * RS_REC_DOUBLES; }
 
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer) {
     if (p.max_queue <= 0) return hipSuccess;
     size_t lds = rs_lds_bytes(p.tile_cap);
+    // register budget of the validation kernel: 4 waves / SIMD (128 VGPRs, some spills) or 3 (168 VGPRs); HOPE_RS_OCC picks
+    static const int occ = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 3;   // the 4-wave build (50 spilled VGPRs) hung on the GPU: kept for experiments only
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(occ == 3 ? (const void*)k_rs_validate<3> : (const void*)k_rs_validate<4>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
@@ -783,7 +810,8 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->end(stream);
     static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
-    hipLaunchKernelGGL(k_rs_validate, dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    if (occ == 3) hipLaunchKernelGGL(k_rs_validate<3>, dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    else hipLaunchKernelGGL(k_rs_validate<4>, dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
