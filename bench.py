@@ -43,6 +43,10 @@ def parse():
     ap.add_argument('--horizon', type=int, default=8, help='PPO steps per update / SAC ring depth')
     ap.add_argument('--mini-batch', type=int, default=16384, help='PPO mini-batch / SAC batch (transitions per rank)')
     ap.add_argument('--mini-epoch', type=int, default=2, help='PPO epochs per update (reference: 10)')
+    ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (small batches: launch latency); '
+                    'per-kernel HIP events are unavailable then, the roofline is stated on the whole step')
+    ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
+                    help='launch chains of the two tile classes on two streams (auto = on)')
     ap.add_argument('--max-obst', type=int, default=128)
     ap.add_argument('--mix', default='mixed', choices=['mixed', 'dlp', 'normal'])
     ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
@@ -114,8 +118,9 @@ def main():
     stages = {'all': L.STAGE_ALL, 'norss': L.STAGE_MOTION | L.STAGE_OBS | L.STAGE_REWARD,
               'motion': L.STAGE_MOTION | L.STAGE_REWARD}[args.stages]
 
+    overlap = {'auto': None, 'on': True, 'off': False}[args.overlap]
     env = ParkingBatch(N, args.max_obst, device=str(dev), obs_dtype=torch.float32, action_dtype=torch.float32,
-                       profile=True, image=args.image)
+                       profile=not args.graph, image=args.image, overlap=overlap, graph=args.graph)
     chunk = 8192
     for a in range(0, N, chunk):
         b = min(N, a + chunk)
@@ -157,13 +162,15 @@ def main():
     # launch costs ~4 % of the step in launch latency (16 event records per step), so the other kernels are timed in a
     # short separate pass after it (ms_per_bench_step_by_kernel)
     dom = 'k_bev_image' if args.image else 'k_env_step'
-    env.profile_kernels([dom])
+    if not args.graph:
+        env.profile_kernels([dom])
     if trainer is None:
         env.reset_obs(stages=stages)
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(dev)
-    env.kernel_ms(reset=True)
+    if not args.graph:
+        env.kernel_ms(reset=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -175,13 +182,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    dom_stats = env.kernel_ms(reset=True)[dom]
-    env.profile_kernels(None)
     n_break = min(args.steps, 10)
-    for i in range(n_break):
-        one_step(args.warmup + args.steps + i)
-    torch.cuda.synchronize(dev)
-    kstats = env.kernel_ms(reset=True)
+    if args.graph:
+        # graph replay: no per-launch events; the roofline below is stated on the whole step
+        dom_stats = (elapsed * 1e3, args.steps)
+        kstats = {}
+    else:
+        dom_stats = env.kernel_ms(reset=True)[dom]
+        env.profile_kernels(None)
+        for i in range(n_break):
+            one_step(args.warmup + args.steps + i)
+        torch.cuda.synchronize(dev)
+        kstats = env.kernel_ms(reset=True)
     done_frac = float(env.done.float().mean().item())
     rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
     if dist is not None:
@@ -202,7 +214,9 @@ def main():
         # The roofline is stated for the kernel that moves the algorithmic bytes of §8(d): k_env_step (k_rs_validate
         # takes about the same time but only re-reads obstacle tiles); with --image it is k_bev_image, which is then
         # also the largest by time.  `largest_by_time` is reported next to it.
-        largest = max(per_step, key=per_step.get)
+        largest = max(per_step, key=per_step.get) if per_step else None
+        if args.graph:
+            dom = 'whole step (hipGraph replay)'
         dom_total_ms, dom_launches = dom_stats
         dom_ms = dom_total_ms / max(dom_launches, 1)
         bytes_avg_launch = bytes_per_launch * args.steps / max(dom_launches, 1)
@@ -237,6 +251,7 @@ def main():
             'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
+                       'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'kernel': dom, 'largest_by_time': largest,

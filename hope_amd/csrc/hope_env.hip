@@ -66,6 +66,39 @@ struct hope_env {
     std::vector<hipEvent_t> free_events;
     double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
     int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
+    // HOPE_F_OVERLAP: the two tile classes' launches go to two streams (fork / join with events)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // HOPE_F_GRAPH: the launches of one step, captured on a library stream and replayed while the arguments repeat
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    struct GraphKey {
+        const void* actions; const uint8_t* active; uint32_t stages; int has_action; hope_step_out out;
+        bool operator==(const GraphKey& o) const {
+            return actions == o.actions && active == o.active && stages == o.stages && has_action == o.has_action &&
+                   memcmp(&out, &o.out, sizeof(out)) == 0;
+        }
+    };
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec; uint64_t used; };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+};
+
+static void drop_graphs(hope_env* h) {
+    for (auto& g : h->graphs) hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+// every entry point runs on the handle's device and puts the caller's current device back (a process that drives
+// several GPUs keeps PyTorch's notion of the current device)
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
 };
 
 static hipEvent_t get_event(hope_env* h) {
@@ -254,6 +287,8 @@ int hope_abi_version(void) { return HOPE_ABI_VERSION; }
 
 int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int device_id, uint32_t flags) {
     if (!out || n_scenes <= 0 || max_obstacles <= 0) return fail(HOPE_EINVAL, "hope_env_create: bad argument");
+    if ((flags & HOPE_F_GRAPH) && (flags & HOPE_F_PROFILE))
+        return fail(HOPE_EINVAL, "hope_env_create: HOPE_F_GRAPH cannot be combined with HOPE_F_PROFILE (event timing inside a captured graph)");
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -323,6 +358,16 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    if (flags & (HOPE_F_OVERLAP | HOPE_F_GRAPH)) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    if (flags & HOPE_F_GRAPH) {
+        HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    }
     HIPCHK(hipDeviceSynchronize());
     *out = h;
     return HOPE_OK;
@@ -330,8 +375,13 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
 
 int hope_env_destroy(hope_env_t* h) {
     if (!h) return HOPE_OK;
-    hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     drain_events(h);
+    hipDeviceSynchronize();
+    drop_graphs(h);
+    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_in, h->ev_out}) if (e) hipEventDestroy(e);
+    if (h->side) hipStreamDestroy(h->side);
+    if (h->gstream) hipStreamDestroy(h->gstream);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
                     h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_rec, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
@@ -347,7 +397,8 @@ const char* hope_env_device_arch(const hope_env_t* h) { return h ? h->arch : "";
 
 int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double* hull_base, const double* beam_ab) {
     if (!h || !dist_star || !hull_base || !beam_ab) return fail(HOPE_EINVAL, "hope_env_upload_tables: null argument");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     // device layout: prefix-max over k (first exceedance of a sequence == first exceedance of its running
     // max: exact), transposed to [l][k][a] so that lane = action reads coalesced rows.
     std::vector<double> tab((size_t)NL * NITER * NACT), pmax(NL);
@@ -382,7 +433,8 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
         if (n_obst[k] < 0 || n_obst[k] > h->max_obst) return fail(HOPE_EINVAL, "hope_env_set_scenes: n_obst exceeds max_obstacles");
         if (n_obst[k] > 0 && !verts) return fail(HOPE_EINVAL, "hope_env_set_scenes: verts is null");
     }
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     size_t tile = (size_t)h->max_obst * 8 * sizeof(double);
     size_t o_ids = 0, o_nob = o_ids + sizeof(int32_t) * n, o_start = (o_nob + sizeof(int32_t) * n + 15) & ~(size_t)15;
     size_t o_dest = o_start + 24 * (size_t)n, o_bbox = o_dest + 24 * (size_t)n, o_verts = (o_bbox + 32 * (size_t)n + 15) & ~(size_t)15;
@@ -420,7 +472,85 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
         if (!l1.empty()) HIPCHK(hipMemcpy(h->cls_list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     HIPCHK(hipDeviceSynchronize());
+    drop_graphs(h);                                         // grids depend on the class sizes
     h->have_scenes = true;
+    return HOPE_OK;
+}
+
+// Enqueues the launches of one step on `s`.  With a side stream `s2` (HOPE_F_OVERLAP) the two tile classes run
+// concurrently: kinematics -> fork -> { k_env_step class 0 | class 1 } -> join -> k_rs_compact -> fork ->
+// { k_rs_words + k_rs_validate class 0 | class 1 } -> join -> image.  Every class kernel is latency-bound per wave, so at
+// <= 16 k scenes per GPU (BASELINE config 4: 8 192) one class alone cannot fill the 1024 SIMDs.
+static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages, const hope_step_out* out,
+                        hipStream_t s, hipStream_t s2, int has_action, LaunchTimer* tm) {
+    StepParams p;
+    p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
+    p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
+    p.actions = actions; p.active = active; p.kin = h->kin;
+    p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
+    p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
+    p.out = *out;
+    const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
+    dim3 block(WAVE);
+    if ((stages & HOPE_STAGE_MOTION) && has_action) {
+        dim3 kg((h->n + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
+        if (tm) tm->begin(HOPE_K_KINEMATICS, s);
+        if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
+        else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
+        if (tm) tm->end(s);
+    }
+    // One chain of launches per tile class (scenes with few obstacles get a small LDS tile and therefore more resident
+    // waves): k_env_step -> k_rs_compact -> k_rs_words -> k_rs_validate.  The chains share nothing but read-only data
+    // (own scene list, own queue counter, record slots filled from opposite ends), so with a side stream they run
+    // concurrently from the fork after the kinematics to the join before the image.
+    const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
+    const bool two = s2 && n_cls == 2 && h->cls_count[0] > 0 && h->cls_count[1] > 0;
+    const bool want_rs = (stages & HOPE_STAGE_RS) && out->rs_word;
+    if (two) { HIPCHK(hipEventRecord(h->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
+    for (int c = n_cls - 1; c >= 0; c--) {                  // the large-tile class first: its chain is the longer one
+        if (h->cls_count[c] == 0) continue;
+        hipStream_t sc = (two && c == 1) ? s2 : s;
+        p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
+        p.scene_list = h->cls_list[c];
+        p.n_list = h->cls_count[c];
+        p.rs_flag = h->rs_flag;
+        p.rs_count_zero = want_rs ? h->rs_count + c : nullptr;
+        const dim3 grid(p.n_list);
+        size_t lds = step_lds_bytes(p.tile_cap);
+        if (tm) tm->begin(HOPE_K_STEP, sc);
+        if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, sc, p);
+        else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, sc, p);
+        else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, sc, p);
+        else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
+        if (tm) tm->end(sc);
+        if (!want_rs) continue;
+        if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
+        hipLaunchKernelGGL(k_rs_compact, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, h->cls_list[c], h->cls_count[c],
+                           (const int32_t*)nullptr, 0, h->rs_flag, active, h->rs_list + (size_t)c * h->n, h->n, h->rs_count + c);
+        if (tm) tm->end(sc);
+        RsParams r;
+        r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
+        r.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
+        r.max_queue = h->cls_count[c];
+        r.slot_base = (c == 0) ? 0 : h->n - 1;              // the two classes fill the record storage from both ends
+        r.slot_dir = (c == 0) ? 1 : -1;
+        r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
+        r.rs_count = h->rs_count + c; r.rs_list = h->rs_list + (size_t)c * h->n;
+        r.rs_rec = h->rs_rec;
+        r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
+        HIPCHK(launch_rs_search(r, sc, tm));
+    }
+    HIPCHK(hipGetLastError());
+    if (two) { HIPCHK(hipEventRecord(h->ev_join, s2)); HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0)); }
+    if (stages & HOPE_STAGE_IMG) {
+        BevParams b;
+        b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
+        b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.traj_valid = h->traj_valid; b.scratch = h->bev_scratch; b.img = out->img;
+        // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
+        b.active = active;
+        b.debug = (stages >> 12) & 0xF;
+        HIPCHK(launch_bev_image(b, s, tm));
+    }
     return HOPE_OK;
 }
 
@@ -435,79 +565,49 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         if (!h->traj) return fail(HOPE_ESTATE, "hope_env_step: HOPE_STAGE_IMG needs a handle created with HOPE_F_IMAGE");
         if (!out->img) return fail(HOPE_EINVAL, "hope_env_step: HOPE_STAGE_IMG without out->img");
     }
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
-    StepParams p;
-    p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
-    p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
-    p.actions = actions; p.active = active; p.kin = h->kin;
-    p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
-    p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
-    p.out = *out;
-    const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
-    dim3 block(WAVE);
     const bool prof = h->flags & HOPE_F_PROFILE;
+    if (h->flags & HOPE_F_GRAPH) {
+        // The caller's stream may be the null stream, which cannot be captured: the graph lives on a library stream that
+        // is ordered after / before the caller's stream with two events.
+        hope_env::GraphKey key{actions, active, stages, has_action, *out};
+        hope_env::GraphEntry* hit = nullptr;
+        for (auto& g : h->graphs) if (g.key == key) { hit = &g; break; }
+        if (!hit) {
+            if (h->graphs.size() >= 64) {                    // evict the least recently used
+                size_t o = 0;
+                for (size_t i = 1; i < h->graphs.size(); i++) if (h->graphs[i].used < h->graphs[o].used) o = i;
+                hipGraphExecDestroy(h->graphs[o].exec);
+                h->graphs.erase(h->graphs.begin() + o);
+            }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_step(h, actions, active, stages, out, h->gstream, (h->flags & HOPE_F_OVERLAP) ? h->side : nullptr, has_action, nullptr);
+            hipError_t e = hipStreamEndCapture(h->gstream, &graph);
+            if (rc != HOPE_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return fail(HOPE_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            hipGraphExec_t exec = nullptr;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) return fail(HOPE_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            h->graphs.push_back({key, exec, 0});
+            hit = &h->graphs.back();
+        }
+        hit->used = ++h->graph_clock;
+        HIPCHK(hipEventRecord(h->ev_in, s));
+        HIPCHK(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+        HIPCHK(hipGraphLaunch(hit->exec, h->gstream));
+        HIPCHK(hipEventRecord(h->ev_out, h->gstream));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_out, 0));
+        return HOPE_OK;
+    }
     if (prof && h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
     EventTimer timer(h);
     LaunchTimer* tm = prof ? &timer : nullptr;
-    if ((stages & HOPE_STAGE_MOTION) && has_action) {
-        dim3 kg((h->n + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
-        if (tm) tm->begin(HOPE_K_KINEMATICS, s);
-        if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
-        else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
-        if (tm) tm->end(s);
-    }
-    // one launch per tile class: scenes with few obstacles get a small LDS tile and therefore more resident
-    // waves; a wave whose scene belongs to the other class exits at once
-    const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
-    bool zeroed = false;
-    for (int c = 0; c < n_cls; c++) {
-        if (h->cls_count[c] == 0) continue;
-        p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
-        p.scene_list = h->cls_list[c];
-        p.n_list = h->cls_count[c];
-        p.rs_flag = h->rs_flag;
-        p.rs_count_zero = ((stages & HOPE_STAGE_RS) && !zeroed) ? h->rs_count : nullptr;   // cleared by the step's first launch
-        zeroed = true;
-        const dim3 grid(p.n_list);
-        size_t lds = step_lds_bytes(p.tile_cap);
-        if (tm) tm->begin(HOPE_K_STEP, s);
-        if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, s, p);
-        else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, s, p);
-        else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, s, p);
-        if (tm) tm->end(s);
-    }
-    HIPCHK(hipGetLastError());
-    if ((stages & HOPE_STAGE_RS) && out->rs_word) {
-        if (tm) tm->begin(HOPE_K_RS_COMPACT, s);
-        hipLaunchKernelGGL(k_rs_compact, dim3(COMPACT_BLOCKS, n_cls), dim3(COMPACT_THREADS), 0, s, h->cls_list[0], h->cls_count[0],
-                           h->cls_list[1], h->cls_count[1], h->rs_flag, active, h->rs_list, h->n, h->rs_count);
-        if (tm) tm->end(s);
-        for (int c = 0; c < n_cls; c++) {
-            if (h->cls_count[c] == 0) continue;
-            RsParams r;
-            r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
-            r.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
-            r.max_queue = h->cls_count[c];
-            r.slot_base = (c == 0) ? 0 : h->n - 1;          // the two classes fill the word storage from both ends
-            r.slot_dir = (c == 0) ? 1 : -1;
-            r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
-            r.rs_count = h->rs_count + c; r.rs_list = h->rs_list + (size_t)c * h->n;
-            r.rs_rec = h->rs_rec;
-            r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
-            HIPCHK(launch_rs_search(r, s, tm));
-        }
-    }
-    if (stages & HOPE_STAGE_IMG) {
-        BevParams b;
-        b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
-        b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.traj_valid = h->traj_valid; b.scratch = h->bev_scratch; b.img = out->img;
-        // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
-        b.active = active;
-        b.debug = (stages >> 12) & 0xF;
-        HIPCHK(launch_bev_image(b, s, tm));
-    }
+    int rc = enqueue_step(h, actions, active, stages, out, s, (h->flags & HOPE_F_OVERLAP) ? h->side : nullptr, has_action, tm);
+    if (rc != HOPE_OK) return rc;
     if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
     return HOPE_OK;
 }
@@ -515,7 +615,8 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
 int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
     if (!h || !mask) return fail(HOPE_EINVAL, "hope_env_restart: null argument");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_restart: hope_env_set_scenes has not been called");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(k_restart, dim3((h->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->n, mask, h->scene_c,
                        h->state, h->tstep, h->traj, h->traj_len, h->traj_valid);
     HIPCHK(hipGetLastError());
@@ -525,7 +626,8 @@ int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
 int hope_env_kernel_ms(hope_env_t* h, double* ms, int64_t* launches, int reset) {
     if (!h) return fail(HOPE_EINVAL, "hope_env_kernel_ms: null handle");
     if (!(h->flags & HOPE_F_PROFILE)) return fail(HOPE_ESTATE, "hope_env_kernel_ms: handle was not created with HOPE_F_PROFILE");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     int rc = drain_events(h);
     if (rc) return rc;
     for (int k = 0; k < HOPE_N_KERNELS; k++) {
@@ -562,7 +664,8 @@ int hope_debug_math(int fn, int n, const double* a, const double* b, double* out
 
 int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* accum) {
     if (!h) return fail(HOPE_EINVAL, "hope_env_download_state: null handle");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     HIPCHK(hipDeviceSynchronize());
     std::vector<double> st((size_t)h->n * ST_WORDS);
     HIPCHK(hipMemcpy(st.data(), h->state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -576,7 +679,8 @@ int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* acc
 
 int hope_env_upload_state(hope_env_t* h, const double* pose, const int32_t* t, const double* accum) {
     if (!h) return fail(HOPE_EINVAL, "hope_env_upload_state: null handle");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     HIPCHK(hipDeviceSynchronize());
     std::vector<double> st((size_t)h->n * ST_WORDS);
     HIPCHK(hipMemcpy(st.data(), h->state, st.size() * sizeof(double), hipMemcpyDeviceToHost));

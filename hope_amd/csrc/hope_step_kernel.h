@@ -43,7 +43,7 @@ struct StepParams {
     const double* beam_ab;    // [NBEAM][2]
     hope_step_out out;
     uint8_t* rs_flag;         // [n] 1: the scene passes the Reeds-Shepp gate this step (k_rs_compact builds the queues)
-    int32_t* rs_count_zero;   // [2] queue counters to clear for k_rs_compact (first launch of a step only), else null
+    int32_t* rs_count_zero;   // this tile class's RS queue counter, cleared here for the k_rs_compact that follows; or null
 };
 
 // LDS per wave (doubles): tile 8*tile_cap | region A [320] | hb[10] cb[10] sb[10] px[10] py[10] | dest box[8] |
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= p.n_list) return;
-    if (p.rs_count_zero && blockIdx.x == 0 && threadIdx.x < 2) p.rs_count_zero[threadIdx.x] = 0;
+    if (p.rs_count_zero && blockIdx.x == 0 && threadIdx.x == 0) p.rs_count_zero[0] = 0;   // this class's queue length
     const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
     if (p.active && !p.active[scene]) return;
 

@@ -70,6 +70,11 @@ extern "C" {
 #define HOPE_F_ACTION_F64 0x2   /* action buffer is float64; default float32 */
 #define HOPE_F_PROFILE 0x4      /* record HIP events around every kernel launch (hope_env_kernel_ms) */
 #define HOPE_F_IMAGE 0x8        /* keep vehicle.trajectory (last 20 poses/scene) so that HOPE_STAGE_IMG can be used */
+#define HOPE_F_OVERLAP 0x10     /* launch the two obstacle-tile classes of a step on two streams (fork / join with events):
+                                   at <= 16 k scenes per GPU one class alone cannot fill the 1024 SIMDs */
+#define HOPE_F_GRAPH 0x20       /* capture the launches of a step into a hipGraph on a library stream (ordered against the
+                                   caller's stream with two events) and replay it while the arguments repeat: same
+                                   actions / active / out pointers and stages.  Not combinable with HOPE_F_PROFILE */
 
 /* hope_env_step stage mask */
 #define HOPE_STAGE_MOTION 0x1   /* kinematics + arrival + collision sub-step loop (CarParking.step :255-277) */

@@ -201,7 +201,7 @@ def test_restart_and_profile_api():
     assert km['k_kinematics'][1] == 5 and km['k_env_step'][1] in (7, 14)
     assert km['k_rs_validate'][1] in (7, 14) and km['k_rs_words'][1] in (7, 14) and all(v[0] > 0 for k, v in km.items() if not k.startswith('k_bev'))
     assert km['k_bev_image'] == (0.0, 0) and km['k_bev_prep'] == (0.0, 0)      # handle created without image=True
-    assert km['k_rs_compact'][1] == 7                                          # one queue-compaction launch per call
+    assert km['k_rs_compact'][1] == 14                                         # one queue-compaction launch per call and tile class
     assert all(v == (0.0, 0) for v in env.kernel_ms().values())
     # state upload round trip
     env.upload_state(pose=pose, t=t, accum=acc)
@@ -429,3 +429,35 @@ def test_full_size_properties_64k():
         if it == 3:
             assert np.array_equal(poseA1, poseA0) and np.array_equal(tA1, tA0 + 1)
     envA.close(); envB.close()
+
+
+def test_overlap_and_graph_modes_equal_the_plain_launch():
+    """HOPE_F_OVERLAP (two tile classes on two streams) and HOPE_F_GRAPH (hipGraph replay of the step) only change how
+    the same kernels are launched: every output must be bit-identical to the plain stream-ordered launch, including the
+    image, across steps with auto-reset and a changing action buffer."""
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import SceneSource
+    n = 3072
+    src = SceneSource(seed=5)
+    scenes = [src.draw() for _ in range(n)]
+    rng = np.random.default_rng(5)
+    for s in scenes[::2]:
+        r, a = rng.uniform(1.0, 8.0), rng.uniform(0, 2 * np.pi)
+        s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.5])
+    envs = [ParkingBatch(n, 128, overlap=ov, graph=gr, image=True) for ov, gr in ((False, False), (True, False), (True, True), (False, True))]
+    for e in envs:
+        e.set_scenes(np.arange(n), scenes)
+        e.reset_obs()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    names = ('lidar', 'action_mask', 'target', 'reward', 'reward_info', 'status', 'done', 'pose', 'rs_word', 'rs_lengths', 'img')
+    for it in range(14):
+        a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+        for e in envs:
+            e.step(a.clone() if it % 2 else a, auto_reset=True)
+        torch.cuda.synchronize()
+        for e in envs[1:]:
+            for k in names:
+                assert torch.equal(getattr(e, k), getattr(envs[0], k)), (it, k, e.overlap, e.graph)
+    assert len({int(x) for x in envs[0].status.unique().tolist()}) >= 2
+    for e in envs:
+        e.close()
