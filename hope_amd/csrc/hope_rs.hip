@@ -5,19 +5,20 @@
 //     (src/env/reeds_shepp.py:35-557) and CarParking.is_traj_valid (car_parking_base.py:452-534),
 // for the scenes the step kernel queued (gate :293-294: t > 1, CONTINUE, |pos - dest| < 10).
 //
-// Mapping onto the wave:
-//   1. the 46 word-solver calls of generate_path run one per lane (lanes 0..45);
-//   2. set_path's ORDER-DEPENDENT de-dup (signed length-sum test, :63-66) is replayed sequentially over
-//      the candidates with a cross-lane ballot; L = sum |len|, L >= 1000 dropped (:68-71);
-//   3. lane 0 replays heapdict's array heap (push order = path order, non-strict sift-up, strict
-//      sift-down) to obtain the pop order find_rs_path sees, ties included;
-//   4. for each popped path (stop rule :443) the samples of generate_local_course are produced 64 at a
-//      time: the `pd += d` chain is run in lock-step by all lanes (sequential rounding kept), each
-//      lane interpolates ITS sample, builds the 4 hull edges and tests them against the obstacle tile
-//      in LDS.  A (hull edge, obstacle edge) pair can only be a hit if the two edge bounding boxes
-//      overlap (the reference requires the intersection point inside both), so pairs failing that
-//      exact pre-test skip the two float64 divisions.  The reference's obstacle cull (:482-494) and
-//      its T x 4 x E matrix are result-neutral and are not materialised.
+// Two kernels per obstacle-tile class (details at each kernel):
+//   k_rs_words     FOUR LANES PER SCENE (16 searches per wave): the 12 solver families of generate_path run one after
+//                  the other, lane q of a quad evaluating reflection q, so the solver bodies never diverge; set_path's
+//                  order-dependent de-dup (:57-76) only compares words of equal type sequence, which are known
+//                  statically (quad broadcasts); lane 0 of the quad replays heapdict's array heap (push order = path
+//                  order, non-strict sift-up, strict sift-down) for the pop order find_rs_path sees, ties included,
+//                  and stops where the search's stop rule (:443) would; output = one record per search (RS_REC_*).
+//   k_rs_validate  ONE WAVE PER SEARCH: the record arrives in one coalesced load; for each popped word the samples of
+//                  generate_local_course are produced 64 at a time (`pd += d` chain in lock-step, sequential rounding
+//                  kept), each lane interpolates ITS sample, builds the 4 hull edges and tests them against the
+//                  obstacle tile in LDS.  A (hull edge, obstacle edge) pair can only be a hit if the two edge bounding
+//                  boxes overlap (the reference requires the intersection point inside both), so pairs failing that
+//                  exact pre-test skip the two float64 divisions.  The reference's obstacle cull (:482-494) and its
+//                  T x 4 x E matrix are result-neutral and are not materialised.
 // Deviation (documented in DESIGN.md): generate_local_course's "pop trailing samples whose local x is
 // exactly 0.0" (:501-505) is not replayed beyond the unused array tail (a measure-zero event).
 #include <stdlib.h>
