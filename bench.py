@@ -43,6 +43,11 @@ def parse():
     ap.add_argument('--horizon', type=int, default=8, help='PPO steps per update / SAC ring depth')
     ap.add_argument('--mini-batch', type=int, default=16384, help='PPO mini-batch / SAC batch (transitions per rank)')
     ap.add_argument('--mini-epoch', type=int, default=2, help='PPO epochs per update (reference: 10)')
+    ap.add_argument('--fresh-scenes', action='store_true',
+                    help='episode turnover on a NEW map (the reference draws a new case every episode): finished scenes draw '
+                         'from a device-resident pool of --pool generated scenes (hope_env_redraw + reset_obs inside the timed '
+                         'region); default = restart on the same map, fused into the step')
+    ap.add_argument('--pool', type=int, default=8192)
     ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (small batches: launch latency); '
                     'per-kernel HIP events are unavailable then, the roofline is stated on the whole step')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
@@ -143,6 +148,14 @@ def main():
         # episode turnover is fused into the step (HOPE_AUTO_RESET = step + restart(done) + reset_obs(active=done))
         env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
 
+    if args.fresh_scenes:
+        pool_scenes = make_scenes(args.pool, args.mix, rng)
+        env.set_pool(pool_scenes)
+
+        def one_step(i):  # noqa: F811
+            env.step(act_bank[i % len(act_bank)], stages=stages)
+            env.turnover(seed=args.seed * 7919 + i)
+
     trainer = None
     if args.policy == 'hope':
         # BASELINE configs 4 / 5: the transformer policy (stock PyTorch-ROCm) drives the env; gradients of the update
@@ -152,10 +165,11 @@ def main():
         torch.manual_seed(args.seed)                                  # identical initial weights on every rank
         if args.algo == 'ppo':
             agent = A.BatchedPPO(device=dev, use_img=args.image, mini_batch=args.mini_batch, mini_epoch=args.mini_epoch)
-            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank)
+            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=args.fresh_scenes)
         else:
             agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
-            trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac')
+            trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac',
+                                 fresh_scenes=args.fresh_scenes)
         one_step = lambda i: trainer.step()  # noqa: E731
 
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY
@@ -252,6 +266,8 @@ def main():
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
+                       'episode_turnover': (f'new map from a device-resident pool of {args.pool} scenes (hope_env_redraw + reset_obs)'
+                                            if args.fresh_scenes else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'kernel': dom, 'largest_by_time': largest,

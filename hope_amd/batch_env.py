@@ -58,6 +58,10 @@ class ParkingBatch:
         # obs['img'] * 255 as uint8, channel-first (env_wrapper.py:53-54); the reference's float image is img / 255
         self.img = torch.zeros((n, L.IMG_CHANNELS, L.IMG_SIZE, L.IMG_SIZE), dtype=torch.uint8, device=dev) if image else None
         self._act_buf = torch.zeros((n, 2), dtype=action_dtype, device=dev) if graph else None
+        self._done_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+        # observation-only view for turnover(): the finished step's reward / status / done / RS outputs are kept
+        self._out_obs = L.StepOut(self.lidar.data_ptr(), self.action_mask.data_ptr(), self.target.data_ptr(), None, None, None,
+                                  None, self.pose.data_ptr(), None, None, self.img.data_ptr() if image else None)
         self._out = L.StepOut(self.lidar.data_ptr(), self.action_mask.data_ptr(), self.target.data_ptr(),
                               self.reward.data_ptr(), self.reward_info.data_ptr(), self.status.data_ptr(),
                               self.done.data_ptr(), self.pose.data_ptr(), self.rs_word.data_ptr(),
@@ -79,6 +83,39 @@ class ParkingBatch:
         L.check(self.lib.hope_env_set_scenes(self.h, ids.ctypes.data, len(ids), a[0].ctypes.data, a[1].ctypes.data,
                                              a[2].ctypes.data, a[3].ctypes.data, nob.ctypes.data),
                 'hope_env_set_scenes')
+
+    def set_pool(self, scenes):
+        """upload a pool of complete scenes (list[Scene] or the tuple pack_scenes returns) that redraw() draws from"""
+        start, dest, bbox, verts, nob, _nv = pack_scenes(scenes, self.max_obst) if isinstance(scenes, list) else scenes
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (start, dest, bbox, verts)]
+        nob = np.ascontiguousarray(nob, dtype=np.int32)
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.hope_env_set_pool(self.h, len(nob), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+                                           a[3].ctypes.data, nob.ctypes.data), 'hope_env_set_pool')
+        self.pool_size = len(nob)
+
+    def redraw(self, mask, seed=0):
+        """map.reset for the flagged scenes: each takes a pool scene of its tile class and restarts (asynchronous)"""
+        assert mask.dtype == torch.uint8 and mask.shape == (self.n,) and mask.device == self.device
+        L.check(self.lib.hope_env_redraw(self.h, C.c_void_p(mask.data_ptr()), C.c_uint64(int(seed) & (2 ** 64 - 1)), self._stream()),
+                'hope_env_redraw')
+        return self
+
+    def turnover(self, seed=0):
+        """episode turnover with a NEW map, as the reference's training loop does (`env.reset(...)` after `done`):
+        finished scenes draw a pool scene and get their first observation; reward / reward_info / status / done / RS
+        outputs keep the values of the finished step (like auto_reset)."""
+        self._done_mask.copy_(self.done)
+        self.redraw(self._done_mask, seed)
+        stages = L.STAGE_ALL | (L.STAGE_IMG if self.image else 0)
+        L.check(self.lib.hope_env_reset_obs(self.h, C.c_void_p(self._done_mask.data_ptr()), stages, C.byref(self._out_obs),
+                                            self._stream()), 'hope_env_reset_obs')
+        return self
+
+    def pool_index(self):
+        out = np.zeros(self.n, np.int32)
+        L.check(self.lib.hope_env_download_pool_index(self.h, out.ctypes.data), 'hope_env_download_pool_index')
+        return out
 
     # -- the hot path ------------------------------------------------------------------------------
     def _stream(self):

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,17 @@ struct hope_env {
     std::vector<hipEvent_t> free_events;
     double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
     int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
+    // scene pool (hope_env_set_pool): complete scenes resident in HBM; hope_env_redraw copies one into a finished slot
+    int pool_n = 0;
+    double* pool_verts = nullptr;   // [pool_n][max_obst][8]
+    double* pool_c = nullptr;       // [pool_n][SC_WORDS]
+    int32_t* pool_nobst = nullptr;  // [pool_n]
+    double* pool_state = nullptr;   // scratch for k_set_scene_consts
+    int32_t* pool_t = nullptr;
+    int32_t* pool_cls[2] = {nullptr, nullptr};   // pool entries of each tile class
+    int pool_cls_n[2] = {0, 0};
+    int32_t* cur_pool = nullptr;    // [n] pool entry a scene currently holds (-1: uploaded by set_scenes)
+    uint32_t* episode = nullptr;    // [n] redraw counter (part of the draw's hash)
     // HOPE_F_OVERLAP: the two tile classes' launches go to two streams (fork / join with events)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -221,6 +233,52 @@ __global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, dou
     }
 }
 
+// New map at episode turnover (map.reset + vehicle.reset, car_parking_base.py:127-137), without the host: a finished scene
+// (mask) takes a pool entry of ITS tile class -- the dense per-class launch lists stay valid -- picked by a counter-based
+// hash of (seed, scene, episodes drawn so far), copies its obstacle tile and constants and restarts.  One wave per scene.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {        // splitmix64 finaliser
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask, uint64_t seed, const int32_t* pl0, int n0,
+                                               const int32_t* pl1, int n1, const double* pverts, const double* pc,
+                                               const int32_t* pnob, double* verts, double* scene_c, int32_t* n_obst,
+                                               double* state, int32_t* tstep, double* traj, int32_t* traj_len,
+                                               int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (!mask[s]) return;
+    const int cls = (max_obst > SMALL_TILE && n_obst[s] > SMALL_TILE) ? 1 : 0;
+    const int32_t* pl = cls ? pl1 : pl0;
+    const int cnt = cls ? n1 : n0;
+    const uint32_t ep = episode[s];
+    __syncthreads();
+    double* c = scene_c + (size_t)s * SC_WORDS;
+    if (cnt > 0) {
+        const int j = pl[(int)(mix64(seed ^ mix64(((uint64_t)s << 32) | ep)) % (uint64_t)cnt)];
+        const int nob = pnob[j];
+        const double2* src = (const double2*)(pverts + (size_t)j * max_obst * 8);
+        double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
+        for (int v = lane; v < 4 * nob; v += WAVE) dst[v] = src[v];
+        if (lane < SC_WORDS) c[lane] = pc[(size_t)j * SC_WORDS + lane];
+        if (lane == 0) { n_obst[s] = nob; cur_pool[s] = j; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        episode[s] = ep + 1;
+        double* st = state + (size_t)s * ST_WORDS;
+        st[0] = c[SC_START]; st[1] = c[SC_START + 1]; st[2] = c[SC_START + 2]; st[3] = 0.0;
+        tstep[s] = 0;
+        if (traj) {
+            double* tr = traj + (size_t)s * BEV_TRAJ_LEN * 3;
+            tr[0] = st[0]; tr[1] = st[1]; tr[2] = st[2];
+            traj_len[s] = 1;
+            traj_valid[s] = 0;
+        }
+    }
+}
+
 // Reeds-Shepp work queues: the flagged scenes of each tile class (blockIdx.y), compacted.  Each block scans its share
 // of the class's scene list (thread = a few consecutive entries, block-wide exclusive scan) and reserves one
 // contiguous range of the queue with a single atomicAdd.
@@ -333,6 +391,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->cls_list[0], N * sizeof(int32_t));
     ALLOC(h->cls_list[1], N * sizeof(int32_t));
     ALLOC(h->rs_rec, N * rs_rec_bytes_per_scene());
+    ALLOC(h->cur_pool, N * sizeof(int32_t));
+    ALLOC(h->episode, N * sizeof(uint32_t));
     if (flags & HOPE_F_IMAGE) {
         ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
         ALLOC(h->traj_len, N * sizeof(int32_t));
@@ -352,6 +412,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_count, 0, 2 * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_flag, 0, N));
+    HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -384,7 +446,7 @@ int hope_env_destroy(hope_env_t* h) {
     if (h->gstream) hipStreamDestroy(h->gstream);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_rec, h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pool_verts, h->pool_c, h->pool_nobst, h->pool_state, h->pool_t, h->pool_cls[0], h->pool_cls[1], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -423,6 +485,10 @@ int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double*
     return HOPE_OK;
 }
 
+static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double* start, const double* dest, const double* bbox,
+                         const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
+                         int32_t* d_nobst, double* d_verts, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid);
+
 int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const double* start, const double* dest,
                         const double* bbox, const double* verts, const int32_t* n_obst) {
     if (!h || n < 0 || (n > 0 && (!scene_ids || !start || !dest || !bbox || !n_obst)))
@@ -435,31 +501,11 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     }
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
-    size_t tile = (size_t)h->max_obst * 8 * sizeof(double);
-    size_t o_ids = 0, o_nob = o_ids + sizeof(int32_t) * n, o_start = (o_nob + sizeof(int32_t) * n + 15) & ~(size_t)15;
-    size_t o_dest = o_start + 24 * (size_t)n, o_bbox = o_dest + 24 * (size_t)n, o_verts = (o_bbox + 32 * (size_t)n + 15) & ~(size_t)15;
-    size_t need = o_verts + tile * n;
-    if (need > h->stage_bytes) {
-        if (h->stage) hipFree(h->stage);
-        h->stage = nullptr; h->stage_bytes = 0;
-        hipError_t e2 = hipMalloc(&h->stage, need);
-        if (e2 != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc stage: ") + hipGetErrorString(e2));
-        h->stage_bytes = need;
+    {
+        int rc = upload_scenes(h, scene_ids, n, start, dest, bbox, verts, n_obst, h->scene_c, h->state, h->tstep, h->n_obst,
+                               h->verts, h->traj, h->traj_len, h->traj_valid);
+        if (rc != HOPE_OK) return rc;
     }
-    char* sp = (char*)h->stage;
-    HIPCHK(hipMemcpy(sp + o_ids, scene_ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp + o_nob, n_obst, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp + o_start, start, 24 * (size_t)n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp + o_dest, dest, 24 * (size_t)n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp + o_bbox, bbox, 32 * (size_t)n, hipMemcpyHostToDevice));
-    if (verts) HIPCHK(hipMemcpy(sp + o_verts, verts, tile * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_set_scene_consts, dim3((n + 127) / 128), dim3(128), 0, 0, n, (const int32_t*)(sp + o_ids),
-                       (const double*)(sp + o_start), (const double*)(sp + o_dest), (const double*)(sp + o_bbox),
-                       (const int32_t*)(sp + o_nob), h->scene_c, h->state, h->tstep, h->n_obst, h->traj, h->traj_len, h->traj_valid);
-    if (verts)
-        hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
-                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), h->verts, h->max_obst);
-    HIPCHK(hipGetLastError());
     // rebuild the dense per-class scene lists (host mirror of n_obst; N ints, reset-time only)
     for (int k = 0; k < n; k++) h->n_obst_host[scene_ids[k]] = n_obst[k];
     {
@@ -609,6 +655,109 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     int rc = enqueue_step(h, actions, active, stages, out, s, (h->flags & HOPE_F_OVERLAP) ? h->side : nullptr, has_action, tm);
     if (rc != HOPE_OK) return rc;
     if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
+    return HOPE_OK;
+}
+
+
+// Shared by set_scenes and set_pool: stage the host arrays and write constants / tiles for entries ids[0..n)
+static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double* start, const double* dest, const double* bbox,
+                         const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
+                         int32_t* d_nobst, double* d_verts, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid) {
+    size_t tile = (size_t)h->max_obst * 8 * sizeof(double);
+    size_t o_ids = 0, o_nob = o_ids + sizeof(int32_t) * n, o_start = (o_nob + sizeof(int32_t) * n + 15) & ~(size_t)15;
+    size_t o_dest = o_start + 24 * (size_t)n, o_bbox = o_dest + 24 * (size_t)n, o_verts = (o_bbox + 32 * (size_t)n + 15) & ~(size_t)15;
+    size_t need = o_verts + tile * n;
+    if (need > h->stage_bytes) {
+        if (h->stage) hipFree(h->stage);
+        h->stage = nullptr; h->stage_bytes = 0;
+        hipError_t e2 = hipMalloc(&h->stage, need);
+        if (e2 != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc stage: ") + hipGetErrorString(e2));
+        h->stage_bytes = need;
+    }
+    char* sp = (char*)h->stage;
+    HIPCHK(hipMemcpy(sp + o_ids, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_nob, n_obst, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_start, start, 24 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_dest, dest, 24 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp + o_bbox, bbox, 32 * (size_t)n, hipMemcpyHostToDevice));
+    if (verts) HIPCHK(hipMemcpy(sp + o_verts, verts, tile * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_scene_consts, dim3((n + 127) / 128), dim3(128), 0, 0, n, (const int32_t*)(sp + o_ids),
+                       (const double*)(sp + o_start), (const double*)(sp + o_dest), (const double*)(sp + o_bbox),
+                       (const int32_t*)(sp + o_nob), d_scene_c, d_state, d_t, d_nobst, d_traj, d_traj_len, d_traj_valid);
+    if (verts)
+        hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
+                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), d_verts, h->max_obst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return HOPE_OK;
+}
+
+int hope_env_set_pool(hope_env_t* h, int n_pool, const double* start, const double* dest, const double* bbox,
+                      const double* verts, const int32_t* n_obst) {
+    if (!h || n_pool <= 0 || !start || !dest || !bbox || !verts || !n_obst) return fail(HOPE_EINVAL, "hope_env_set_pool: bad argument");
+    for (int k = 0; k < n_pool; k++)
+        if (n_obst[k] < 0 || n_obst[k] > h->max_obst) return fail(HOPE_EINVAL, "hope_env_set_pool: n_obst exceeds max_obstacles");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    for (void* q : {(void*)h->pool_verts, (void*)h->pool_c, (void*)h->pool_nobst, (void*)h->pool_state, (void*)h->pool_t,
+                    (void*)h->pool_cls[0], (void*)h->pool_cls[1]})
+        if (q) hipFree(q);
+    h->pool_verts = h->pool_c = h->pool_state = nullptr; h->pool_nobst = h->pool_t = h->pool_cls[0] = h->pool_cls[1] = nullptr;
+    h->pool_n = 0;
+#define PALLOC(ptr, bytes)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                      \
+        if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc pool: ") + hipGetErrorString(e_)); \
+    } while (0)
+    const size_t P = (size_t)n_pool;
+    PALLOC(h->pool_verts, P * h->max_obst * 8 * sizeof(double));
+    PALLOC(h->pool_c, P * SC_WORDS * sizeof(double));
+    PALLOC(h->pool_nobst, P * sizeof(int32_t));
+    PALLOC(h->pool_state, P * ST_WORDS * sizeof(double));
+    PALLOC(h->pool_t, P * sizeof(int32_t));
+    PALLOC(h->pool_cls[0], P * sizeof(int32_t));
+    PALLOC(h->pool_cls[1], P * sizeof(int32_t));
+#undef PALLOC
+    const int chunk = 4096;
+    std::vector<int32_t> ids(chunk);
+    for (int a = 0; a < n_pool; a += chunk) {
+        const int m = std::min(chunk, n_pool - a);
+        for (int k = 0; k < m; k++) ids[k] = a + k;
+        int rc = upload_scenes(h, ids.data(), m, start + 3 * (size_t)a, dest + 3 * (size_t)a, bbox + 4 * (size_t)a,
+                               verts + (size_t)a * h->max_obst * 8, n_obst + a, h->pool_c, h->pool_state, h->pool_t,
+                               h->pool_nobst, h->pool_verts, nullptr, nullptr, nullptr);
+        if (rc != HOPE_OK) return rc;
+    }
+    std::vector<int32_t> l0, l1;
+    const bool two = h->max_obst > SMALL_TILE;
+    for (int k = 0; k < n_pool; k++) (two && n_obst[k] > SMALL_TILE ? l1 : l0).push_back(k);
+    h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
+    if (!l0.empty()) HIPCHK(hipMemcpy(h->pool_cls[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!l1.empty()) HIPCHK(hipMemcpy(h->pool_cls[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->pool_n = n_pool;
+    return HOPE_OK;
+}
+
+int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* stream) {
+    if (!h || !mask) return fail(HOPE_EINVAL, "hope_env_redraw: null argument");
+    if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_redraw: hope_env_set_scenes has not been called");
+    if (h->pool_n <= 0) return fail(HOPE_ESTATE, "hope_env_redraw: hope_env_set_pool has not been called");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(k_redraw, dim3(h->n), dim3(WAVE), 0, (hipStream_t)stream, h->max_obst, mask, seed, h->pool_cls[0],
+                       h->pool_cls_n[0], h->pool_cls[1], h->pool_cls_n[1], h->pool_verts, h->pool_c, h->pool_nobst, h->verts,
+                       h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode);
+    HIPCHK(hipGetLastError());
+    return HOPE_OK;
+}
+
+int hope_env_download_pool_index(hope_env_t* h, int32_t* out) {
+    if (!h || !out) return fail(HOPE_EINVAL, "hope_env_download_pool_index: null argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->cur_pool, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return HOPE_OK;
 }
 

@@ -134,8 +134,11 @@ class TransitionRing:
 
 
 class HopeRollout:
-    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True):
-        self.env, self.agent, self.use_mask = env, agent, use_mask
+    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True, fresh_scenes=False):
+        """fresh_scenes: finished episodes continue on a NEW map drawn from the env's device-resident scene pool
+        (ParkingBatch.set_pool), as the reference's loop does with `env.reset(...)`; otherwise on the same map."""
+        self.env, self.agent, self.use_mask, self.fresh = env, agent, use_mask, fresh_scenes
+        self.seed = seed
         dev = env.device
         self.ring = TransitionRing(env.n, horizon, agent.keys, dev)
         self.planner = G.BatchedRsPlanner(env.n, device=dev) if use_planner else None
@@ -167,7 +170,11 @@ class HopeRollout:
             from .policy import gaussian_log_prob
             log_prob = gaussian_log_prob(mean, agent.log_std.expand_as(mean), action)
         self.ring.write_before(nobs, action, log_prob)              # copies: env.step overwrites the buffers in place
-        env.step(action.to(env.action_dtype).contiguous(), auto_reset=True)
+        if self.fresh:
+            env.step(action.to(env.action_dtype).contiguous())
+            env.turnover(seed=self.seed * 1000003 + self.steps)
+        else:
+            env.step(action.to(env.action_dtype).contiguous(), auto_reset=True)
         self.ring.write_after(env.reward, env.done)
         agent.observe(self._raw_obs())                              # push_memory: state_norm(next_obs, update=True)
         done = env.done.bool()
@@ -193,8 +200,8 @@ class PPOTrainer(HopeRollout):
     """train_HOPE_ppo.py:177-213: act -> step -> push; when the buffer is full (`horizon` steps of all scenes,
     the batched `len(memory) % batch_size == 0`) run PPO.update and clear."""
 
-    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True):
-        super().__init__(env, agent, horizon, use_mask=True, seed=seed, use_planner=use_planner)
+    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True, fresh_scenes=False):
+        super().__init__(env, agent, horizon, use_mask=True, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes)
         self.updates = 0
 
     def step(self):
@@ -212,8 +219,8 @@ class SACTrainer(HopeRollout):
     """train_HOPE_sac.py:177-221: uniform random actions until the memory is full, then the policy (plain Gaussian
     sample, no action mask), one SAC update every `update_every` env steps on a uniform batch from the ring."""
 
-    def __init__(self, env, agent, horizon=8, update_every=10, seed=0, use_planner=True, learn=True):
-        super().__init__(env, agent, horizon, use_mask=False, seed=seed, use_planner=use_planner)
+    def __init__(self, env, agent, horizon=8, update_every=10, seed=0, use_planner=True, learn=True, fresh_scenes=False):
+        super().__init__(env, agent, horizon, use_mask=False, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes)
         self.update_every, self.learn, self.updates = update_every, learn, 0
 
     def step(self):

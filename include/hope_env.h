@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 2
+#define HOPE_ABI_VERSION 3
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -157,6 +157,20 @@ int hope_env_reset_obs(hope_env_t *h, const uint8_t *active, uint32_t stages, co
  * scenes with mask[i] != 0 go back to pose = start, t = 0, accum_arrive_reward = 0 (asynchronous).
  * Follow with hope_env_reset_obs(active = mask) to obtain the first observation. */
 int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
+
+/* ---- scene pool: a new map at episode turnover without the host in the loop -------------------------------------- */
+/* The reference draws a new case for EVERY episode (ParkingMapNormal.reset parking_map_normal.py:474-494, ParkingMapDLP.reset
+ * parking_map_dlp.py:38-86, called from CarParking.reset car_parking_base.py:134).  hope_env_set_pool uploads n_pool complete
+ * scenes (host pointers, layout as hope_env_set_scenes, host-synchronous) into device memory owned by the handle;
+ * hope_env_redraw (asynchronous on `stream`) gives every scene with mask[i] != 0 a pool entry of ITS obstacle-tile class
+ * (n_obst <= 32 or larger: the dense per-class launch lists stay valid), chosen by a counter-based hash of
+ * (seed, scene, episodes drawn so far), and restarts it (pose = start, t = 0, accum_arrive_reward = 0).  Follow with
+ * hope_env_reset_obs(active = mask) for the first observation.  The host refills / replaces the pool whenever it likes. */
+int hope_env_set_pool(hope_env_t *h, int n_pool, const double *start, const double *dest, const double *bbox,
+                      const double *verts, const int32_t *n_obst);
+int hope_env_redraw(hope_env_t *h, const uint8_t *mask, uint64_t seed, void *stream);
+/* pool entry each scene currently holds (-1: as uploaded by hope_env_set_scenes); host-synchronous */
+int hope_env_download_pool_index(hope_env_t *h, int32_t *out /*[N]*/);
 
 /* With HOPE_F_PROFILE every kernel launch is bracketed by its own HIP event pair on the launch stream.
  * Returns the accumulated time (ms) and launch count per kernel since the last call with reset != 0:

@@ -95,7 +95,7 @@ def rollout(env, orc, rng, steps, tol, with_rs=False, stages=None):
 def test_library_is_native():
     from hope_amd import load_library
     L = load_library()
-    assert L.hope_abi_version() == 2
+    assert L.hope_abi_version() == 3
 
 
 def test_step_parity_f64_dlp():
@@ -566,4 +566,67 @@ def test_independent_math_libm_oracle():
         assert searches > 3000 and excused <= max(3, searches // 2000)
     finally:
         O.use_libm(False)
+    env.close()
+
+
+def test_scene_pool_turnover_matches_oracle_on_the_drawn_scenes():
+    """f-2: episode turnover with a NEW map from the device-resident pool.  After redraw + reset_obs every scene must
+    behave exactly like the oracle on the pool scene it drew (identified through pool_index): same class, first
+    observation and following steps exact; the finished step's reward / status / done are kept."""
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import SceneSource, pack_scenes
+    from oracle import oracle as O
+    n, mo, P = 1024, 128, 700
+    src = SceneSource(seed=31)
+    scenes = [src.draw() for _ in range(n)]
+    pool = [src.draw() for _ in range(P)]
+    env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
+    env.set_scenes(np.arange(n), scenes)
+    env.set_pool(pool)
+    t = env.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    rng = np.random.default_rng(32)
+    env.reset_obs()
+    cur = list(scenes)
+    assert (env.pool_index() == -1).all()
+    drawn = 0
+    for it in range(30):
+        act = rng.uniform(-1.2, 1.2, (n, 2))
+        act[:, 1] = np.where(np.arange(n) % 2 == 0, np.sign(act[:, 1] + 1e-9), act[:, 1])      # many leave the map / collide
+        env.step(torch.from_numpy(act).to(env.device))
+        torch.cuda.synchronize()
+        fin = {k: getattr(env, k).clone() for k in ('reward', 'status', 'done', 'rs_word')}
+        done = env.done.cpu().numpy().astype(bool)
+        env.turnover(seed=1000 + it)
+        torch.cuda.synchronize()
+        for k, v in fin.items():
+            assert torch.equal(getattr(env, k), v), k                       # the finished step's outputs survive
+        idx = env.pool_index()
+        assert (idx[done] >= 0).all()
+        for i in np.nonzero(done)[0]:
+            new = pool[int(idx[i])]
+            assert (new.n_obst > 32) == (cur[i].n_obst > 32)                # same tile class
+            cur[i] = new
+        drawn += int(done.sum())
+        if it % 6 == 5 or it == 29:                                          # full-state check against the oracle
+            pose, tt, acc = env.download_state()
+            start, dest, bbox, verts, nob, nvert = pack_scenes(cur, mo)
+            orc = O.BatchOracle(n, mo, omp=True)
+            orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+            orc.pose[:], orc.t[:], orc.accum[:] = pose, tt, acc
+            assert np.array_equal(pose[done], start[done]) and (tt[done] == 1).all()
+            a2 = rng.uniform(-1, 1, (n, 2))
+            env.step(torch.from_numpy(a2).to(env.device))
+            st = new_stats()
+            compare(env, orc.step(a2), TOL64, st, True)
+            assert st['status_mismatch'] == 0 and st['mask_mismatch'] == 0 and st['rs_word_mismatch'] == 0
+            assert max(st['lidar_err'], st['target_err'], st['reward_err']) <= TOL64
+            env.turnover(seed=5000 + it)
+            idx2 = env.pool_index()
+            d2 = env.done.cpu().numpy().astype(bool)
+            for i in np.nonzero(d2)[0]:
+                cur[i] = pool[int(idx2[i])]
+    assert drawn > 300
+    idx = env.pool_index()
+    assert len(np.unique(idx[idx >= 0])) > 150                               # draws spread over the pool
     env.close()
