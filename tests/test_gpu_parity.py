@@ -587,6 +587,7 @@ def test_scene_pool_turnover_matches_oracle_on_the_drawn_scenes():
     O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
     rng = np.random.default_rng(32)
     env.reset_obs()
+    env.upload_state(t=rng.integers(172, 200, n))            # episodes run out of time (t > 200) all through the test
     cur = list(scenes)
     assert (env.pool_index() == -1).all()
     drawn = 0
