@@ -11,8 +11,9 @@ can drive it.  Old-gym API: reset -> obs ; step -> (obs, reward, done, info).
 `use_img_observation=True` adds the bird's-eye image obs['img'] ((64, 64, 3) float64 in [0, 1] from the raw env,
 (3, 64, 64) after the wrapper; rendered on the GPU by k_bev_image).  It defaults to False here
 (the reference's USE_IMG default is True, configs.py:100) because its pixel parity with pygame / OpenCV is unpinned
-(DESIGN.md §3).  Not provided: `get_map_level` bucketing (`map.map_level` reports the generator
-level, 'dlp' for DLP cases) and the pygame window (`render` returns None).
+(DESIGN.md §3).  `map.map_level` is the generator's level for Normal / Complex / Extrem maps and, for DLP maps, the
+label `get_map_level` gives (hope_amd/map_level.py <-> src/env/map_level.py, as ParkingMapDLP.reset does :84).
+Not provided: the pygame window (`render` returns None).
 """
 import math
 from collections import OrderedDict
@@ -194,7 +195,7 @@ class CarParking:
         self.reward = self.prev_reward = self.accum_arrive_reward = 0.0
         self.t = 0.0
         initial_state = self.map.load(scene)
-        self.map.map_level = scene.level
+        self.map.map_level = scene.map_level
         self.vehicle.reset(initial_state)
         self._batch.set_scenes([0], [scene])
         return self.step()[0]

@@ -34,6 +34,15 @@ class Scene:
     def n_obst(self):
         return len(self.verts)
 
+    @property
+    def map_level(self):
+        """`map.map_level`: the generator's level for Normal / Complex / Extrem scenes; for DLP scenes the label
+        ParkingMapDLP.reset computes with get_map_level (parking_map_dlp.py:84)"""
+        if self.level != 'dlp':
+            return self.level
+        from .map_level import get_map_level
+        return get_map_level(self.start, self.dest, [v[:int(n)] for v, n in zip(self.verts, self.nvert)])
+
 
 def create_box(pose):
     """State.create_box (vehicle.py:32-36): 4 hull corners of a pose."""
