@@ -79,8 +79,10 @@ struct hope_env {
     int32_t* cur_pool = nullptr;    // [n] pool entry a scene currently holds (-1: uploaded by set_scenes)
     uint32_t* episode = nullptr;    // [n] redraw counter (part of the draw's hash)
     // HOPE_F_OVERLAP: the two tile classes' launches go to two streams (fork / join with events)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static constexpr int MAX_CHAINS = 8;                    // launch chains in flight: tile classes x HOPE_CHAINS sub-lists
+    int sub_chains = 1;
+    hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {};
     // HOPE_F_GRAPH: the launches of one step, captured on a library stream and replayed while the arguments repeat
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -384,7 +386,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->pmax, NL * sizeof(double));
     ALLOC(h->hull_base, NBEAM * sizeof(double));
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
-    ALLOC(h->rs_count, 2 * sizeof(int32_t));
+    ALLOC(h->rs_count, 2 * hope_env::MAX_CHAINS * sizeof(int32_t));
     ALLOC(h->rs_list, 2 * N * sizeof(int32_t));
     ALLOC(h->rs_flag, N);
     ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
@@ -410,7 +412,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->scene_c, 0, N * SC_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->state, 0, N * ST_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
-    HIPCHK(hipMemset(h->rs_count, 0, 2 * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->rs_count, 0, 2 * hope_env::MAX_CHAINS * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_flag, 0, N));
     HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
@@ -421,9 +423,13 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (flags & (HOPE_F_OVERLAP | HOPE_F_GRAPH)) {
-        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
+        h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        for (int i = 1; i < hope_env::MAX_CHAINS; i++) {
+            HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
     }
     if (flags & HOPE_F_GRAPH) {
         HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
@@ -441,8 +447,11 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     hipDeviceSynchronize();
     drop_graphs(h);
-    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_in, h->ev_out}) if (e) hipEventDestroy(e);
-    if (h->side) hipStreamDestroy(h->side);
+    for (hipEvent_t e : {h->ev_fork, h->ev_in, h->ev_out}) if (e) hipEventDestroy(e);
+    for (int i = 0; i < hope_env::MAX_CHAINS; i++) {
+        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+        if (h->side[i]) hipStreamDestroy(h->side[i]);
+    }
     if (h->gstream) hipStreamDestroy(h->gstream);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
@@ -528,7 +537,7 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
 // { k_rs_words + k_rs_validate class 0 | class 1 } -> join -> image.  Every class kernel is latency-bound per wave, so at
 // <= 16 k scenes per GPU (BASELINE config 4: 8 192) one class alone cannot fill the 1024 SIMDs.
 static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages, const hope_step_out* out,
-                        hipStream_t s, hipStream_t s2, int has_action, LaunchTimer* tm) {
+                        hipStream_t s, bool overlap, int has_action, LaunchTimer* tm) {
     StepParams p;
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
     p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
@@ -550,17 +559,32 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     // (own scene list, own queue counter, record slots filled from opposite ends), so with a side stream they run
     // concurrently from the fork after the kinematics to the join before the image.
     const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
-    const bool two = s2 && n_cls == 2 && h->cls_count[0] > 0 && h->cls_count[1] > 0;
     const bool want_rs = (stages & HOPE_STAGE_RS) && out->rs_word;
-    if (two) { HIPCHK(hipEventRecord(h->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, h->ev_fork, 0)); }
-    for (int c = n_cls - 1; c >= 0; c--) {                  // the large-tile class first: its chain is the longer one
-        if (h->cls_count[c] == 0) continue;
-        hipStream_t sc = (two && c == 1) ? s2 : s;
+    // chains: (class, sub-list) pairs with work, the large-tile class first (its chains are the longer ones)
+    struct Chain { int c, a, b; };
+    Chain chains[hope_env::MAX_CHAINS];
+    int n_chain = 0;
+    const int subs = overlap ? h->sub_chains : 1;
+    for (int c = n_cls - 1; c >= 0; c--)
+        for (int j = 0; j < subs; j++) {
+            const int a = (int)((long long)h->cls_count[c] * j / subs), b = (int)((long long)h->cls_count[c] * (j + 1) / subs);
+            if (b > a) chains[n_chain++] = {c, a, b};
+        }
+    const bool fork = overlap && n_chain > 1;
+    if (fork) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        for (int i = 1; i < n_chain; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
+    }
+    for (int i = 0; i < n_chain; i++) {
+        const Chain& ch = chains[i];
+        const int c = ch.c;
+        hipStream_t sc = (fork && i > 0) ? h->side[i] : s;
+        int32_t* counter = h->rs_count + i;
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
-        p.scene_list = h->cls_list[c];
-        p.n_list = h->cls_count[c];
+        p.scene_list = h->cls_list[c] + ch.a;
+        p.n_list = ch.b - ch.a;
         p.rs_flag = h->rs_flag;
-        p.rs_count_zero = want_rs ? h->rs_count + c : nullptr;
+        p.rs_count_zero = want_rs ? counter : nullptr;
         const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
         if (tm) tm->begin(HOPE_K_STEP, sc);
@@ -570,24 +594,26 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
         if (tm) tm->end(sc);
         if (!want_rs) continue;
+        int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
-        hipLaunchKernelGGL(k_rs_compact, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, h->cls_list[c], h->cls_count[c],
-                           (const int32_t*)nullptr, 0, h->rs_flag, active, h->rs_list + (size_t)c * h->n, h->n, h->rs_count + c);
+        hipLaunchKernelGGL(k_rs_compact, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list,
+                           (const int32_t*)nullptr, 0, h->rs_flag, active, qlist, h->n, counter);
         if (tm) tm->end(sc);
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
-        r.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
-        r.max_queue = h->cls_count[c];
-        r.slot_base = (c == 0) ? 0 : h->n - 1;              // the two classes fill the record storage from both ends
+        r.tile_cap = p.tile_cap;
+        r.max_queue = p.n_list;
+        r.slot_base = (c == 0) ? ch.a : h->n - 1 - ch.a;    // the two classes fill the record storage from both ends
         r.slot_dir = (c == 0) ? 1 : -1;
         r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
-        r.rs_count = h->rs_count + c; r.rs_list = h->rs_list + (size_t)c * h->n;
+        r.rs_count = counter; r.rs_list = qlist;
         r.rs_rec = h->rs_rec;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
         HIPCHK(launch_rs_search(r, sc, tm));
     }
     HIPCHK(hipGetLastError());
-    if (two) { HIPCHK(hipEventRecord(h->ev_join, s2)); HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0)); }
+    if (fork)
+        for (int i = 1; i < n_chain; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
     if (stages & HOPE_STAGE_IMG) {
         BevParams b;
         b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
@@ -630,7 +656,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
             }
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_step(h, actions, active, stages, out, h->gstream, (h->flags & HOPE_F_OVERLAP) ? h->side : nullptr, has_action, nullptr);
+            int rc = enqueue_step(h, actions, active, stages, out, h->gstream, (h->flags & HOPE_F_OVERLAP) != 0, has_action, nullptr);
             hipError_t e = hipStreamEndCapture(h->gstream, &graph);
             if (rc != HOPE_OK) { if (graph) hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) return fail(HOPE_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -652,7 +678,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (prof && h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
     EventTimer timer(h);
     LaunchTimer* tm = prof ? &timer : nullptr;
-    int rc = enqueue_step(h, actions, active, stages, out, s, (h->flags & HOPE_F_OVERLAP) ? h->side : nullptr, has_action, tm);
+    int rc = enqueue_step(h, actions, active, stages, out, s, (h->flags & HOPE_F_OVERLAP) != 0, has_action, tm);
     if (rc != HOPE_OK) return rc;
     if (timer.failed) return fail(HOPE_EHIP, "hipEventRecord failed");
     return HOPE_OK;
