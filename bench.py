@@ -235,13 +235,37 @@ def main():
         dom_ms = dom_total_ms / max(dom_launches, 1)
         bytes_avg_launch = bytes_per_launch * args.steps / max(dom_launches, 1)
         achieved = bytes_avg_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_image.json' if args.image else 'r01_pmc_traffic.json')
-        if os.path.exists(pmc):
+        # Memory-side traffic and instruction counts are NOT measured in this run: they come from the PMC passes committed
+        # under profiles/ (tools/collect_profiles.sh: separate rocprofv3 --pmc passes of this same command) and are
+        # labelled as such.  They describe the default workload only.
+        default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and not args.fresh_scenes)
+        traffic = traffic_source = None
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_image.json' if args.image else 'r02_pmc_traffic.json')
+        if os.path.exists(pmc) and default_workload and not args.graph:
             try:
                 traffic = json.load(open(pmc))['kernels'][dom]['hbm_bytes']
+                traffic_source = 'static: ' + os.path.relpath(pmc, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)'
             except Exception:
                 traffic = None
+        # instruction-issue roofline (every kernel here is VALU-issue / latency bound, none is HBM bound): a gfx950 SIMD
+        # issues one wave64 VALU instruction per 4 cycles -- measured: float64 add / mul / fma run at that full rate
+        # (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.04 quad-cycles) -- so the chip retires at most
+        # 1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s.
+        valu = None
+        sq = os.path.join(ROOT, 'profiles', 'r02_sq_counters.json')
+        if os.path.exists(sq) and default_workload and not args.image:
+            try:
+                sqd = json.load(open(sq))
+                peak_issue = 1024 * 2.4e9 / 4
+                insts = sqd['valu_insts_per_bench_step']
+                valu = {'valu_insts_per_bench_step': insts, 'peak_wave_insts_per_s': peak_issue,
+                        'min_ms_per_step_at_peak_issue': insts / peak_issue * 1e3,
+                        'frac': insts / peak_issue / (elapsed / args.steps),
+                        'per_kernel_valu_insts_per_launch': {k: v.get('SQ_INSTS_VALU') for k, v in sqd['kernels'].items()},
+                        'source': 'static instruction counts: profiles/r02_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU pass '
+                                  'of this command); step time: this run'}
+            except Exception:
+                valu = None
         # the box's own streaming ceiling next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB
         copy_gbps = None
         try:
@@ -270,7 +294,15 @@ def main():
                                             if args.fresh_scenes else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': traffic, 'kernel': dom, 'largest_by_time': largest,
+                         'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': dom,
+                         'largest_by_time': largest,
+                         'concurrent_launches': ('the launch chains of the two obstacle-tile classes run on two streams: the '
+                                                 'k_env_step launches overlap each other and the other class\'s kernels, so '
+                                                 'per-launch durations include that sharing') if env.overlap else None,
+                         'whole_step': {'achieved': bytes_per_launch / (elapsed / args.steps) / 1e9, 'unit': 'GB/s',
+                                        'frac': bytes_per_launch / (elapsed / args.steps) / 1e9 / 8000.0,
+                                        'note': 'algorithmic bytes of one bench step / driver-timed step'},
+                         'valu_issue': valu,
                          'measured_copy_GBps': copy_gbps,
                          'kernel_ms': dom_ms, 'kernel_launches': dom_launches,
                          'algorithmic_bytes_per_launch': bytes_avg_launch,

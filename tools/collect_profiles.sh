@@ -32,8 +32,24 @@ for V in "" "_image"; do
   done
 done
 python $R/tools/reduce_profiles.py $O $TAG
+# raw SQ counters (instruction mix, wait / active quad-cycles) -> VALU-issue roofline of bench.py
+(cd $R && bash tools/pmc_sq.sh final/sq > /dev/null 2>&1)
+cp $O/sq/sq_summary.txt $O/${TAG}_sq_summary.txt; cp $O/sq/sq_counters.json $O/${TAG}_sq_counters.json; rm -rf $O/sq
 py $R/tools/stage_times.py --scenes 32768 > $O/${TAG}_stage_times.txt
 py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
-py $R/examples/rollout_demo.py --scenes 65536 --steps 50 > $O/${TAG}_rollout_demo.txt
+# batch-size sweep, launch modes, new-map turnover, BASELINE configs 4 / 5 on one GPU, 2 ranks sharing the GPU
+{
+  for NS in 4096 8192 16384 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --steps 40 --warmup 10 | tail -1; done
+  echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 | tail -1
+  echo "== --scenes 8192 --graph"; py $R/bench.py --scenes 8192 --graph --no-cpu-baseline --steps 40 --warmup 10 | tail -1
+  echo "== --fresh-scenes"; py $R/bench.py --fresh-scenes --no-cpu-baseline --steps 40 --warmup 10 | tail -1
+  echo "== config 4 share: --policy hope --algo rollout --scenes 8192 --image"; py $R/bench.py --policy hope --algo rollout --scenes 8192 --image --no-cpu-baseline | tail -1
+  echo "== --policy hope --algo rollout (65536 scenes, no image)"; py $R/bench.py --policy hope --algo rollout --no-cpu-baseline | tail -1
+  echo "== config 5 share: --policy hope --algo ppo --scenes 16384"; py $R/bench.py --policy hope --algo ppo --scenes 16384 --no-cpu-baseline --steps 32 --warmup 16 | tail -1
+  echo "== 2 ranks sharing the GPU (gloo): weak scaling 16384 scenes/rank"
+  HOPE_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --scenes 16384 --steps 20 --warmup 5 2>/dev/null | tail -1
+  echo "== 2 ranks sharing the GPU (gloo): strong scaling 16384 scenes total, PPO with gradient all-reduce"
+  HOPE_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 $R/bench.py --gpus 2 --scaling strong --scenes 16384 --policy hope --algo ppo --steps 16 --warmup 8 2>/dev/null | tail -1
+} > $O/${TAG}_bench_modes.txt
 rm -rf $O/kstats $O/kstats_img $O/pmc_* $O/pmc*_FETCH_SIZE $O/pmc*_WRITE_SIZE $O/busy*
 ls -la $O

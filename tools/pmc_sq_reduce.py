@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Per-kernel averages of the raw SQ counters collected by tools/pmc_sq.sh (second half of the launches of each kernel)."""
+"""Per-kernel averages of the raw SQ counters collected by tools/pmc_sq.sh (second half of the launches of each kernel).
+Also writes <dir>/sq_counters.json: per-launch averages per kernel and the VALU / SALU instructions of one bench step
+(launches per step = launches of the kernel / launches of k_kinematics, which runs once per env step with an action)."""
 import csv
+import json
 import glob
 import os
 import re
@@ -34,3 +37,17 @@ for k, cs in acc.items():
         for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_SCA'):
             if c in vals:
                 print(f'   frac of wave cycles {c:20s} {vals[c] / wc:8.3f}')
+
+summary = {'unit': 'per launch, average over the second half of the launches in the profiled run', 'kernels': {}}
+kin = len(next(iter(acc.get('k_kinematics', {'x': [0]}).values()))) or 1
+tot_valu = tot_salu = 0.0
+for k, cs in acc.items():
+    per = {c: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for c, v in cs.items()}
+    nl = len(next(iter(cs.values())))
+    per['launches_per_bench_step'] = round(nl / kin) if k != 'k_kinematics' else 1
+    summary['kernels'][k] = per
+    tot_valu += per.get('SQ_INSTS_VALU', 0.0) * per['launches_per_bench_step']
+    tot_salu += per.get('SQ_INSTS_SALU', 0.0) * per['launches_per_bench_step']
+summary['valu_insts_per_bench_step'] = tot_valu
+summary['salu_insts_per_bench_step'] = tot_salu
+json.dump(summary, open(os.path.join(d, 'sq_counters.json'), 'w'), indent=1)
