@@ -33,13 +33,29 @@ class _Opaque:
         self.__dict__.update(state if isinstance(state, dict) else {'state': state})
 
 
+# globals a HOPE checkpoint legitimately refers to besides the reference's own classes: tensor / storage rebuilders,
+# optimizers (the 'optimizer' tuple), containers and numpy scalars / arrays.  Anything else is refused, so that loading an
+# untrusted file cannot import and call arbitrary code (weights_only=False is needed for the StateNorm instance).
+_ALLOWED_PREFIX = ('torch._utils.', 'torch.optim.', 'torch.nn.', 'torch.storage.', 'torch._tensor.', 'numpy.core.multiarray.',
+                   'numpy._core.multiarray.', 'numpy.core.numeric.', 'numpy._core.numeric.')
+_ALLOWED = {'collections.OrderedDict', 'collections.defaultdict', 'collections.deque', 'builtins.dict', 'builtins.list',
+            'builtins.tuple', 'builtins.set', 'builtins.int', 'builtins.float', 'builtins.bool', 'builtins.str',
+            'builtins.complex', 'builtins.slice', 'builtins.range', 'builtins.bytes', 'builtins.bytearray', '_codecs.encode', 'numpy.dtype', 'numpy.ndarray', 'torch.Tensor', 'torch.Size',
+            'torch.device', 'torch.dtype', 'torch.serialization._get_layout', 'torch.FloatStorage', 'torch.DoubleStorage',
+            'torch.LongStorage', 'torch.IntStorage', 'torch.HalfStorage', 'torch.BoolStorage', 'torch.ByteStorage',
+            'torch.BFloat16Storage', 'torch.float32', 'torch.float64', 'torch.int64', 'torch.int32', 'torch.uint8'}
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, mod, name):
         if mod == 'model.state_norm' and name == 'StateNorm':
             return RefStateNorm
         if mod.split('.')[0] in ('model', 'configs', 'env', 'evaluation', 'train'):
             return type(name, (_Opaque,), {'__module__': mod})
-        return super().find_class(mod, name)
+        full = f'{mod}.{name}'.replace('__builtin__.', 'builtins.')       # protocol-2 pickles name the py2 module
+        if full in _ALLOWED or any(full.startswith(p) for p in _ALLOWED_PREFIX):
+            return super().find_class(mod, name)
+        raise pickle.UnpicklingError(f'hope_amd.checkpoint: refusing to load global {full!r} from a checkpoint')
 
 
 class _shim_pickle:
@@ -55,7 +71,10 @@ class _shim_pickle:
 
 def state_norm_from_ref(ref, device='cpu'):
     """model.state_norm.StateNorm (running mean / S / std per modality, n_state, fixed) -> BatchedStateNorm"""
-    modal = tuple(k for k, v in (ref.update_modal or {}).items() if v and k in ref.state_mean)
+    mean, S, std = getattr(ref, 'state_mean', None), getattr(ref, 'S', None), getattr(ref, 'state_std', None)
+    if not mean or S is None or std is None:               # older saves without running statistics
+        return None
+    modal = tuple(k for k, v in (ref.update_modal or {}).items() if v and k in mean)
     shapes = {k: int(np.prod(np.shape(ref.state_mean[k]))) for k in modal}
     sn = BatchedStateNorm(shapes=shapes, update_modal=modal, device=device)
     for k in modal:

@@ -32,6 +32,9 @@ def load_cases(path):
 def pool_from_pickle(path):
     """build an in-memory DlpScenePool from a dlp.data-style pickle."""
     cases = load_cases(path)
+    # ParkingMapDLP.reset (:43-46): start candidates given as a LIST per case = multi-start data (one is drawn per episode
+    # and jittered, :60-63); a single start pose per case is used as it is
+    multi_start = isinstance(cases[0][0], list)
     verts, nvert, set_off, case_set, dest, starts, start_off = [], [], [0], [], [], [], [0]
     for ci, case in enumerate(cases):
         cand, dst, rings = case[:3]
@@ -56,4 +59,5 @@ def pool_from_pickle(path):
     pool.set_verts, pool.set_nvert = np.array(verts), np.array(nvert, np.int32)
     pool.set_off, pool.case_set = np.array(set_off), np.array(case_set)
     pool.dest, pool.starts, pool.start_off = np.array(dest), np.array(starts), np.array(start_off)
+    pool.multi_start = bool(multi_start)
     return pool

@@ -79,6 +79,7 @@ class DlpScenePool:
         d = np.load(path)
         self.set_verts, self.set_nvert, self.set_off = d['set_verts'], d['set_nvert'].astype(np.int32), d['set_off']
         self.case_set, self.dest, self.starts, self.start_off = d['case_set'], d['dest'], d['starts'], d['start_off']
+        self.multi_start = True                     # data/dlp.data holds a list of start candidates per case
 
     def __len__(self):
         return len(self.case_set)
@@ -97,7 +98,7 @@ class DlpScenePool:
         case = int(rng.integers(len(self))) if case is None else int(case) % len(self)
         cand = self.candidates(case)
         start = cand[int(rng.integers(len(cand)))].copy()
-        if jitter:
+        if jitter and getattr(self, 'multi_start', True):          # parking_map_dlp.py:60-63: only multi-start data is jittered
             start = start + rng.standard_normal(3) * np.array([0.05, 0.05, 0.02])
         dest = self.dest[case].copy()
         bbox = np.array([np.floor(min(start[0], dest[0]) - 20), np.ceil(max(start[0], dest[0]) + 20),

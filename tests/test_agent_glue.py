@@ -151,3 +151,21 @@ def test_load_reference_checkpoint_without_the_reference_on_the_path():
     out = sn.normalize(obs)
     assert np.allclose(out['lidar'][0].numpy(), (1.0 - e['mean_lidar']) / (e['std_lidar'] + 1e-8), atol=1e-6)
     assert torch.equal(out['action_mask'], obs['action_mask'])
+
+
+def test_checkpoint_loader_refuses_foreign_globals(tmp_path):
+    """a checkpoint is untrusted input -- only tensor / optimizer / container globals and the reference's own
+    classes (mapped to inert stand-ins) may be unpickled."""
+    import pickle
+    import pytest
+    import torch
+    from hope_amd.checkpoint import load_hope_checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ('echo pwned > /dev/null',))
+    path = tmp_path / 'evil.pt'
+    torch.save({'actor_net': {'weight': torch.zeros(2)}, 'configs': Evil()}, str(path))
+    with pytest.raises(pickle.UnpicklingError, match='refusing'):
+        load_hope_checkpoint(str(path))
