@@ -9,9 +9,8 @@ so that the reference's callers (train_HOPE_sac.py:114-118,183-213; train_HOPE_p
 can drive it.  Old-gym API: reset -> obs ; step -> (obs, reward, done, info).
 
 `use_img_observation=True` adds the bird's-eye image obs['img'] ((64, 64, 3) float64 in [0, 1] from the raw env,
-(3, 64, 64) after the wrapper; rendered on the GPU by k_bev_image).  It defaults to False here
-(the reference's USE_IMG default is True, configs.py:100) because its pixel parity with pygame / OpenCV is unpinned
-(DESIGN.md §3).  `map.map_level` is the generator's level for Normal / Complex / Extrem maps and, for DLP maps, the
+(3, 64, 64) after the wrapper; rendered on the GPU by k_bev_image).  It defaults to True like the
+reference's USE_IMG (configs.py:100); its pixel parity with pygame / OpenCV is unpinned.  `map.map_level` is the generator's level for Normal / Complex / Extrem maps and, for DLP maps, the
 label `get_map_level` gives (hope_amd/map_level.py <-> src/env/map_level.py, as ParkingMapDLP.reset does :84).
 Not provided: the pygame window (`render` returns None).
 """
@@ -132,7 +131,7 @@ class CarParking:
     metadata = {'render_mode': ['human', 'rgb_array']}
 
     def __init__(self, render_mode=None, fps=100, verbose=True, use_lidar_observation=True,
-                 use_img_observation=False, use_action_mask=True, device='cuda:0', max_obstacles=128, seed=None,
+                 use_img_observation=True, use_action_mask=True, device='cuda:0', max_obstacles=128, seed=None,
                  level='Normal'):
         import torch
         from .batch_env import ParkingBatch
@@ -215,9 +214,14 @@ class CarParking:
         self.t += 1
         speed = float(np.clip(action[1], *VALID_SPEED)) if action is not None else 0
         steer = float(np.clip(action[0], *VALID_STEER)) if action is not None else 0
+        prev = self.vehicle.state.get_pos()
         self.vehicle.state = State([pose[0], pose[1], pose[2], speed, steer])
         self.vehicle.box = self.vehicle.state.create_box()
-        self.vehicle.trajectory.append(self.vehicle.state)
+        # vehicle.trajectory (vehicle.py:144,158; car_parking_base.py:274-276): of a step's sub-step states only the last
+        # kept one stays; the action-less reset step and a step blocked at its first sub-step (collision -> retreat) add
+        # nothing -- the rule the device-side trajectory ring follows.  (A zero-speed action keeps its sub-steps.)
+        if action is not None and (self.vehicle.state.get_pos() != prev or speed == 0):
+            self.vehicle.trajectory.append(self.vehicle.state)
         observation = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
         if self.use_img_observation:                       # processed_img / 255.0, (W, H, C)  observation_processor.py:14
             observation['img'] = b.img[0].permute(1, 2, 0).cpu().numpy().astype(np.float64) / 255.0

@@ -19,10 +19,12 @@ def test_config1_trace_2000_steps():
     scene = Scene(start=g['start'], dest=g['dest'], bbox=g['bbox'], verts=g['verts'], nvert=g['nvert'], level='dlp', case_id=0)
     raw = CarParking(render_mode='rgb_array', fps=100, verbose=False)
     env = CarParkingWrapper(raw)
-    assert env.observation_shape == {'action_mask': (42,), 'lidar': (120,), 'target': (5,)}
+    # the reference's defaults (configs.py:100-101): USE_IMG and USE_ACTION_MASK on; wrapper shape (C, W, H) (env_wrapper.py:68-71)
+    assert env.observation_shape == {'img': (3, 64, 64), 'action_mask': (42,), 'lidar': (120,), 'target': (5,)}
     assert env.action_space.shape[0] == 2 and env.vehicle.kinetic_model.step_len == 0.05
     obs = raw.reset_to_scene(scene)
-    assert list(obs.keys()) == ['img', 'lidar', 'target', 'action_mask'] and obs['img'] is None
+    assert list(obs.keys()) == ['img', 'lidar', 'target', 'action_mask'] and obs['img'].shape == (64, 64, 3)
+    assert obs['img'].dtype == np.float64 and 0.0 <= obs['img'].min() and obs['img'].max() <= 1.0
     assert np.abs(obs['lidar'] - g['first_lidar']).max() < 1e-9 and np.array_equal(obs['action_mask'], g['first_mask'])
     bad = dict(status=0, mask=0, rs=0)
     err = dict(pose=0.0, lidar=0.0, reward=0.0, rslen=0.0, target=0.0)
