@@ -82,7 +82,7 @@ struct hope_env {
     static constexpr int MAX_CHAINS = 8;                    // launch chains in flight: tile classes x HOPE_CHAINS sub-lists
     int sub_chains = 1;
     hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {};
     // HOPE_F_GRAPH: the launches of one step, captured on a library stream and replayed while the arguments repeat
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -426,6 +426,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming));
         for (int i = 1; i < hope_env::MAX_CHAINS; i++) {
             HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
@@ -447,7 +448,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     hipDeviceSynchronize();
     drop_graphs(h);
-    for (hipEvent_t e : {h->ev_fork, h->ev_in, h->ev_out}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_fork, h->ev_in, h->ev_out, h->ev_step[0], h->ev_step[1]}) if (e) hipEventDestroy(e);
     for (int i = 0; i < hope_env::MAX_CHAINS; i++) {
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
         if (h->side[i]) hipStreamDestroy(h->side[i]);
@@ -460,6 +461,11 @@ int hope_env_destroy(hope_env_t* h) {
         if (q) hipFree(q);
     delete h;
     return HOPE_OK;
+}
+
+int hope_debug_rs_prof(uint64_t* out, int reset) {
+    hipError_t e = rs_prof_read((unsigned long long*)out, reset);
+    return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_prof: ") + hipGetErrorString(e));
 }
 
 int hope_env_num_scenes(const hope_env_t* h) { return h ? h->n : HOPE_EINVAL; }
@@ -533,8 +539,7 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
 }
 
 // Enqueues the launches of one step on `s`.  With a side stream `s2` (HOPE_F_OVERLAP) the two tile classes run
-// concurrently: kinematics -> fork -> { k_env_step class 0 | class 1 } -> join -> k_rs_compact -> fork ->
-// { k_rs_words + k_rs_validate class 0 | class 1 } -> join -> image.  Every class kernel is latency-bound per wave, so at
+// concurrently: fork -> { k_kinematics, k_env_step, k_rs_compact, k_rs_words, k_rs_validate of class 1 | of class 0 } -> join -> image.  Every class kernel is latency-bound per wave, so at
 // <= 16 k scenes per GPU (BASELINE config 4: 8 192) one class alone cannot fill the 1024 SIMDs.
 static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages, const hope_step_out* out,
                         hipStream_t s, bool overlap, int has_action, LaunchTimer* tm) {
@@ -547,13 +552,6 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     p.out = *out;
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 block(WAVE);
-    if ((stages & HOPE_STAGE_MOTION) && has_action) {
-        dim3 kg((h->n + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
-        if (tm) tm->begin(HOPE_K_KINEMATICS, s);
-        if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
-        else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, s, h->n, h->state, actions, active, stages, h->kin);
-        if (tm) tm->end(s);
-    }
     // One chain of launches per tile class (scenes with few obstacles get a small LDS tile and therefore more resident
     // waves): k_env_step -> k_rs_compact -> k_rs_words -> k_rs_validate.  The chains share nothing but read-only data
     // (own scene list, own queue counter, record slots filled from opposite ends), so with a side stream they run
@@ -585,6 +583,13 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         p.n_list = ch.b - ch.a;
         p.rs_flag = h->rs_flag;
         p.rs_count_zero = want_rs ? counter : nullptr;
+        if ((stages & HOPE_STAGE_MOTION) && has_action) {       // this class's sub-step poses head its chain
+            dim3 kg((p.n_list + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
+            if (tm) tm->begin(HOPE_K_KINEMATICS, sc);
+            if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->kin);
+            else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->kin);
+            if (tm) tm->end(sc);
+        }
         const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
         if (tm) tm->begin(HOPE_K_STEP, sc);
@@ -593,6 +598,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, sc, p);
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
         if (tm) tm->end(sc);
+        if (fork && (stages & HOPE_STAGE_IMG) && i < 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses
         if (!want_rs) continue;
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
@@ -612,8 +618,6 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         HIPCHK(launch_rs_search(r, sc, tm));
     }
     HIPCHK(hipGetLastError());
-    if (fork)
-        for (int i = 1; i < n_chain; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
     if (stages & HOPE_STAGE_IMG) {
         BevParams b;
         b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
@@ -621,7 +625,23 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
         b.active = active;
         b.debug = (stages >> 12) & 0xF;
-        HIPCHK(launch_bev_image(b, s, tm));
+        if (fork && n_chain == 2) {
+            // the image depends on the step kernels only (pose, trajectory ring), not on the Reeds-Shepp search: render it on
+            // a third stream while the two chains run k_rs_words / k_rs_validate
+            hipStream_t si = h->side[2];
+            HIPCHK(hipStreamWaitEvent(si, h->ev_step[0], 0));
+            HIPCHK(hipStreamWaitEvent(si, h->ev_step[1], 0));
+            HIPCHK(launch_bev_image(b, si, tm));
+            HIPCHK(hipEventRecord(h->ev_join[2], si));
+        } else {
+            if (fork) for (int i = 1; i < n_chain; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
+            HIPCHK(launch_bev_image(b, s, tm));
+            return HOPE_OK;
+        }
+    }
+    if (fork) {
+        for (int i = 1; i < n_chain; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
+        if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
     }
     return HOPE_OK;
 }

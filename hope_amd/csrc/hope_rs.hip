@@ -243,14 +243,24 @@ __device__ __forceinline__ double wave_min_d(double v) {
     return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
 }
 
+// Cycle accounting of the validation kernel (instantiated only when HOPE_RS_TIMING is set; s_memtime per section):
+// [0] prologue [1] word setup [2] sample generator [3] interpolate + transform [4] pose_hits: hull, union box, obstacle cull
+// [5] pose_hits: candidate loop [6] whole wave [8] waves [9] words tested [10] generator rounds [11] passes [12] passes with
+// candidates [13] candidate obstacles visited
+__device__ unsigned long long g_rs_prof[64 * 16];       // 64 shards (block index mod 64), summed by the host
+#define RS_T0() unsigned long long t0_ = TIMING ? __builtin_readcyclecounter() : 0
+#define RS_T(i) do { if (TIMING) { const unsigned long long t1_ = __builtin_readcyclecounter(); tsec[i] += t1_ - t0_; t0_ = t1_; } } while (0)
+
 // is_traj_valid for the (up to 64) poses held one per lane: returns true on a lane whose pose is out of the
 // map box or whose hull meets an obstacle edge (line-line intersection inside both edge boxes, no tolerance).
 // Obstacles are culled per call: the union box of the active lanes' hulls is wave-reduced, one lane per
 // obstacle compares its precomputed box (obb, in LDS) with it, and only the survivors (cand[], usually 0-3)
 // are visited.  A pair whose boxes do not overlap cannot pass the reference's box tests, so this is exact.
+template <bool TIMING>
 __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, double wyaw, const double* tile,
                                           const float4* obb, int* cand, int n_obst, double xmin, double xmax,
-                                          double ymin, double ymax, int lane) {
+                                          double ymin, double ymax, int lane, unsigned long long* tsec) {
+    RS_T0();
     bool bad = false;
     double vx[4], vy[4];
     double hminx = INFINITY, hmaxx = -INFINITY, hminy = INFINITY, hmaxy = -INFINITY;
@@ -285,7 +295,9 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         if (near) cand[nc + __popcll(m & ((1ull << lane) - 1))] = o;
         nc += __popcll(m);
     }
+    RS_T(4);
     if (nc == 0) return false;
+    if (TIMING) { tsec[12] += 1; tsec[13] += nc; }
     wsync();
     for (int ci = 0; ci < nc; ci++) {
         const int r = cand[ci];
@@ -320,6 +332,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         }
     }
     wsync();
+    RS_T(5);
     return bad;
 }
 
@@ -525,6 +538,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     }
 }
 
+
 // ================================================================================================
 // Kernel B: find_rs_path's main loop (:436-450) over the ordered words
 // ================================================================================================
@@ -534,10 +548,13 @@ constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_QCAP = 256, RSB_BAD 
 constexpr int RSB_REC_WORDS = 14;                              // words of the record kept in LDS (two 512-byte loads)
 constexpr int RSB_WORDS = RSB_REC + RS_REC_HDR + 8 * RSB_REC_WORDS;
 
-template <int OCC>
+template <int OCC, bool TIMING>
 __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
+    unsigned long long tsec[16] = {};
+    const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
+    RS_T0();
     const int count = *p.rs_count;
     if ((int)blockIdx.x >= count) return;
     if (obs_f64 & 0x400) return;                          // profiling switch: words kernel only
@@ -589,6 +606,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     if (lane < 6) bad1[lane] = INFINITY;
     wsync();
     const unsigned char* order = (const unsigned char*)(wl + RS_REC_ORDER);
+    RS_T(0);
     for (int idx = 1; idx <= n_paths; idx++) {            // the stop rule (:443) is already applied: n_paths ends there
         if ((obs_f64 & 0x200) && idx > 1) break;          // profiling switch: first path only
         const int pi = order[idx - 1];                    // push index of the idx-th popped word
@@ -661,6 +679,8 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
         }
         int nq = 1;
         wsync();
+        if (TIMING) tsec[9] += 1;
+        RS_T(1);
         // Resumable sample generator + ONE window test site.  Samples are appended to the queue until it cannot
         // take another chunk (or the path ends); then the window is tested coarse-to-fine: a path is invalid as
         // soon as ANY of its samples is bad, whatever the order they are looked at, and a path that crosses an
@@ -677,6 +697,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
         double pd = 0, ll = 0.0, lprev = 0.0, d = 0, l = 0;
         while (!invalid && (!finished || nq > 0)) {
             while (!finished && nq + WAVE + 1 <= win) {
+                if (TIMING) tsec[10] += 1;
                 if (!seg_open) {
                     l = segp[RSB_SEGW * i + 8];               // len[i]
                     d = l > 0.0 ? step : -step;
@@ -721,6 +742,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
                 } else pd = t;                                // all 64 inside: keep walking
             }
             wsync();
+            RS_T(2);
             // only whole waves of samples are tested while the path goes on; the remainder (< 64) stays queued and is
             // topped up by the next segments, so every pass but the path's last runs with all 64 lanes busy
             const int n_all = nq;
@@ -745,7 +767,10 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
                 const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
                 const double wy = -s_q * px + c_q * py + q0y;
                 const double wyaw = pi_2_pi(pyaw + q0w);
-                const bool hit = !(obs_f64 & 0x100) && pose_hits(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane);
+                if (TIMING) tsec[11] += 1;
+                RS_T(3);
+                const bool hit = !(obs_f64 & 0x100) && pose_hits<TIMING>(active, wx, wy, wyaw, tile, obb, cand, n_obst, xmin, xmax, ymin, ymax, lane, tsec);
+                if (TIMING) t0_ = __builtin_readcyclecounter();
                 if (__any(hit)) {
                     // remember the nearest colliding sample of the FIRST segment (re-read from the queue: rare path)
                     const double mine1 = (hit && active && qseg[idx] == 0) ? fabs(qpd[idx]) : INFINITY;
@@ -768,6 +793,12 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
             wsync();
         }
         if (!invalid) { found = idx - 1; break; }
+    }
+    if (TIMING) {
+        tsec[6] = __builtin_readcyclecounter() - tstart_;
+        tsec[8] = 1;
+        if (lane == 0)
+            for (int i = 0; i < 16; i++) if (tsec[i]) atomicAdd(&g_rs_prof[(blockIdx.x & 63) * 16 + i], tsec[i]);
     }
     if (found < 0) return;
 
@@ -795,13 +826,27 @@ size_t rs_lds_bytes(int max_obst) {
 }
 size_t rs_rec_bytes_per_scene() { return sizeof(double) * RS_REC_DOUBLES; }
 
+hipError_t rs_prof_read(unsigned long long* out, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    static unsigned long long buf[64 * 16];
+    e = hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_rs_prof), sizeof(buf));
+    for (int i = 0; i < 16; i++) { out[i] = 0; for (int sh = 0; sh < 64; sh++) out[i] += buf[sh * 16 + i]; }
+    if (e == hipSuccess && reset) {
+        for (auto& v : buf) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), buf, sizeof(buf));
+    }
+    return e;
+}
+
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer) {
     if (p.max_queue <= 0) return hipSuccess;
     size_t lds = rs_lds_bytes(p.tile_cap);
     // register budget of the validation kernel: 4 waves / SIMD (128 VGPRs, some spills) or 3 (168 VGPRs); HOPE_RS_OCC picks
+    static const bool timing = getenv("HOPE_RS_TIMING") != nullptr;      // cycle accounting build (tools/rs_timing.py)
     static const int occ = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 3;   // the 4-wave build (50 spilled VGPRs) hung on the GPU: kept for experiments only
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(occ == 3 ? (const void*)k_rs_validate<3> : (const void*)k_rs_validate<4>,
+        hipError_t e = hipFuncSetAttribute(timing ? (const void*)k_rs_validate<3, true> : occ == 3 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -811,8 +856,9 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->end(stream);
     static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
-    if (occ == 3) hipLaunchKernelGGL(k_rs_validate<3>, dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
-    else hipLaunchKernelGGL(k_rs_validate<4>, dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    else if (occ == 3) hipLaunchKernelGGL((k_rs_validate<3, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    else hipLaunchKernelGGL((k_rs_validate<4, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }

@@ -262,13 +262,17 @@ __device__ __forceinline__ double quad_bcast(double v) {
 }
 
 template <typename AT>
-__global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, const void* actions, const uint8_t* active,
-                                                  uint32_t stages, double* kin) {
+__global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_list, const double* state, const void* actions,
+                                                  const uint8_t* active, uint32_t stages, double* kin) {
+    // n entries of scene_list (a tile class's dense list: the kinematics head each class's launch chain), or scenes 0..n-1
     __shared__ double buf[KIN_SCENES_PER_BLOCK * KIN_WORDS];
+    __shared__ int sid[KIN_SCENES_PER_BLOCK];
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
-    const int scene = blockIdx.x * KIN_SCENES_PER_BLOCK + ls;
-    const bool live = scene < n && !(active && !active[scene]);
+    const int idx = blockIdx.x * KIN_SCENES_PER_BLOCK + ls;
+    const int scene = idx < n ? (scene_list ? scene_list[idx] : idx) : -1;
+    const bool live = scene >= 0 && !(active && !active[scene]);
     if (__all(!live)) return;
+    if (q == 0) sid[ls] = live ? scene : -1;
     const int sc_ = live ? scene : 0;
     const double* st = state + (size_t)sc_ * ST_WORDS;
     double x = st[0], y = st[1], h = st[2];
@@ -306,12 +310,10 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const double* state, c
         out[9] = h; out[19] = c_; out[29] = s_; out[39] = x; out[49] = y;
     }
     __syncthreads();
-    const int first = blockIdx.x * KIN_SCENES_PER_BLOCK;
-    const int n_here = min(KIN_SCENES_PER_BLOCK, n - first);
-    double* dst = kin + (size_t)first * KIN_WORDS;
-    for (int w = threadIdx.x; w < n_here * KIN_WORDS; w += WAVE) {
+    for (int w = threadIdx.x; w < KIN_SCENES_PER_BLOCK * KIN_WORDS; w += WAVE) {     // one 400-byte row per scene
         const int s = w / KIN_WORDS;
-        if (!active || active[first + s]) dst[w] = buf[w];
+        const int sc = sid[s];
+        if (sc >= 0) kin[(size_t)sc * KIN_WORDS + (w - s * KIN_WORDS)] = buf[w];
     }
 }
 

@@ -201,6 +201,11 @@ int hope_env_upload_state(hope_env_t *h, const double *pose, const int32_t *t, c
  * from IEEE-exact operations only, so the results must equal the host evaluation bit for bit. */
 int hope_debug_math(int fn, int n, const double *a, const double *b, double *out, void *stream);
 
+/* Cycle accounting of the Reeds-Shepp validation kernel: 16 counters accumulated by the instrumented build that the library
+ * launches when the environment variable HOPE_RS_TIMING is set (hope_amd/csrc/hope_rs.hip lists the sections); zeros
+ * otherwise.  Host-synchronous.  tools/rs_timing.py prints the breakdown. */
+int hope_debug_rs_prof(uint64_t *out /*[16]*/, int reset);
+
 /* ---- introspection ---------------------------------------------------------------------------- */
 int hope_env_num_scenes(const hope_env_t *h);
 int hope_env_max_obstacles(const hope_env_t *h);
