@@ -184,6 +184,7 @@ def main():
         one_step(i)
     torch.cuda.synchronize(dev)
     if not args.graph:
+        env.kernel_union_ms(reset=True)
         env.kernel_ms(reset=True)
     if dist is not None:
         dist.barrier()
@@ -200,13 +201,16 @@ def main():
     if args.graph:
         # graph replay: no per-launch events; the roofline below is stated on the whole step
         dom_stats = (elapsed * 1e3, args.steps)
+        dom_union = dom_stats
         kstats = {}
     else:
+        dom_union = env.kernel_union_ms(reset=True)[dom]
         dom_stats = env.kernel_ms(reset=True)[dom]
         env.profile_kernels(None)
         for i in range(n_break):
             one_step(args.warmup + args.steps + i)
         torch.cuda.synchronize(dev)
+        env.kernel_union_ms(reset=True)
         kstats = env.kernel_ms(reset=True)
     done_frac = float(env.done.float().mean().item())
     rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
@@ -299,6 +303,11 @@ def main():
                          'concurrent_launches': ('the launch chains of the two obstacle-tile classes run on two streams: the '
                                                  'k_env_step launches overlap each other and the other class\'s kernels, so '
                                                  'per-launch durations include that sharing') if env.overlap else None,
+                         # the same kernel per step CALL: all its launches' bytes over the time during which at least one of them
+                         # ran (the union of the launch intervals) -- what the kernel sustains while its launches overlap
+                         'per_call': {'kernel_ms': dom_union[0] / max(dom_union[1], 1), 'calls': dom_union[1],
+                                      'achieved': bytes_per_launch * args.steps / max(dom_union[1], 1) / (dom_union[0] / max(dom_union[1], 1) * 1e-3) / 1e9 if dom_union[0] > 0 else None,
+                                      'frac': bytes_per_launch * args.steps / max(dom_union[1], 1) / (dom_union[0] / max(dom_union[1], 1) * 1e-3) / 1e9 / 8000.0 if dom_union[0] > 0 else None},
                          'whole_step': {'achieved': bytes_per_launch / (elapsed / args.steps) / 1e9, 'unit': 'GB/s',
                                         'frac': bytes_per_launch / (elapsed / args.steps) / 1e9 / 8000.0,
                                         'note': 'algorithmic bytes of one bench step / driver-timed step'},

@@ -160,6 +160,14 @@ class ParkingBatch:
         L.check(self.lib.hope_env_kernel_ms(self.h, ms.ctypes.data, cnt.ctypes.data, int(reset)), 'hope_env_kernel_ms')
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(L.KERNELS)}
 
+    def kernel_union_ms(self, reset=True):
+        """{kernel name: (accumulated ms during which >= 1 launch of the kernel ran, calls)}: per step call the UNION of the
+        kernel's launch intervals (the two tile classes overlap on two streams).  Read it before kernel_ms(reset=True)."""
+        ms = np.zeros(len(L.KERNELS))
+        cnt = np.zeros(len(L.KERNELS), np.int64)
+        L.check(self.lib.hope_env_kernel_union_ms(self.h, ms.ctypes.data, cnt.ctypes.data, int(reset)), 'hope_env_kernel_union_ms')
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(L.KERNELS)}
+
     def profile_kernels(self, names=None):
         """time only the listed kernels (names from _lib.KERNELS; None = all) -- every event pair costs launch latency"""
         mask = 0xffffffff if names is None else sum(1 << L.KERNELS.index(k) for k in names)

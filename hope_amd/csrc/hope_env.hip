@@ -62,7 +62,10 @@ struct hope_env {
     void* stage = nullptr;
     size_t stage_bytes = 0;
     // HOPE_F_PROFILE: event pairs recorded on the launch stream, drained by hope_env_kernel_ms
-    struct EvPair { hipEvent_t a, b; int kind; };
+    struct EvPair { hipEvent_t a, b; int kind; uint64_t seq; };   // seq: the hope_env_step / reset_obs call the launch belongs to
+    uint64_t step_seq = 0;
+    double union_ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};       // per kernel: time during which >= 1 launch of a call was running
+    int64_t union_calls[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> free_events;
     double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
@@ -137,20 +140,50 @@ struct EventTimer : LaunchTimer {
     void end(hipStream_t s) override {
         if (skip) return;
         if (failed || hipEventRecord(b, s) != hipSuccess) { failed = true; return; }
-        h->pending.push_back({a, b, kind});
+        h->pending.push_back({a, b, kind, h->step_seq});
     }
 };
 
 static int drain_events(hope_env* h) {
-    for (auto& p : h->pending) {
+    // per launch: duration; per (call, kernel): the union of its launches' intervals (with HOPE_F_OVERLAP the launches of the
+    // two tile classes run concurrently on two streams; event times are compared through hipEventElapsedTime)
+    for (size_t i = 0; i < h->pending.size(); i++) {
+        auto& p = h->pending[i];
         float ms = 0;
         hipError_t e = hipEventSynchronize(p.b);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.a, p.b);
         if (e != hipSuccess) return fail(HOPE_EHIP, std::string("event timing: ") + hipGetErrorString(e));
         h->ms[p.kind] += ms;
         h->launches[p.kind] += 1;
+    }
+    for (size_t i = 0; i < h->pending.size(); i++) {
+        auto& p = h->pending[i];
+        if (!p.a) continue;                                   // already merged into an earlier launch of its call
+        // intervals of this (call, kernel) relative to p.a: merge (at most a handful per call)
+        std::vector<std::pair<float, float>> iv;
+        for (size_t j = i; j < h->pending.size(); j++) {
+            auto& q = h->pending[j];
+            if (!q.a || q.kind != p.kind || q.seq != p.seq) continue;
+            float t0 = 0, t1 = 0;
+            hipError_t e = hipSuccess;
+            if (j != i) { hipEventSynchronize(q.b); e = hipEventElapsedTime(&t0, p.a, q.a); }
+            if (e == hipSuccess) e = hipEventElapsedTime(&t1, p.a, q.b);
+            if (e != hipSuccess) { t0 = 0; t1 = 0; }          // (a later event recorded "before" the reference: negative times are fine)
+            iv.push_back({t0, t1});
+            if (j != i) { h->free_events.push_back(q.a); h->free_events.push_back(q.b); q.a = nullptr; }
+        }
+        std::sort(iv.begin(), iv.end());
+        double total = 0, lo = iv[0].first, hi = iv[0].second;
+        for (size_t k = 1; k < iv.size(); k++) {
+            if (iv[k].first <= hi) hi = std::max<double>(hi, iv[k].second);
+            else { total += hi - lo; lo = iv[k].first; hi = iv[k].second; }
+        }
+        total += hi - lo;
+        h->union_ms[p.kind] += total;
+        h->union_calls[p.kind] += 1;
         h->free_events.push_back(p.a);
         h->free_events.push_back(p.b);
+        p.a = nullptr;
     }
     h->pending.clear();
     return HOPE_OK;
@@ -661,6 +694,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
     const bool prof = h->flags & HOPE_F_PROFILE;
+    h->step_seq++;
     if (h->flags & HOPE_F_GRAPH) {
         // The caller's stream may be the null stream, which cannot be captured: the graph lives on a library stream that
         // is ordered after / before the caller's stream with two events.
@@ -829,6 +863,21 @@ int hope_env_kernel_ms(hope_env_t* h, double* ms, int64_t* launches, int reset) 
         if (ms) ms[k] = h->ms[k];
         if (launches) launches[k] = h->launches[k];
         if (reset) { h->ms[k] = 0; h->launches[k] = 0; }
+    }
+    return HOPE_OK;
+}
+
+int hope_env_kernel_union_ms(hope_env_t* h, double* ms, int64_t* calls, int reset) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_kernel_union_ms: null handle");
+    if (!(h->flags & HOPE_F_PROFILE)) return fail(HOPE_ESTATE, "hope_env_kernel_union_ms: handle was not created with HOPE_F_PROFILE");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    int rc = drain_events(h);
+    if (rc) return rc;
+    for (int k = 0; k < HOPE_N_KERNELS; k++) {
+        if (ms) ms[k] = h->union_ms[k];
+        if (calls) calls[k] = h->union_calls[k];
+        if (reset) { h->union_ms[k] = 0; h->union_calls[k] = 0; }
     }
     return HOPE_OK;
 }

@@ -185,6 +185,11 @@ int hope_env_download_pool_index(hope_env_t *h, int32_t *out /*[N]*/);
 #define HOPE_N_KERNELS 7
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
+/* Same bookkeeping, per CALL instead of per launch: for every hope_env_step / hope_env_reset_obs call and kernel, the time
+ * during which at least one launch of that kernel was running (with HOPE_F_OVERLAP the launches of the two tile classes run
+ * concurrently on two streams, so this union is shorter than the sum of the per-launch durations).  ms / calls: arrays of
+ * HOPE_N_KERNELS entries.  Host-synchronous; call it BEFORE hope_env_kernel_ms with reset (both drain the same events). */
+int hope_env_kernel_union_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *calls /*[HOPE_N_KERNELS]*/, int reset);
 /* Restricts the event bracketing to the kernels whose bit (1 << HOPE_K_*) is set; default all.  An event pair costs
  * a few microseconds of launch latency, so a throughput measurement times only the kernel it reports on. */
 int hope_env_profile_kernels(hope_env_t *h, uint32_t kernel_mask);
