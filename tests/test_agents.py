@@ -101,7 +101,7 @@ def check_ppo_update(dev, n_rows, tol=5e-4):
 
     def mse(a, b):
         v = real_mse(a, b)
-        rec['c'].append(float(v))
+        rec["c"].append(float(v.detach()))
         return v
     A.F.mse_loss = mse
     try:
