@@ -546,10 +546,9 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 // ================================================================================================
 // Kernel B: find_rs_path's main loop (:436-450) over the ordered words
 // ================================================================================================
-// LDS: tile 8*M doubles | obstacle boxes M float4 | scratch (doubles): segment params 6 words x 5 x 8, sample queue pd[192], bad1[6+2],
+// LDS: tile 8*M doubles | obstacle boxes M float4 | scratch (doubles): segment params 5 x 10, sample queue pd[256], bad1[6+2],
 //      the head of the search record (header + 14 words) | ints: cand[M] | bytes: seg[256]
-constexpr int RSB_BATCH = 6;                                   // words whose segment origins are set up together (10 lanes each)
-constexpr int RSB_SEG = 0, RSB_SEGW = 8, RSB_QPD = RSB_BATCH * 5 * RSB_SEGW, RSB_QCAP = 192, RSB_BAD = RSB_QPD + RSB_QCAP, RSB_REC = RSB_BAD + 8;
+constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_QCAP = 256, RSB_BAD = RSB_QPD + RSB_QCAP, RSB_REC = RSB_BAD + 8;
 constexpr int RSB_REC_WORDS = 14;                              // words of the record kept in LDS (two 512-byte loads)
 constexpr int RSB_WORDS = RSB_REC + RS_REC_HDR + 8 * RSB_REC_WORDS;
 
@@ -614,80 +613,74 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     RS_T(0);
     for (int idx = 1; idx <= n_paths; idx++) {            // the stop rule (:443) is already applied: n_paths ends there
         if ((obs_f64 & 0x200) && idx > 1) break;          // profiling switch: first path only
-        // ---- segment origins of the next RSB_BATCH words, all at once ------------------------------------------------
-        // generate_local_course (:452-507) needs, per segment, its origin (ox, oy, oyaw) = the end point of the previous
-        // segment (interpolate(ind, l, ...) :497-498).  The origin headings are plain sums (oyaw_{i+1} = oyaw_i +- l_i), so
-        // every sine / cosine a word needs -- of its five origin headings and of its five segment lengths -- is one
-        // lane's share of ONE sincos call: lane 10 w + r serves word w (r < 5: heading r, r >= 5: length r - 5), six words
-        // per call.  The sequential origin accumulation then runs on one lane per word.  (Setting the words up one at a
-        // time with wave-uniform arithmetic was 26 % of this kernel's cycles: ~600 instructions per tested word.)
-        const int wb = (idx - 1) % RSB_BATCH;
-        if (wb == 0) {
-            const int nb = min(RSB_BATCH, n_paths - (idx - 1));
-            const int wj = lane / 10, r = lane - 10 * wj;
-            const bool mine = wj < nb;
-            double arg = 0;
-            const double* Wm = wl + RS_REC_HDR;
-            if (mine) {
-                const int pj = order[idx - 1 + wj];
-                Wm = (pj < RSB_REC_WORDS) ? (const double*)(wl + RS_REC_HDR + 8 * pj) : rec + RS_REC_HDR + 8 * pj;
-                const int cj = __double2loint(Wm[6]);
-                if (r >= 5) arg = Wm[r - 5];
-                else {
+        const int pi = order[idx - 1];                    // push index of the idx-th popped word
+        double len[5];
+        int code, nseg;
+        if (pi < RSB_REC_WORDS) {                         // wave-uniform
+            const double* W = wl + RS_REC_HDR + 8 * pi;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if (i < r) {
-                            const int m = type_of(cj, i);
-                            const double li = Wm[i];
-                            arg = (m == TL) ? arg + li : ((m == TR) ? arg - li : arg);
-                        }
-                    }
-                }
+            for (int i = 0; i < 5; i++) len[i] = W[i];
+            code = __double2loint(W[6]); nseg = __double2hiint(W[6]);
+        } else {
+            const double* W = rec + RS_REC_HDR + 8 * pi;
+#pragma unroll
+            for (int i = 0; i < 5; i++) len[i] = W[i];
+            code = __double2loint(W[6]); nseg = __double2hiint(W[6]);
+        }
+        const int cls1 = type_of(code, 0) * 2 + (len[0] > 0.0 ? 1 : 0);
+        if (!(obs_f64 & 0x800) && fabs(len[0]) >= bad1[cls1]) continue;    // contains a sample already known to collide
+
+        // generate_local_course (:452-507).  Samples are queued as (pd, segment) and collision-tested 64 at a
+        // time, so short segments share a pass.  Sample 0 (the start pose, local (0,0,0)) = segment 0 at pd = 0.
+        //
+        // Segment origins first.  The origin headings are plain sums (oyaw_{i+1} = oyaw_i +- l_i), so every
+        // sine/cosine the path needs -- of the five origin headings and of the five segment lengths (for the
+        // segment end points, interpolate(ind, l, ...) :497-498) -- comes from ONE lane-parallel sincos
+        // (lanes 0-4: headings, lanes 5-9: lengths); hm_cos(-x) = cos x and hm_sin(-x) = -sin x give :522-523.
+        bool invalid = false;
+        {
+            double hy[5];
+            hy[0] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = type_of(code, i);
+                hy[i + 1] = (m == TL) ? hy[i] + len[i] : ((m == TR) ? hy[i] - len[i] : hy[i]);
+            }
+            double arg = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (lane == i) arg = hy[i];
+                if (lane == 5 + i) arg = len[i];
             }
             double sv, cv;
             hm_sincos(arg, &sv, &cv);
-            qpd[lane] = sv; qpd[WAVE + lane] = cv; qpd[2 * WAVE + lane] = arg;      // the sample queue is empty between words
+            double ox = 0, oy = 0;
             wsync();
-            if (mine && r == 0) {
-                const int cj = __double2loint(Wm[6]), nj = __double2hiint(Wm[6]);
-                double ox = 0, oy = 0;
-                double* sb = segp + wj * 5 * RSB_SEGW;
 #pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    if (i < nj) {
-                        const int m = type_of(cj, i);
-                        const double l = Wm[i];
-                        const double s_oy = qpd[10 * wj + i], c_oy = qpd[WAVE + 10 * wj + i];
-                        const double sl = qpd[10 * wj + 5 + i], cl = qpd[WAVE + 10 * wj + 5 + i];
-                        double* sp_ = sb + RSB_SEGW * i;
-                        sp_[0] = ox; sp_[1] = oy; sp_[2] = qpd[2 * WAVE + 10 * wj + i]; sp_[3] = c_oy; sp_[4] = s_oy;
-                        sp_[5] = (double)m; sp_[6] = l;
-                        if (m == TS) {                               // interpolate(l) = next origin (:512-513)
-                            ox = ox + l / MAXC * c_oy;
-                            oy = oy + l / MAXC * s_oy;
-                        } else {
-                            const double ldx = sl / MAXC;
-                            const double ldy = (m == TL) ? (1.0 - cl) / MAXC : (1.0 - cl) / (-MAXC);
-                            ox = ox + (c_oy * ldx + (-s_oy) * ldy);
-                            oy = oy + (s_oy * ldx + c_oy * ldy);
-                        }
+            for (int i = 0; i < 5; i++) {
+                if (i < nseg) {
+                    const int m = type_of(code, i);
+                    const double c_oy = readlane_d(cv, i), s_oy = readlane_d(sv, i);
+                    const double sl = readlane_d(sv, 5 + i), cl = readlane_d(cv, 5 + i);
+                    if (lane == 0) {
+                        double* sp_ = segp + RSB_SEGW * i;
+                        sp_[0] = ox; sp_[1] = oy; sp_[2] = hy[i]; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_oy; sp_[6] = -s_oy;
+                        sp_[7] = (double)m; sp_[8] = len[i];
+                    }
+                    const double l = len[i];
+                    if (m == TS) {                                   // interpolate(l) = next origin (:512-513)
+                        ox = ox + l / MAXC * c_oy;
+                        oy = oy + l / MAXC * s_oy;
+                    } else {
+                        const double ldx = sl / MAXC;
+                        const double ldy = (m == TL) ? (1.0 - cl) / MAXC : (1.0 - cl) / (-MAXC);
+                        ox = ox + (c_oy * ldx + (-s_oy) * ldy);
+                        oy = oy + (s_oy * ldx + c_oy * ldy);
                     }
                 }
             }
-            wsync();
+            if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
         }
-        const double* seg = segp + wb * 5 * RSB_SEGW;    // this word's segment table
-        const int pi = order[idx - 1];                    // push index of the idx-th popped word
-        const double w6 = (pi < RSB_REC_WORDS) ? wl[RS_REC_HDR + 8 * pi + 6] : rec[RS_REC_HDR + 8 * pi + 6];
-        const int code = __double2loint(w6), nseg = __double2hiint(w6);
-        const double len0 = seg[6];
-        const int cls1 = type_of(code, 0) * 2 + (len0 > 0.0 ? 1 : 0);
-        if (!(obs_f64 & 0x800) && fabs(len0) >= bad1[cls1]) continue;    // contains a sample already known to collide
-
-        // Samples are queued as (pd, segment) and collision-tested 64 at a time, so short segments share a pass.
-        // Sample 0 (the start pose, local (0,0,0)) = segment 0 at pd = 0.
-        bool invalid = false;
-        if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
         int nq = 1;
         wsync();
         if (TIMING) tsec[9] += 1;
@@ -702,7 +695,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
         // (64 samples in path order) as early as possible -- invalid paths mostly hit something within their first
         // metres (measured 128 / 130 / 160 / 194 / 258: 0.645 / 0.659 / 0.689 / 0.759 / 0.778 ms).  At least 128: the
         // generator must always be able to bring the queue to a whole wave.
-        constexpr int win = 128;
+        const int win = (obs_f64 >> 12) ? min(max(obs_f64 >> 12, 128), RSB_QCAP - WAVE - 1) : 128;
         int i = 0;
         bool seg_open = false, finished = false;
         double pd = 0, ll = 0.0, lprev = 0.0, d = 0, l = 0;
@@ -710,7 +703,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
             while (!finished && nq + WAVE + 1 <= win) {
                 if (TIMING) tsec[10] += 1;
                 if (!seg_open) {
-                    l = seg[RSB_SEGW * i + 6];                // len[i]
+                    l = segp[RSB_SEGW * i + 8];               // len[i]
                     d = l > 0.0 ? step : -step;
                     if (i >= 1 && (lprev * l) > 0) pd = -d - ll; else pd = d - ll;
                     lprev = l;
@@ -771,9 +764,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
                 double px = 0, py = 0, pyaw = 0;
                 if (active) {
                     const double spd = qpd[idx];
-                    const double* sp_ = seg + RSB_SEGW * (int)qseg[idx];
-                    const int m = (int)sp_[5];
-                    interpolate(spd, m, sp_[0], sp_[1], sp_[2], sp_[3], -sp_[4], sp_[3], sp_[4], px, py, pyaw);   // cos(-oyaw), sin(-oyaw)
+                    const double* sp_ = segp + RSB_SEGW * (int)qseg[idx];
+                    const int m = (int)sp_[7];
+                    interpolate(spd, m, sp_[0], sp_[1], sp_[2], sp_[5], sp_[6], sp_[3], sp_[4], px, py, pyaw);
                 }
                 const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
                 const double wy = -s_q * px + c_q * py + q0y;
@@ -855,12 +848,9 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     size_t lds = rs_lds_bytes(p.tile_cap);
     // register budget of the validation kernel: 4 waves / SIMD (128 VGPRs, some spills) or 3 (168 VGPRs); HOPE_RS_OCC picks
     static const bool timing = getenv("HOPE_RS_TIMING") != nullptr;      // cycle accounting build (tools/rs_timing.py)
-    static const int occ_env = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 3;   // the 4-wave build (50 spilled VGPRs) hung on the GPU: kept for experiments only
-    // HOPE_RS_OCC=23: 2 waves / SIMD (195 VGPRs, no spills) for the large-tile class, whose LDS tile allows only 2.5 anyway
-    const int occ = occ_env == 23 ? (p.tile_cap > 32 ? 2 : 3) : occ_env;
+    static const int occ = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 3;   // the 4-wave build (50 spilled VGPRs) hung on the GPU: kept for experiments only
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(timing ? (occ == 2 ? (const void*)k_rs_validate<2, true> : (const void*)k_rs_validate<3, true>)
-                                           : occ == 2 ? (const void*)k_rs_validate<2, false> : occ == 3 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>,
+        hipError_t e = hipFuncSetAttribute(timing ? (const void*)k_rs_validate<3, true> : occ == 3 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -870,9 +860,7 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->end(stream);
     static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
-    if (timing && occ == 2) hipLaunchKernelGGL((k_rs_validate<2, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
-    else if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
-    else if (occ == 2) hipLaunchKernelGGL((k_rs_validate<2, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
     else if (occ == 3) hipLaunchKernelGGL((k_rs_validate<3, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
     else hipLaunchKernelGGL((k_rs_validate<4, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
     if (timer) timer->end(stream);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel averages of the raw SQ counters collected by tools/pmc_sq.sh (second half of the launches of each kernel).
 Also writes <dir>/sq_counters.json: per-launch averages per kernel and the VALU / SALU instructions of one bench step
-(launches per step = launches of the kernel / launches of k_kinematics, which runs once per env step with an action)."""
+(launches per step = launches of the kernel / 16 env steps of the profiled command, rounded)."""
 import csv
 import json
 import glob
@@ -39,12 +39,14 @@ for k, cs in acc.items():
                 print(f'   frac of wave cycles {c:20s} {vals[c] / wc:8.3f}')
 
 summary = {'unit': 'per launch, average over the second half of the launches in the profiled run', 'kernels': {}}
-kin = len(next(iter(acc.get('k_kinematics', {'x': [0]}).values()))) or 1
+# tools/pmc_sq.sh profiles `bench.py --steps 4 --warmup 8`: 8 + 4 timed + 4 breakdown = 16 env steps with an action (plus one
+# action-less reset_obs, which also launches the class kernels once)
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 tot_valu = tot_salu = 0.0
 for k, cs in acc.items():
     per = {c: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for c, v in cs.items()}
     nl = len(next(iter(cs.values())))
-    per['launches_per_bench_step'] = round(nl / kin) if k != 'k_kinematics' else 1
+    per['launches_per_bench_step'] = max(1, round(nl / STEPS))
     summary['kernels'][k] = per
     tot_valu += per.get('SQ_INSTS_VALU', 0.0) * per['launches_per_bench_step']
     tot_salu += per.get('SQ_INSTS_SALU', 0.0) * per['launches_per_bench_step']
