@@ -683,27 +683,28 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                     lo = ((ilo % NBEAM) + NBEAM) % NBEAM;
                 }
             }
-            // Append the pairs to the queue four beams per lane and round: the lanes' counts (0..4) are prefix-summed
-            // through three ballots (bit planes), one reservation per round instead of a ballot + popcount per beam
-            // (the per-beam loop was ~14 instructions per step of the widest edge, ~16 % of this kernel's issue slots).
-            int rem = cnt, kk = 0;
-            const unsigned long long lt = (1ull << lane) - 1;
-            while (__any(rem > 0)) {
-                const int c = rem < 4 ? rem : 4;
-                const unsigned long long m0 = __ballot((c & 1) != 0), m1 = __ballot((c & 2) != 0), m2 = __ballot((c & 4) != 0);
-                const int pre = __popcll(m0 & lt) + 2 * __popcll(m1 & lt) + 4 * __popcll(m2 & lt);
-                const int total = __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
-                if (qn + total > LQ) drain();
-                const int off = qn + pre;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (u < c) {
-                        int bi = lo + kk + u;
-                        if (bi >= NBEAM) bi -= NBEAM;
-                        queue[off + u] = (e << 7) | bi;
-                    }
+            // Append the pairs to the queue EDGE BY EDGE: for every edge with beams (a scalar walk over the ballot) its range
+            // [lo, lo + cnt) is written by the lanes 0 .. cnt-1 in one store -- no per-beam ballots / prefix counts at all
+            // (a lane-per-edge loop over the beams cost ~14 VALU instructions per beam of the widest edge; a four-beams-per-
+            // round variant with bit-plane prefix sums ~8).
+            unsigned long long todo = __ballot(cnt > 0);
+            while (todo) {
+                const int el = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int lo_e = __builtin_amdgcn_readlane(lo, el), cnt_e = __builtin_amdgcn_readlane(cnt, el);
+                if (qn + cnt_e > LQ) drain();
+                const int tag = (base + el) << 7;
+                if (lane < cnt_e) {
+                    int bi = lo_e + lane;
+                    if (bi >= NBEAM) bi -= NBEAM;
+                    queue[qn + lane] = tag | bi;
                 }
-                qn += total; rem -= c; kk += c;
+                if (cnt_e > WAVE && lane + WAVE < cnt_e) {        // an edge that spans more than 64 beams
+                    int bi = lo_e + lane + WAVE;
+                    if (bi >= NBEAM) bi -= NBEAM;
+                    queue[qn + lane + WAVE] = tag | bi;
+                }
+                qn += cnt_e;
             }
         }
     }
