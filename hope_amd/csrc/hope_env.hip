@@ -451,6 +451,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
     if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -494,6 +495,18 @@ int hope_env_destroy(hope_env_t* h) {
         if (q) hipFree(q);
     delete h;
     return HOPE_OK;
+}
+
+int hope_debug_step_prof(uint64_t* out, int reset) {
+    static unsigned long long buf[64 * 16];
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_step_prof), sizeof(buf));
+    for (int i = 0; i < 16; i++) { out[i] = 0; for (int sh = 0; sh < 64; sh++) out[i] += buf[sh * 16 + i]; }
+    if (e == hipSuccess && reset) {
+        for (auto& v : buf) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_step_prof), buf, sizeof(buf));
+    }
+    return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_step_prof: ") + hipGetErrorString(e));
 }
 
 int hope_debug_rs_prof(uint64_t* out, int reset) {
@@ -589,6 +602,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     // waves): k_env_step -> k_rs_compact -> k_rs_words -> k_rs_validate.  The chains share nothing but read-only data
     // (own scene list, own queue counter, record slots filled from opposite ends), so with a side stream they run
     // concurrently from the fork after the kinematics to the join before the image.
+    static const bool step_timing = getenv("HOPE_STEP_TIMING") != nullptr;      // cycle accounting build (tools/step_timing.py)
     const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
     const bool want_rs = (stages & HOPE_STAGE_RS) && out->rs_word;
     // chains: (class, sub-list) pairs with work, the large-tile class first (its chains are the longer ones)
@@ -629,6 +643,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, sc, p);
         else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, sc, p);
         else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, sc, p);
+        else if (step_timing) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sc, p);
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
         if (tm) tm->end(sc);
         if (fork && (stages & HOPE_STAGE_IMG) && i < 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses

@@ -317,11 +317,24 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
     }
 }
 
-template <typename OT, typename AT>
+// Cycle accounting of the step kernel (the <float, float, true> instantiation, launched when HOPE_STEP_TIMING is set;
+// tools/step_timing.py): [0] staging + near list [1] sub-step loop [2] status, reward, turnover, outputs, target
+// [3] lidar: ego transform + ring keep [4] lidar: per-edge beam ranges [5] lidar: enqueue [6] lidar: exact pairs (drain)
+// [7] action mask [8] whole wave [9] waves
+__device__ unsigned long long g_step_prof[64 * 16];
+#define ST_T0() unsigned long long t0_ = TIMING ? __builtin_readcyclecounter() : 0
+#define ST_T(i) do { if (TIMING) { const unsigned long long t1_ = __builtin_readcyclecounter(); tsec[i] += t1_ - t0_; t0_ = t1_; } } while (0)
+#define ST_FLUSH() do { if (TIMING) { tsec[8] = __builtin_readcyclecounter() - tstart_; tsec[9] = 1; \
+        if (lane == 0) for (int i_ = 0; i_ < 16; i_++) if (tsec[i_]) atomicAdd(&g_step_prof[(blockIdx.x & 63) * 16 + i_], tsec[i_]); } } while (0)
+
+template <typename OT, typename AT, bool TIMING = false>
 __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= p.n_list) return;
+    unsigned long long tsec[16] = {};
+    const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
+    ST_T0();
     if (p.rs_count_zero && blockIdx.x == 0 && threadIdx.x == 0) p.rs_count_zero[0] = 0;   // this class's queue length
     const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
     if (p.active && !p.active[scene]) return;
@@ -363,6 +376,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     const int n_near = build_near_list(tile, n_obst, x, y, moving ? 5.2 : 3.9, nlist, lane);
     if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
     wsync();
+    ST_T(0);
 
     if (moving) {
         // the ten sub-step poses (x, y, heading, cos, sin) were produced by k_kinematics (one THREAD per scene):
@@ -453,6 +467,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (!have_cs) hm_sincos(h, &sn, &ct);
     Box box = make_box(x, y, ct, sn);
 
+    ST_T(1);
     // ---- status (:279-282, _check_status :175-184) -------------------------------------------------
     int status = HOPE_STATUS_CONTINUE;
     if (p.stages & (HOPE_STAGE_REWARD | HOPE_STAGE_RS)) {
@@ -570,7 +585,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     }
     if (p.out.rs_lengths && lane < 5) ((OT*)p.out.rs_lengths)[5 * (size_t)scene + lane] = (OT)0;
 
-    if (!(p.stages & HOPE_STAGE_OBS)) return;
+    if (!(p.stages & HOPE_STAGE_OBS)) { ST_T(2); ST_FLUSH(); return; }
 
     // ---- target representation (_get_targt_repr :372-381; 5th entry is cos again) ---------------
     if (p.out.target) {
@@ -591,6 +606,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         }
     }
 
+    ST_T(2);
     // ---- lidar (lidar_simulator.py:31-135) -----------------------------------------------------------
     // world -> ego in place: affine [a, b, -b, a, x_off, y_off] (:58-64)
     {
@@ -617,6 +633,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         if (e < n_slots && (e & 3) == 0) keep[e >> 2] = dd < LIDAR_RANGE;
     }
     wsync();
+    ST_T(3);
     // beams: lane l owns beams l and l+64.  Two passes (SIMT pays for the union of lanes, and every edge is
     // crossed by SOME beam, so the two float64 divisions of a pair must not sit in the lane-per-beam loop):
     //  pass 1 (cheap): per kept edge each lane tests its beams with exact-safe necessary conditions and
@@ -635,6 +652,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     wsync();
     int qn = 0;
     auto drain = [&]() {
+        const unsigned long long td_ = TIMING ? __builtin_readcyclecounter() : 0;
         wsync();
         for (int q0 = 0; q0 < qn; q0 += WAVE) {
             int q = q0 + lane;
@@ -652,6 +670,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         }
         wsync();
         qn = 0;
+        if (TIMING) { const unsigned long long dt_ = __builtin_readcyclecounter() - td_; tsec[6] += dt_; t0_ += dt_; }
     };
     // pass 1, one lane per edge slot: the beams that can see an edge are those inside the angle it subtends at
     // the sensor (a segment not through the origin subtends < pi).  The range is taken from float32 atan2 with
@@ -687,6 +706,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             // [lo, lo + cnt) is written by the lanes 0 .. cnt-1 in one store -- no per-beam ballots / prefix counts at all
             // (a lane-per-edge loop over the beams cost ~14 VALU instructions per beam of the widest edge; a four-beams-per-
             // round variant with bit-plane prefix sums ~8).
+            ST_T(4);
             unsigned long long todo = __ballot(cnt > 0);
             while (todo) {
                 const int el = __ffsll((long long)todo) - 1;
@@ -706,6 +726,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 }
                 qn += cnt_e;
             }
+            ST_T(5);
         }
     }
     if (qn > 0) drain();
@@ -719,7 +740,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         lo[i0] = (OT)lid0;
         if (has1) lo[i1] = (OT)lid1;
     }
-    if (!p.out.action_mask || (p.stages & 0x2000)) return;    // 0x2000: internal profiling switch
+    ST_T(5);
+    if (!p.out.action_mask || (p.stages & 0x2000)) { ST_FLUSH(); return; }    // 0x2000: internal profiling switch
 
     // ---- action mask (action_mask.py:166-196) ----------------------------------------------------------
     wsync();                                                      // region A: best[]/queue[] are dead from here
@@ -841,6 +863,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     unsigned long long nz = __ballot(lane < NACT && mn > 0);
     if (nz == 0) mo = clipd(mo, 0.01, 1);                          // all-zero -> 0.01 (:182-183)
     if (lane < NACT) ((OT*)p.out.action_mask)[(size_t)NACT * scene + lane] = (OT)mo;
+    ST_T(7);
+    ST_FLUSH();
 }
 
 }  // namespace hope

@@ -210,6 +210,8 @@ int hope_debug_math(int fn, int n, const double *a, const double *b, double *out
  * launches when the environment variable HOPE_RS_TIMING is set (hope_amd/csrc/hope_rs.hip lists the sections); zeros
  * otherwise.  Host-synchronous.  tools/rs_timing.py prints the breakdown. */
 int hope_debug_rs_prof(uint64_t *out /*[16]*/, int reset);
+/* the same for k_env_step (environment variable HOPE_STEP_TIMING; float32 observation / action handles); tools/step_timing.py */
+int hope_debug_step_prof(uint64_t *out /*[16]*/, int reset);
 
 /* ---- introspection ---------------------------------------------------------------------------- */
 int hope_env_num_scenes(const hope_env_t *h);
