@@ -606,24 +606,36 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     const int n_cls = h->max_obst > SMALL_TILE ? 2 : 1;
     const bool want_rs = (stages & HOPE_STAGE_RS) && out->rs_word;
     // chains: (class, sub-list) pairs with work, the large-tile class first (its chains are the longer ones)
-    struct Chain { int c, a, b; };
+    struct Chain { int c, a, b, st; };                      // st: 0 = the caller's stream, k = side[k]
     Chain chains[hope_env::MAX_CHAINS];
-    int n_chain = 0;
+    int n_chain = 0, n_streams = 1;
     const int subs = overlap ? h->sub_chains : 1;
-    for (int c = n_cls - 1; c >= 0; c--)
-        for (int j = 0; j < subs; j++) {
-            const int a = (int)((long long)h->cls_count[c] * j / subs), b = (int)((long long)h->cls_count[c] * (j + 1) / subs);
-            if (b > a) chains[n_chain++] = {c, a, b};
-        }
-    const bool fork = overlap && n_chain > 1;
+    static const int balance = getenv("HOPE_BALANCE") ? atoi(getenv("HOPE_BALANCE")) : 100;
+    if (overlap && subs == 1 && n_cls == 2 && balance < 100 && h->cls_count[0] > 0 && h->cls_count[1] > 0) {
+        // two streams, three chains: the large-tile class, then the tail of the small-tile class behind it on the side stream,
+        // the head of the small-tile class on the caller's stream -- so that both streams finish together
+        const int cut = (int)((long long)h->cls_count[0] * balance / 100);
+        chains[n_chain++] = {1, 0, h->cls_count[1], 1};
+        if (cut > 0) chains[n_chain++] = {0, 0, cut, 0};
+        if (cut < h->cls_count[0]) chains[n_chain++] = {0, cut, h->cls_count[0], 1};
+        n_streams = 2;
+    } else {
+        for (int c = n_cls - 1; c >= 0; c--)
+            for (int j = 0; j < subs; j++) {
+                const int a = (int)((long long)h->cls_count[c] * j / subs), b = (int)((long long)h->cls_count[c] * (j + 1) / subs);
+                if (b > a) { chains[n_chain] = {c, a, b, overlap ? n_chain : 0}; n_chain++; }
+            }
+        n_streams = overlap ? n_chain : 1;
+    }
+    const bool fork = overlap && n_streams > 1;
     if (fork) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
-        for (int i = 1; i < n_chain; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
+        for (int i = 1; i < n_streams; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
     }
     for (int i = 0; i < n_chain; i++) {
         const Chain& ch = chains[i];
         const int c = ch.c;
-        hipStream_t sc = (fork && i > 0) ? h->side[i] : s;
+        hipStream_t sc = (fork && ch.st > 0) ? h->side[ch.st] : s;
         int32_t* counter = h->rs_count + i;
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.scene_list = h->cls_list[c] + ch.a;
@@ -646,7 +658,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else if (step_timing) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sc, p);
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
         if (tm) tm->end(sc);
-        if (fork && (stages & HOPE_STAGE_IMG) && i < 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses
+        if (fork && (stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses
         if (!want_rs) continue;
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
@@ -682,13 +694,13 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             HIPCHK(launch_bev_image(b, si, tm));
             HIPCHK(hipEventRecord(h->ev_join[2], si));
         } else {
-            if (fork) for (int i = 1; i < n_chain; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
+            if (fork) for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
             HIPCHK(launch_bev_image(b, s, tm));
             return HOPE_OK;
         }
     }
     if (fork) {
-        for (int i = 1; i < n_chain; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
+        for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
         if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
     }
     return HOPE_OK;
