@@ -12,7 +12,7 @@ ACTION_PHYSICAL = 0x10
 STAGE_IMG = 0x40
 IMG_SIZE, IMG_CHANNELS, TRAJ_RENDER_LEN = 64, 3, 20
 AUTO_RESET = 0x20
-KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_rs_compact')
+KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_rs_compact', 'k_post')
 ABI_VERSION = 3
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',

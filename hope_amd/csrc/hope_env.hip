@@ -49,6 +49,7 @@ struct hope_env {
     int32_t* rs_list = nullptr;
     uint8_t* rs_flag = nullptr;
     double* kin = nullptr;
+    double* post = nullptr;        // [n][POST_WORDS] k_env_step -> k_post hand-over
     double* traj = nullptr;        // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory
     int32_t* traj_len = nullptr;   // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
     int32_t* traj_valid = nullptr; // HOPE_F_IMAGE: [n] entries below this index have span tables in bev_scratch
@@ -64,12 +65,12 @@ struct hope_env {
     // HOPE_F_PROFILE: event pairs recorded on the launch stream, drained by hope_env_kernel_ms
     struct EvPair { hipEvent_t a, b; int kind; uint64_t seq; };   // seq: the hope_env_step / reset_obs call the launch belongs to
     uint64_t step_seq = 0;
-    double union_ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};       // per kernel: time during which >= 1 launch of a call was running
-    int64_t union_calls[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
+    double union_ms[HOPE_N_KERNELS] = {};       // per kernel: time during which >= 1 launch of a call was running
+    int64_t union_calls[HOPE_N_KERNELS] = {};
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
-    int64_t launches[HOPE_N_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
+    double ms[HOPE_N_KERNELS] = {};
+    int64_t launches[HOPE_N_KERNELS] = {};
     // scene pool (hope_env_set_pool): complete scenes resident in HBM; hope_env_redraw copies one into a finished slot
     int pool_n = 0;
     double* pool_verts = nullptr;   // [pool_n][max_obst][8]
@@ -423,6 +424,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->rs_list, 2 * N * sizeof(int32_t));
     ALLOC(h->rs_flag, N);
     ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
+    ALLOC(h->post, N * POST_WORDS * sizeof(double));
     ALLOC(h->cls_list[0], N * sizeof(int32_t));
     ALLOC(h->cls_list[1], N * sizeof(int32_t));
     ALLOC(h->rs_rec, N * rs_rec_bytes_per_scene());
@@ -490,7 +492,7 @@ int hope_env_destroy(hope_env_t* h) {
     if (h->gstream) hipStreamDestroy(h->gstream);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pool_verts, h->pool_c, h->pool_nobst, h->pool_state, h->pool_t, h->pool_cls[0], h->pool_cls[1], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pool_verts, h->pool_c, h->pool_nobst, h->pool_state, h->pool_t, h->pool_cls[0], h->pool_cls[1], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -592,7 +594,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     StepParams p;
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
     p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
-    p.actions = actions; p.active = active; p.kin = h->kin;
+    p.actions = actions; p.active = active; p.kin = h->kin; p.post = h->post;
     p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
@@ -659,6 +661,13 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
         if (tm) tm->end(sc);
         if (fork && (stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses
+        if (stages & (HOPE_STAGE_REWARD | HOPE_STAGE_OBS)) {    // reward / target arithmetic, one lane per scene
+            dim3 pg((p.n_list + WAVE - 1) / WAVE);
+            if (tm) tm->begin(HOPE_K_POST, sc);
+            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, p.out);
+            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, p.out);
+            if (tm) tm->end(sc);
+        }
         if (!want_rs) continue;
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);

@@ -182,7 +182,8 @@ int hope_env_download_pool_index(hope_env_t *h, int32_t *out /*[N]*/);
 #define HOPE_K_IMAGE 4         /* k_bev_image    (wave per scene tile: 16 per scene)         */
 #define HOPE_K_IMAGE_PREP 5    /* k_bev_prep     (wave per scene: map + new boxes' spans)    */
 #define HOPE_K_RS_COMPACT 6    /* k_rs_compact   (Reeds-Shepp work queues from per-scene flags) */
-#define HOPE_N_KERNELS 7
+#define HOPE_K_POST 7           /* k_post         (reward + target arithmetic, one lane per scene; per tile class) */
+#define HOPE_N_KERNELS 8
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
 /* Same bookkeeping, per CALL instead of per launch: for every hope_env_step / hope_env_reset_obs call and kernel, the time
