@@ -9,10 +9,11 @@ LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10,
 F_OBS_F64, F_ACTION_F64, F_PROFILE, F_IMAGE, F_OVERLAP, F_GRAPH = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 ACTION_PHYSICAL = 0x10
+ACTION_RESCALE_F32 = 0x80
 STAGE_IMG = 0x40
 IMG_SIZE, IMG_CHANNELS, TRAJ_RENDER_LEN = 64, 3, 20
 AUTO_RESET = 0x20
-KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_rs_compact', 'k_post')
+KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_rs_compact', 'k_post', 'k_rs_segs')
 ABI_VERSION = 3
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',

@@ -15,10 +15,13 @@ from .scenes import pack_scenes
 
 class ParkingBatch:
     def __init__(self, n_scenes, max_obstacles=128, device='cuda:0', obs_dtype=torch.float32,
-                 action_dtype=torch.float32, tables=None, profile=False, image=False, overlap=None, graph=False):
+                 action_dtype=torch.float32, tables=None, profile=False, image=False, overlap=None, graph=False,
+                 rescale_f32=False):
         """overlap: run the launch chains of the two obstacle-tile classes on two streams (default on: +15 % at 65 536
         scenes, +45 % at 4 096-8 192, measured).  graph: replay the step's launches as one hipGraph (the actions are copied
-        into a persistent buffer so that the captured pointers repeat); not combinable with profile."""
+        into a persistent buffer so that the captured pointers repeat); not combinable with profile.  rescale_f32: with
+        float32 actions, evaluate action_rescale in float32 as the reference does with gym's float32 Box
+        (env_wrapper.py:46-47); default: float64 arithmetic whatever the action dtype."""
         if not torch.cuda.is_available():
             raise L.HopeError('ParkingBatch needs a HIP device (torch.cuda.is_available() is False); no CPU fallback')
         self.lib = L.load_library()
@@ -33,6 +36,7 @@ class ParkingBatch:
         flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0) | (L.F_PROFILE if profile else 0) | (L.F_IMAGE if image else 0) | (L.F_OVERLAP if overlap else 0) | (L.F_GRAPH if graph else 0)
         self.graph, self.overlap = bool(graph), bool(overlap)
         self.image = bool(image)
+        self._action_bits = L.ACTION_RESCALE_F32 if (rescale_f32 and action_dtype == torch.float32) else 0
         h = C.c_void_p()
         L.check(self.lib.hope_env_create(C.byref(h), self.n, self.max_obst, self.device.index or 0, flags),
                 'hope_env_create')
@@ -137,6 +141,7 @@ class ParkingBatch:
             stages |= L.STAGE_IMG                    # USE_IMG (configs.py:100): the image is part of the observation
         if auto_reset:
             stages |= L.AUTO_RESET
+        stages |= self._action_bits
         assert actions.shape == (self.n, 2) and actions.dtype == self.action_dtype and actions.is_contiguous()
         assert actions.device == self.device
         if self._act_buf is not None and actions.data_ptr() != self._act_buf.data_ptr():

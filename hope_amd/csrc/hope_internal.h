@@ -20,9 +20,13 @@ constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generat
 //   [2..4] pose x, y, heading  [5..8] map box xmin, xmax, ymin, ymax   [9] unused
 //   [10..15] 48 bytes: push index of the k-th word heapdict pops (k < words to test)
 //   [16 + 8 i ..] word with push index i (RsWord)
+//   [400 + 40 k ..] segment table of the k-th popped word (k < words to test), written by k_rs_segs: 5 segments x 8 doubles
+//       (origin x, y, heading, cos, sin of the heading, type, length, [seg 0 only] int2 (type code, segment count))
 constexpr int RS_REC_HDR = 16;
 constexpr int RS_REC_ORDER = 10;
-constexpr int RS_REC_DOUBLES = RS_REC_HDR + 8 * RS_WORDS_PER_SCENE;
+constexpr int RS_REC_SEGS = RS_REC_HDR + 8 * RS_WORDS_PER_SCENE;
+constexpr int RS_SEGW = 8, RS_SEG_TABLE = 5 * RS_SEGW;
+constexpr int RS_REC_DOUBLES = RS_REC_SEGS + RS_SEG_TABLE * RS_WORDS_PER_SCENE;
 
 struct RsParams {
     int n, max_obst;

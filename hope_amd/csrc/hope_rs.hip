@@ -544,13 +544,64 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 
 
 // ================================================================================================
+// Kernel A2: segment origins of the words the search will test -- ONE LANE PER WORD (eight searches per wave)
+// ================================================================================================
+// generate_local_course (:452-507) needs, per segment, its origin (ox, oy, oyaw) = the end point of the previous segment
+// (interpolate(ind, l, ...) :497-498; hm_cos(-x) = cos x and hm_sin(-x) = -sin x give :522-523).  This is scalar arithmetic
+// per word (two sincos and two divisions per segment); inside the validation kernel, one wave per search, it cost the
+// whole wave ~400 instructions per tested word -- a quarter of that kernel's cycles.
+__global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
+    const int lane = threadIdx.x, ls = lane >> 3, k0 = lane & 7;
+    const int count = *p.rs_count;
+    const int qi = blockIdx.x * 8 + ls;
+    if (qi >= count) return;
+    const int slot = p.slot_base + p.slot_dir * qi;
+    double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
+    const int n_test = __double2hiint(rec[1]);
+    const unsigned char* order = (const unsigned char*)(rec + RS_REC_ORDER);
+    for (int k = k0; k < n_test; k += 8) {
+        const double* W = rec + RS_REC_HDR + 8 * (int)order[k];
+        double len[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) len[i] = W[i];
+        const double w6 = W[6];
+        const int code = __double2loint(w6), nseg = __double2hiint(w6);
+        double* tb = rec + RS_REC_SEGS + RS_SEG_TABLE * k;
+        double ox = 0, oy = 0, hy = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            if (i < nseg) {
+                const int m = type_of(code, i);
+                const double l = len[i];
+                double s_oy, c_oy;
+                hm_sincos(hy, &s_oy, &c_oy);
+                double* sp_ = tb + RS_SEGW * i;
+                sp_[0] = ox; sp_[1] = oy; sp_[2] = hy; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = (double)m; sp_[6] = l;
+                if (i == 0) sp_[7] = w6;
+                if (m == TS) {                                   // interpolate(l) = next origin (:512-513)
+                    ox = ox + l / MAXC * c_oy;
+                    oy = oy + l / MAXC * s_oy;
+                } else {
+                    double sl, cl;
+                    hm_sincos(l, &sl, &cl);
+                    const double ldx = sl / MAXC;
+                    const double ldy = (m == TL) ? (1.0 - cl) / MAXC : (1.0 - cl) / (-MAXC);
+                    ox = ox + (c_oy * ldx + (-s_oy) * ldy);
+                    oy = oy + (s_oy * ldx + c_oy * ldy);
+                }
+                hy = (m == TL) ? hy + l : ((m == TR) ? hy - l : hy);
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // Kernel B: find_rs_path's main loop (:436-450) over the ordered words
 // ================================================================================================
-// LDS: tile 8*M doubles | obstacle boxes M float4 | scratch (doubles): segment params 5 x 10, sample queue pd[256], bad1[6+2],
-//      the head of the search record (header + 14 words) | ints: cand[M] | bytes: seg[256]
-constexpr int RSB_SEG = 0, RSB_SEGW = 10, RSB_QPD = 50, RSB_QCAP = 256, RSB_BAD = RSB_QPD + RSB_QCAP, RSB_REC = RSB_BAD + 8;
-constexpr int RSB_REC_WORDS = 14;                              // words of the record kept in LDS (two 512-byte loads)
-constexpr int RSB_WORDS = RSB_REC + RS_REC_HDR + 8 * RSB_REC_WORDS;
+// LDS: tile 8*M doubles | obstacle boxes M float4 | scratch (doubles): the current word's segment table 5 x 8, sample queue
+//      pd[256], bad1[6+2] | ints: cand[M] | bytes: seg[256]
+constexpr int RSB_SEG = 0, RSB_SEGW = RS_SEGW, RSB_QPD = RS_SEG_TABLE, RSB_QCAP = 256, RSB_BAD = RSB_QPD + RSB_QCAP;
+constexpr int RSB_WORDS = RSB_BAD + 8;
 
 template <int OCC, bool TIMING>
 __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64) {
@@ -570,19 +621,16 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     double* scr = lds + 10 * p.tile_cap;
     double* segp = scr + RSB_SEG;
     double* qpd = scr + RSB_QPD;
-    double* wl = scr + RSB_REC;                           // record head: header, pop order, first words
     int* cand = (int*)(scr + RSB_WORDS);
     unsigned char* qseg = (unsigned char*)(cand + ((p.tile_cap + 3) & ~3));
 
-    // ---- the search record: ONE coalesced 512-byte load brings the header, the pop order and the first 6 words ----
+    // ---- the search record: one coalesced load brings the header; the words come as segment tables (k_rs_segs) ----
     const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
-    const double r0 = rec[lane];
+    const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
     const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);      // words the stop rule lets the search test
     if (n_paths == 0) return;
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
     const int n_obst = __builtin_amdgcn_readlane(__double2hiint(r0), 0);
-    wl[lane] = r0;
-    if (__builtin_amdgcn_readlane(__double2loint(r0), 1) > 6) wl[WAVE + lane] = rec[WAVE + lane];   // kept > 6: words with push index 6..13
     {
         const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
         double2* dst = (double2*)tile;
@@ -609,78 +657,24 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     double* bad1 = scr + RSB_BAD;                         // LDS, wave-uniform
     if (lane < 6) bad1[lane] = INFINITY;
     wsync();
-    const unsigned char* order = (const unsigned char*)(wl + RS_REC_ORDER);
     RS_T(0);
+    const double* tables = rec + RS_REC_SEGS;
+    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;          // segment table of the first word
     for (int idx = 1; idx <= n_paths; idx++) {            // the stop rule (:443) is already applied: n_paths ends there
         if ((obs_f64 & 0x200) && idx > 1) break;          // profiling switch: first path only
-        const int pi = order[idx - 1];                    // push index of the idx-th popped word
-        double len[5];
-        int code, nseg;
-        if (pi < RSB_REC_WORDS) {                         // wave-uniform
-            const double* W = wl + RS_REC_HDR + 8 * pi;
-#pragma unroll
-            for (int i = 0; i < 5; i++) len[i] = W[i];
-            code = __double2loint(W[6]); nseg = __double2hiint(W[6]);
-        } else {
-            const double* W = rec + RS_REC_HDR + 8 * pi;
-#pragma unroll
-            for (int i = 0; i < 5; i++) len[i] = W[i];
-            code = __double2loint(W[6]); nseg = __double2hiint(W[6]);
-        }
-        const int cls1 = type_of(code, 0) * 2 + (len[0] > 0.0 ? 1 : 0);
-        if (!(obs_f64 & 0x800) && fabs(len[0]) >= bad1[cls1]) continue;    // contains a sample already known to collide
+        const double tcur = tb;
+        if (idx < n_paths && lane < RS_SEG_TABLE) tb = tables[RS_SEG_TABLE * idx + lane];      // prefetch the next word's
+        const double len0 = readlane_d(tcur, 6), w6 = readlane_d(tcur, 7);
+        const int code = __double2loint(w6), nseg = __double2hiint(w6);
+        const int cls1 = type_of(code, 0) * 2 + (len0 > 0.0 ? 1 : 0);
+        if (!(obs_f64 & 0x800) && fabs(len0) >= bad1[cls1]) continue;    // contains a sample already known to collide
 
         // generate_local_course (:452-507).  Samples are queued as (pd, segment) and collision-tested 64 at a
         // time, so short segments share a pass.  Sample 0 (the start pose, local (0,0,0)) = segment 0 at pd = 0.
-        //
-        // Segment origins first.  The origin headings are plain sums (oyaw_{i+1} = oyaw_i +- l_i), so every
-        // sine/cosine the path needs -- of the five origin headings and of the five segment lengths (for the
-        // segment end points, interpolate(ind, l, ...) :497-498) -- comes from ONE lane-parallel sincos
-        // (lanes 0-4: headings, lanes 5-9: lengths); hm_cos(-x) = cos x and hm_sin(-x) = -sin x give :522-523.
+        // The segment origins come ready-made from k_rs_segs.
         bool invalid = false;
-        {
-            double hy[5];
-            hy[0] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int m = type_of(code, i);
-                hy[i + 1] = (m == TL) ? hy[i] + len[i] : ((m == TR) ? hy[i] - len[i] : hy[i]);
-            }
-            double arg = 0;
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (lane == i) arg = hy[i];
-                if (lane == 5 + i) arg = len[i];
-            }
-            double sv, cv;
-            hm_sincos(arg, &sv, &cv);
-            double ox = 0, oy = 0;
-            wsync();
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (i < nseg) {
-                    const int m = type_of(code, i);
-                    const double c_oy = readlane_d(cv, i), s_oy = readlane_d(sv, i);
-                    const double sl = readlane_d(sv, 5 + i), cl = readlane_d(cv, 5 + i);
-                    if (lane == 0) {
-                        double* sp_ = segp + RSB_SEGW * i;
-                        sp_[0] = ox; sp_[1] = oy; sp_[2] = hy[i]; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = c_oy; sp_[6] = -s_oy;
-                        sp_[7] = (double)m; sp_[8] = len[i];
-                    }
-                    const double l = len[i];
-                    if (m == TS) {                                   // interpolate(l) = next origin (:512-513)
-                        ox = ox + l / MAXC * c_oy;
-                        oy = oy + l / MAXC * s_oy;
-                    } else {
-                        const double ldx = sl / MAXC;
-                        const double ldy = (m == TL) ? (1.0 - cl) / MAXC : (1.0 - cl) / (-MAXC);
-                        ox = ox + (c_oy * ldx + (-s_oy) * ldy);
-                        oy = oy + (s_oy * ldx + c_oy * ldy);
-                    }
-                }
-            }
-            if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
-        }
+        if (lane < RS_SEG_TABLE) segp[lane] = tcur;
+        if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
         int nq = 1;
         wsync();
         if (TIMING) tsec[9] += 1;
@@ -703,7 +697,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
             while (!finished && nq + WAVE + 1 <= win) {
                 if (TIMING) tsec[10] += 1;
                 if (!seg_open) {
-                    l = segp[RSB_SEGW * i + 8];               // len[i]
+                    l = segp[RSB_SEGW * i + 6];               // len[i]
                     d = l > 0.0 ? step : -step;
                     if (i >= 1 && (lprev * l) > 0) pd = -d - ll; else pd = d - ll;
                     lprev = l;
@@ -765,8 +759,8 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
                 if (active) {
                     const double spd = qpd[idx];
                     const double* sp_ = segp + RSB_SEGW * (int)qseg[idx];
-                    const int m = (int)sp_[7];
-                    interpolate(spd, m, sp_[0], sp_[1], sp_[2], sp_[5], sp_[6], sp_[3], sp_[4], px, py, pyaw);
+                    const int m = (int)sp_[5];
+                    interpolate(spd, m, sp_[0], sp_[1], sp_[2], sp_[3], -sp_[4], sp_[3], sp_[4], px, py, pyaw);
                 }
                 const double wx = c_q * px + s_q * py + q0x;      // calc_all_paths :47-49
                 const double wy = -s_q * px + c_q * py + q0y;
@@ -807,10 +801,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     if (found < 0) return;
 
     // ---- output: PATH.ctypes / PATH.lengths (metres) of the first collision-free path ----------------
-    const int pf = order[found];
-    const double* W = (pf < RSB_REC_WORDS) ? (const double*)(wl + RS_REC_HDR + 8 * pf) : rec + RS_REC_HDR + 8 * pf;
-    const double wlen = lane < 5 ? W[lane] : 0.0;
-    const int code = __double2loint(W[6]), nseg = __double2hiint(W[6]);
+    // `found` is the last table copied to segp: lengths at [8 i + 6], type code and segment count at [7]
+    const double wlen = lane < 5 ? segp[RSB_SEGW * lane + 6] : 0.0;
+    const int code = __double2loint(segp[7]), nseg = __double2hiint(segp[7]);
     if (lane < 5) {
         double lm = lane < nseg ? wlen / MAXC : 0.0;              // path.lengths = [l / maxc ...] (:51)
         if (p.rs_lengths) {
@@ -857,6 +850,9 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
     if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
     hipLaunchKernelGGL(k_rs_words, dim3((p.max_queue + RSA_SCENES - 1) / RSA_SCENES), dim3(WAVE), 0, stream, p);
+    if (timer) timer->end(stream);
+    if (timer) timer->begin(HOPE_K_RS_SEGS, stream);
+    hipLaunchKernelGGL(k_rs_segs, dim3((p.max_queue + 7) / 8), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
     static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);

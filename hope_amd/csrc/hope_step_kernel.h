@@ -284,8 +284,14 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
     const double a0 = (double)act[2 * (size_t)sc_], a1 = (double)act[2 * (size_t)sc_ + 1];
     double steer = a0, speed = a1;
     if (!(stages & HOPE_ACTION_PHYSICAL)) {
-        steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
-        speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
+        if (sizeof(AT) == 4 && (stages & HOPE_ACTION_RESCALE_F32)) {          // float32 Box arithmetic, term by term
+            const float f0 = fminf(fmaxf((float)a0, -1.0f), 1.0f), f1 = fminf(fmaxf((float)a1, -1.0f), 1.0f);
+            steer = (double)(f0 * ((float)STEER_HI - (float)STEER_LO) / 2.0f + ((float)STEER_HI + (float)STEER_LO) / 2.0f);
+            speed = (double)(f1 * ((float)SPEED_HI - (float)SPEED_LO) / 2.0f + ((float)SPEED_HI + (float)SPEED_LO) / 2.0f);
+        } else {
+            steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
+            speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
+        }
     }
     speed = clipd(speed, SPEED_LO, SPEED_HI);
     steer = clipd(steer, STEER_LO, STEER_HI);

@@ -90,6 +90,11 @@ extern "C" {
  * (car_parking_base.py:235); without it they are the wrapper's [-1,1] actions and action_rescale
  * (env_wrapper.py:37-50) is applied first.  KSModel's own clip (vehicle.py:85-86) always applies. */
 #define HOPE_ACTION_PHYSICAL 0x10
+/* modifier bit: with a float32 action buffer, action_rescale is evaluated in float32 -- what the reference's
+ * action_rescale (env_wrapper.py:37-50) does when the agent hands it a float32 array: gym's Box bounds are float32, so
+ * clip, scale and shift all round to float32 before CarParking.step sees the action.  Everything after the rescale
+ * (KSModel.step) is float64 as without the bit.  No effect with a float64 buffer or with HOPE_ACTION_PHYSICAL. */
+#define HOPE_ACTION_RESCALE_F32 0x80
 /* modifier bit: fused episode turnover (gym VectorEnv "autoreset").  A scene whose step ends with status !=
  * CONTINUE is reset in the same kernel exactly as CarParking.reset (:127-138) does on the same map: pose = start,
  * accum_arrive_reward = 0, t = 0 and the action-less step (t = 1, incl. its _get_reward bookkeeping).  reward /
@@ -183,7 +188,8 @@ int hope_env_download_pool_index(hope_env_t *h, int32_t *out /*[N]*/);
 #define HOPE_K_IMAGE_PREP 5    /* k_bev_prep     (wave per scene: map + new boxes' spans)    */
 #define HOPE_K_RS_COMPACT 6    /* k_rs_compact   (Reeds-Shepp work queues from per-scene flags) */
 #define HOPE_K_POST 7           /* k_post         (reward + target arithmetic, one lane per scene; per tile class) */
-#define HOPE_N_KERNELS 8
+#define HOPE_K_RS_SEGS 8       /* k_rs_segs      (segment origins of the words to test, one lane per word; per tile class) */
+#define HOPE_N_KERNELS 9
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
 /* Same bookkeeping, per CALL instead of per launch: for every hope_env_step / hope_env_reset_obs call and kernel, the time
