@@ -57,7 +57,7 @@ constexpr int LDS_TX = 0, LDS_SH = 0, LDS_X = 0, LDS_HB = 320, LDS_CB = 330, LDS
 constexpr int KIN_WORDS = 50;
 // k_env_step -> k_post record: previous pose, final pose of the finished step, overlap area, (status | t << 8 | flags << 24)
 constexpr int POST_WORDS = 8;
-constexpr int POST_F_REWARD = 1, POST_F_TURNOVER = 2;
+constexpr int POST_F_REWARD = 1, POST_F_TURNOVER = 2, POST_F_NEED_UA = 4;   // NEED_UA: k_post computes the overlap area of the final pose
 __host__ __device__ inline size_t step_lds_bytes(int tile_cap) {
     return (size_t)(8 * tile_cap + LDS_SCRATCH_WORDS) * 8 + (size_t)((tile_cap + 3) & ~3) * 4;
 }
@@ -109,6 +109,48 @@ __device__ __noinline__ double quad_intersection_area_lane0(const double* B /*8 
     }
     if (n < 3) return 0.0;
     return fabs(ring_area_signed_lds(ax, ay, n));
+}
+
+// The same clip with one LANE per polygon pair (k_post): the ping-pong buffers are lane-private LDS columns, word i of
+// buffer b of lane l at sh[(8 b + i) * WAVE + l] (b = 0..3: ax, ay, bx, by; a convex quad clipped by a convex quad has
+// at most 8 vertices).  Same expressions in the same order as quad_intersection_area_lane0.
+__device__ __noinline__ double quad_intersection_area_private(const double* B /*8 words x,y, global*/, double* sh /* + lane */) {
+    double* ax = sh;               double* ay = sh + 8 * WAVE;
+    double* bx = sh + 16 * WAVE;   double* by = sh + 24 * WAVE;
+    int n = 4;
+    for (int e = 0; e < 4 && n > 0; e++) {
+        const double c1x = B[2 * e], c1y = B[2 * e + 1];
+        const double c2x = B[2 * ((e + 1) & 3)], c2y = B[2 * ((e + 1) & 3) + 1];
+        const double ex = c2x - c1x, ey = c2y - c1y;
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const int i2 = (i + 1 == n) ? 0 : i + 1;
+            const double sx = ax[i * WAVE], sy = ay[i * WAVE], tx = ax[i2 * WAVE], ty = ay[i2 * WAVE];
+            const double ds = ex * (sy - c1y) - ey * (sx - c1x);
+            const double dt = ex * (ty - c1y) - ey * (tx - c1x);
+            const bool sin_ = ds >= 0, tin = dt >= 0;
+            if (sin_) { bx[m * WAVE] = sx; by[m * WAVE] = sy; m++; }
+            if (sin_ != tin) {
+                const double r = ds / (ds - dt);
+                bx[m * WAVE] = sx + r * (tx - sx);
+                by[m * WAVE] = sy + r * (ty - sy);
+                m++;
+            }
+        }
+        n = m;
+        double* t;
+        t = ax; ax = bx; bx = t;
+        t = ay; ay = by; by = t;
+    }
+    if (n < 3) return 0.0;
+    double sum = 0.0;                                  // GEOS Area::ofRingSigned (ring_area_signed_lds)
+    const double x0 = ax[0];
+    for (int i = 1; i < n; i++) {
+        const double x = ax[i * WAVE] - x0;
+        const int ip = (i + 1 == n) ? 0 : i + 1;
+        sum += x * (ay[(i - 1) * WAVE] - ay[ip * WAVE]);
+    }
+    return fabs(sum / 2.0);
 }
 
 // |hull ∩ dest| with an exact quick reject: both boxes lie inside discs of radius rho about their
@@ -502,10 +544,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     }
 
     // ---- reward (_get_reward :186-227, reward_shaping env_wrapper.py:10-35) ------------------------
-    // Only the geometry stays here: the overlap area of the final pose with the dest box.  The arithmetic of the reward
-    // and of the target representation (tanh, acos(cos .), atan2, sincos, square roots, divisions: ~500 wave instructions
-    // that are the same on every lane) runs in k_post with one LANE per scene (measured: -12 % of this kernel).
-    if ((p.stages & HOPE_STAGE_REWARD) && status == HOPE_STATUS_CONTINUE && !have_ua) { ua = overlap_area(box, dbox, scr + LDS_SH, lane); have_ua = true; }
+    // Nothing of it stays here unless the arrival test already needed the overlap area: the polygon clip of the final
+    // pose against the dest box and the arithmetic of the reward and of the target representation (tanh, acos(cos .),
+    // atan2, sincos, square roots, divisions: hundreds of wave instructions that are the same on every lane) run in
+    // k_post with one LANE per scene.
+    const bool need_ua = (p.stages & HOPE_STAGE_REWARD) && status == HOPE_STATUS_CONTINUE && !have_ua;   // k_post clips (lane per scene)
     const double fin_x = x, fin_y = y, fin_h = h, fin_ua = ua;
     const int fin_t = t;
 
@@ -557,7 +600,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         {   // hand-over to k_post
             double* pr = p.post + (size_t)scene * POST_WORDS;
             pr[0] = prev_x; pr[1] = prev_y; pr[2] = prev_h; pr[3] = fin_x; pr[4] = fin_y; pr[5] = fin_h; pr[6] = fin_ua;
-            const int fl = ((p.stages & HOPE_STAGE_REWARD) ? POST_F_REWARD : 0) | (turnover ? POST_F_TURNOVER : 0);
+            const int fl = ((p.stages & HOPE_STAGE_REWARD) ? POST_F_REWARD : 0) | (turnover ? POST_F_TURNOVER : 0) | (need_ua ? POST_F_NEED_UA : 0);
             pr[7] = __hiloint2double(fl, status | (fin_t << 8));
         }
         if (p.out.rs_word) {   // cleared here; the Reeds-Shepp kernel fills it for eligible scenes
@@ -844,6 +887,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
 template <typename OT>
 __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_list, const uint8_t* active, uint32_t stages,
                                             const double* scene_c, double* state, const double* post, hope_step_out out) {
+    __shared__ double clip_lds[32 * WAVE];                    // lane-private polygon buffers of the clip
     const int idx = blockIdx.x * WAVE + threadIdx.x;
     if (idx >= n_list) return;
     const int scene = scene_list[idx];
@@ -857,7 +901,24 @@ __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_li
     if ((fl & POST_F_REWARD) && (stages & HOPE_STAGE_REWARD)) {
         double ri0 = 0, ri2 = 0, ri3 = 0, ri4 = 0, reward = 0;
         if (status == HOPE_STATUS_CONTINUE) {
-            const double dest_area = sc[SC_DAREA], dnorm = sc[SC_DNORM], ua = pr[6];
+            const double dest_area = sc[SC_DAREA], dnorm = sc[SC_DNORM];
+            double ua = pr[6];
+            if (fl & POST_F_NEED_UA) {                         // overlap_area(box of the final pose, dest box)
+                double sn, ct;
+                hm_sincos(pr[5], &sn, &ct);
+                const Box box = make_box(pr[3], pr[4], ct, sn);
+                const double* dbox = sc + SC_DBOX;
+                const double cx = 0.5 * (box.x[0] + box.x[2]), cy = 0.5 * (box.y[0] + box.y[2]);
+                const double dx = 0.5 * (dbox[0] + dbox[4]) - cx, dy = 0.5 * (dbox[1] + dbox[5]) - cy;
+                const double reach = 5.2;                      // as overlap_area: disjoint discs -> empty intersection
+                ua = 0.0;
+                if (!(dx * dx + dy * dy > reach * reach)) {
+                    double* sh = clip_lds + threadIdx.x;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { sh[i * WAVE] = box.x[i]; sh[(8 + i) * WAVE] = box.y[i]; }
+                    ua = quad_intersection_area_private(dbox, sh);
+                }
+            }
             ri0 = -hm_tanh((double)t / (10 * TOLERANT_TIME));
             double dq[2], aq[2];
 #pragma unroll
