@@ -592,6 +592,10 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
                 hy = (m == TL) ? hy + l : ((m == TR) ? hy - l : hy);
             }
         }
+        if (k == 0) {                                    // calc_all_paths' rotation by -q0 yaw (:47-49), once per search:
+            tb[RS_SEGW + 7] = hm_cos(-rec[4]);           // spare words of table 0
+            tb[2 * RS_SEGW + 7] = hm_sin(-rec[4]);
+        }
     }
 }
 
@@ -627,6 +631,8 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     // ---- the search record: one coalesced load brings the header; the words come as segment tables (k_rs_segs) ----
     const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
     const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
+    const double* tables = rec + RS_REC_SEGS;
+    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;          // segment table of the first word: in flight during the staging
     const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);      // words the stop rule lets the search test
     if (n_paths == 0) return;
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
@@ -645,7 +651,6 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     }
     const double q0x = readlane_d(r0, 2), q0y = readlane_d(r0, 3), q0w = readlane_d(r0, 4);
     const double xmin = readlane_d(r0, 5), xmax = readlane_d(r0, 6), ymin = readlane_d(r0, 7), ymax = readlane_d(r0, 8);
-    const double c_q = hm_cos(-q0w), s_q = hm_sin(-q0w);
     const double step = RS_STEP * MAXC;                   // step_size * maxc (:44)
     wsync();
 
@@ -658,8 +663,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     if (lane < 6) bad1[lane] = INFINITY;
     wsync();
     RS_T(0);
-    const double* tables = rec + RS_REC_SEGS;
-    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;          // segment table of the first word
+    const double c_q = readlane_d(tb, RS_SEGW + 7), s_q = readlane_d(tb, 2 * RS_SEGW + 7);   // cos / sin(-q0 yaw) (k_rs_segs)
     for (int idx = 1; idx <= n_paths; idx++) {            // the stop rule (:443) is already applied: n_paths ends there
         if ((obs_f64 & 0x200) && idx > 1) break;          // profiling switch: first path only
         const double tcur = tb;
