@@ -647,8 +647,8 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if ((stages & HOPE_STAGE_MOTION) && has_action) {       // this class's sub-step poses head its chain
             dim3 kg((p.n_list + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
             if (tm) tm->begin(HOPE_K_KINEMATICS, sc);
-            if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->kin);
-            else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->kin);
+            if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
+            else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
             if (tm) tm->end(sc);
         }
         const dim3 grid(p.n_list);
@@ -661,11 +661,11 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
         if (tm) tm->end(sc);
         if (fork && (stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses
-        if (stages & (HOPE_STAGE_REWARD | HOPE_STAGE_OBS)) {    // reward / target arithmetic, one lane per scene
+        {                                                       // scalar outputs, reward / target arithmetic: one lane per scene
             dim3 pg((p.n_list + WAVE - 1) / WAVE);
             if (tm) tm->begin(HOPE_K_POST, sc);
-            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, p.out);
-            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, p.out);
+            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
+            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
             if (tm) tm->end(sc);
         }
         if (!want_rs) continue;

@@ -54,7 +54,8 @@ struct StepParams {
 //     mask      : x[121]
 constexpr int LDS_TX = 0, LDS_SH = 0, LDS_X = 0, LDS_HB = 320, LDS_CB = 330, LDS_SB = 340, LDS_PX = 350,
               LDS_PY = 360, LDS_DBOX = 370, LDS_W2 = 378, LDS_KEEP = 388, LDS_SCRATCH_WORDS = 388;
-constexpr int KIN_WORDS = 50;
+constexpr int KIN_WORDS = 56;   // h[10] cos[10] sin[10] x[10] y[10], [50] = int2(arrival-possible bits of the ten poses, 0), [51] pad,
+                                // [52..55] = box (xmin, xmax, ymin, ymax) around the hulls of the start pose and the ten poses
 // k_env_step -> k_post record: previous pose, final pose of the finished step, overlap area, (status | t << 8 | flags << 24)
 constexpr int POST_WORDS = 8;
 constexpr int POST_F_REWARD = 1, POST_F_TURNOVER = 2, POST_F_NEED_UA = 4;   // NEED_UA: k_post computes the overlap area of the final pose
@@ -207,6 +208,26 @@ __device__ __forceinline__ int build_near_list(const double* tile, int n_obst, d
     return cnt;
 }
 
+// the same with a box [bx0, bx1] x [by0, by1] instead of the disc's box
+__device__ __forceinline__ int build_near_list_box(const double* tile, int n_obst, double bx0, double bx1, double by0, double by1,
+                                                   int* list, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < n_obst; base += WAVE) {
+        int o = base + lane;
+        bool near = false;
+        if (o < n_obst) {
+            const double* v = tile + 8 * o;
+            double mnx = fmin(fmin(v[0], v[2]), fmin(v[4], v[6])), mxx = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+            double mny = fmin(fmin(v[1], v[3]), fmin(v[5], v[7])), mxy = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+            near = !(mnx > bx1 || mxx < bx0 || mny > by1 || mxy < by0);
+        }
+        unsigned long long m = __ballot(near);
+        if (near) list[cnt + __popcll(m & ((1ull << lane) - 1))] = o;
+        cnt += __popcll(m);
+    }
+    return cnt;
+}
+
 // _detect_collision (car_parking_base.py:153-158): any hull edge x any obstacle edge share a point.
 // Edges are taken from the obstacles in list[0..n_list).
 __device__ __forceinline__ bool detect_collision(const Box& b, const double* tile, const int* list, int n_list, int lane) {
@@ -291,6 +312,16 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 // ------------------------------------------------------------------------------------------------------------
 constexpr int KIN_SCENES_PER_BLOCK = WAVE / 4;
 
+// inclusive prefix sum over the wave: Hillis-Steele inside each row of 16 (DPP row_shr), row totals by readlane
+__device__ __forceinline__ int wave_incl_scan_i(int x, int lane) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+    return x + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+
 // DPP move of a double (two 32-bit moves), e.g. CTRL = quad_perm
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
@@ -309,7 +340,7 @@ __device__ __forceinline__ double quad_bcast(double v) {
 
 template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_list, const double* state, const void* actions,
-                                                  const uint8_t* active, uint32_t stages, double* kin) {
+                                                  const uint8_t* active, uint32_t stages, const double* scene_c, double* kin) {
     // n entries of scene_list (a tile class's dense list: the kinematics head each class's launch chain), or scenes 0..n-1
     __shared__ double buf[KIN_SCENES_PER_BLOCK * KIN_WORDS];
     __shared__ int sid[KIN_SCENES_PER_BLOCK];
@@ -360,6 +391,35 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
         double s_, c_;
         hm_sincos(h, &s_, &c_);
         out[9] = h; out[19] = c_; out[29] = s_; out[39] = x; out[49] = y;
+    }
+    __syncthreads();
+    {   // the slab bound of the arrival test (arrival_possible) for the ten poses: lane q takes poses q, q + 4, q + 8.  In
+        // k_env_step (one wave per scene) this scalar test cost the whole wave ~40 instructions per pass of its sub-step loop.
+        const double* sc = scene_c + (size_t)sc_ * SC_WORDS;
+        const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
+        int bits = 0;
+        for (int k = q; k < NUM_STEP; k += 4)
+            if (arrival_possible(out[30 + k], out[40 + k], out[10 + k], out[20 + k], dcx, dcy, dcd, dsd)) bits |= 1 << k;
+        bits |= __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+        bits |= __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+        if (q == 0) { out[50] = __hiloint2double(0, bits); out[51] = 0.0; }
+        // box around every hull of this step (start pose + ten poses): k_env_step's near list keeps the obstacles whose box
+        // meets it -- far fewer than a disc about the start pose, so more sub-steps fit in one pass of its collision loop
+        double s0, c0;
+        hm_sincos(st[2], &s0, &c0);
+        Box b = make_box(st[0], st[1], c0, s0);
+        double bx0 = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3])), bx1 = fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3]));
+        double by0 = fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3])), by1 = fmax(fmax(b.y[0], b.y[1]), fmax(b.y[2], b.y[3]));
+        for (int k = q; k < NUM_STEP; k += 4) {
+            b = make_box(out[30 + k], out[40 + k], out[10 + k], out[20 + k]);
+            bx0 = fmin(bx0, fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3]))); bx1 = fmax(bx1, fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3])));
+            by0 = fmin(by0, fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3]))); by1 = fmax(by1, fmax(fmax(b.y[0], b.y[1]), fmax(b.y[2], b.y[3])));
+        }
+        bx0 = fmin(bx0, dpp_d<0xB1>(bx0)); bx0 = fmin(bx0, dpp_d<0x4E>(bx0));
+        bx1 = fmax(bx1, dpp_d<0xB1>(bx1)); bx1 = fmax(bx1, dpp_d<0x4E>(bx1));
+        by0 = fmin(by0, dpp_d<0xB1>(by0)); by0 = fmin(by0, dpp_d<0x4E>(by0));
+        by1 = fmax(by1, dpp_d<0xB1>(by1)); by1 = fmax(by1, dpp_d<0x4E>(by1));
+        if (q == 0) { out[52] = bx0; out[53] = bx1; out[54] = by0; out[55] = by1; }
     }
     __syncthreads();
     for (int w = threadIdx.x; w < KIN_SCENES_PER_BLOCK * KIN_WORDS; w += WAVE) {     // one 400-byte row per scene
@@ -424,8 +484,13 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
     int* nlist = keep;           // near-obstacle list (motion/status); the lidar reuses the words as keep flags
     const bool moving = (p.stages & HOPE_STAGE_MOTION) && p.has_action;
-    // hull radius about the rear axle 3.883 m (+ 1.25 m of travel at |v| <= 2.5 m/s over 0.5 s) + slack
-    const int n_near = build_near_list(tile, n_obst, x, y, moving ? 5.2 : 3.9, nlist, lane);
+    int apmask = 0, kf_pose = -1;    // kf_pose: the final pose is sub-step pose kf_pose of this step (-1: the pose the step started from)
+    // moving: the box around every hull of this step (k_kinematics); else the hull's disc about the rear axle (3.883 m + slack)
+    int n_near;
+    if (moving) {
+        const double* kb = p.kin + (size_t)scene * KIN_WORDS + 52;
+        n_near = build_near_list_box(tile, n_obst, kb[0], kb[1], kb[2], kb[3], nlist, lane);
+    } else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
     if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
     wsync();
     ST_T(0);
@@ -433,7 +498,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (moving) {
         // the ten sub-step poses (x, y, heading, cos, sin) were produced by k_kinematics (one THREAD per scene):
         // they do not depend on the collision outcome, only where we stop does
-        if (lane < KIN_WORDS) scr[LDS_HB + lane] = p.kin[(size_t)scene * KIN_WORDS + lane];
+        if (lane < 50) scr[LDS_HB + lane] = p.kin[(size_t)scene * KIN_WORDS + lane];
+        apmask = __double2loint(p.kin[(size_t)scene * KIN_WORDS + 50]);      // arrival_possible of the ten poses (k_kinematics)
         wsync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------
@@ -460,7 +526,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 const bool kv = k < NUM_STEP;
                 const int kk = kv ? k : NUM_STEP - 1;
                 const double qx = scr[LDS_PX + kk], qy = scr[LDS_PY + kk], qc = scr[LDS_CB + kk], qs = scr[LDS_SB + kk];
-                const bool ap = kv && e == 0 && arrival_possible(qx, qy, qc, qs, dcx, dcy, dcd, dsd);
+                const bool ap = kv && e == 0 && ((apmask >> kk) & 1);
                 bool hit = false;
                 if (kv && has_edge) {
                     const Box b = make_box(qx, qy, qc, qs);
@@ -494,7 +560,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             for (int k = 0; k < NUM_STEP; k++) {
                 const double qx = scr[LDS_PX + k], qy = scr[LDS_PY + k], qc = scr[LDS_CB + k], qs = scr[LDS_SB + k];
                 const Box b = make_box(qx, qy, qc, qs);
-                if (arrival_possible(qx, qy, qc, qs, dcx, dcy, dcd, dsd)) {               // _check_arrived :164-170
+                if ((apmask >> k) & 1) {                                                  // _check_arrived :164-170
                     ua = overlap_area(b, dbox, scr + LDS_SH, lane);
                     if (ua / dest_area > 0.95) { ev_k = k; ev_arrive = true; break; }
                 }
@@ -506,6 +572,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         arrive = ev_arrive;
         const int kf = ev_arrive ? ev_k : (ev_k == NUM_STEP ? NUM_STEP - 1 : ev_k - 1);
         moved = kf >= 0;
+        kf_pose = kf;
         if (kf >= 0) {
             x = scr[LDS_PX + kf]; y = scr[LDS_PY + kf]; h = scr[LDS_HB + kf];
             ct = scr[LDS_CB + kf]; sn = scr[LDS_SB + kf];
@@ -532,7 +599,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             else {
                 bool arrived = false;
                 if (have_ua) arrived = ua / dest_area > 0.95;
-                else if (arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {
+                else if (kf_pose >= 0 ? ((apmask >> kf_pose) & 1) != 0 : arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {
                     ua = overlap_area(box, dbox, scr + LDS_SH, lane);
                     have_ua = true;
                     arrived = ua / dest_area > 0.95;
@@ -554,7 +621,6 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
 
     // ---- fused episode turnover (HOPE_AUTO_RESET): CarParking.reset on the same map + its action-less step -------
     const bool turnover = (p.stages & HOPE_AUTO_RESET) && (p.stages & HOPE_STAGE_REWARD) && status != HOPE_STATUS_CONTINUE;
-    int rs_status = status;          // the RS gate below belongs to the finished step
     if (turnover) {
         x = sc[SC_START]; y = sc[SC_START + 1]; h = sc[SC_START + 2];
         accum = 0.0;
@@ -592,29 +658,13 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 p.traj_len[scene] = tl + 1;
             }
         }
-        if (p.out.pose) { p.out.pose[3 * (size_t)scene] = x; p.out.pose[3 * (size_t)scene + 1] = y; p.out.pose[3 * (size_t)scene + 2] = h; }
-        if (p.stages & HOPE_STAGE_REWARD) {
-            if (p.out.status) p.out.status[scene] = status;
-            if (p.out.done) p.out.done[scene] = status != HOPE_STATUS_CONTINUE;
-        }
-        {   // hand-over to k_post
+        {   // hand-over to k_post, which also writes the per-scene scalar outputs (pose, status, done, RS gate flag)
             double* pr = p.post + (size_t)scene * POST_WORDS;
             pr[0] = prev_x; pr[1] = prev_y; pr[2] = prev_h; pr[3] = fin_x; pr[4] = fin_y; pr[5] = fin_h; pr[6] = fin_ua;
             const int fl = ((p.stages & HOPE_STAGE_REWARD) ? POST_F_REWARD : 0) | (turnover ? POST_F_TURNOVER : 0) | (need_ua ? POST_F_NEED_UA : 0);
             pr[7] = __hiloint2double(fl, status | (fin_t << 8));
         }
-        if (p.out.rs_word) {   // cleared here; the Reeds-Shepp kernel fills it for eligible scenes
-            int8_t* w = p.out.rs_word + 8 * (size_t)scene;
-            w[0] = w[1] = w[2] = w[3] = w[4] = HOPE_RS_NONE; w[5] = 0; w[6] = 0; w[7] = 0;
-        }
-        if (p.stages & HOPE_STAGE_RS) {                                                    // gate :293-294
-            // (one global atomicAdd per scene on a single queue counter cost ~45 us per 32 768 scenes: every XCD's
-            // atomics meet at the memory side; a flag and a compaction pass do not)
-            double ddx = x - destx, ddy = y - desty;
-            p.rs_flag[scene] = t > 1 && rs_status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
-        }
     }
-    if (p.out.rs_lengths && lane < 5) ((OT*)p.out.rs_lengths)[5 * (size_t)scene + lane] = (OT)0;
 
     if (!(p.stages & HOPE_STAGE_OBS)) { ST_T(2); ST_FLUSH(); return; }
 
@@ -718,8 +768,27 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             // [lo, lo + cnt) is written by the lanes 0 .. cnt-1 in one store -- no per-beam ballots / prefix counts at all
             // (a lane-per-edge loop over the beams cost ~14 VALU instructions per beam of the widest edge; a four-beams-per-
             // round variant with bit-plane prefix sums ~8).
+            // Edges that subtend at most NARROW beams are appended all at once, one lane per edge: queue offsets from a
+            // wave prefix sum, then NARROW predicated stores (6 x 64 = the queue's capacity).
             ST_T(4);
-            unsigned long long todo = __ballot(cnt > 0);
+            constexpr int NARROW = 6;
+            const int cs = (cnt > 0 && cnt <= NARROW) ? cnt : 0;
+            const int incl = wave_incl_scan_i(cs, lane);
+            const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+            if (total > 0) {
+                if (qn + total > LQ) drain();
+                const int off = qn + incl - cs, tag = e << 7;
+#pragma unroll
+                for (int k = 0; k < NARROW; k++) {
+                    if (k < cs) {
+                        int bi = lo + k;
+                        if (bi >= NBEAM) bi -= NBEAM;
+                        queue[off + k] = tag | bi;
+                    }
+                }
+                qn += total;
+            }
+            unsigned long long todo = __ballot(cnt > NARROW);
             while (todo) {
                 const int el = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -886,7 +955,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename OT>
 __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_list, const uint8_t* active, uint32_t stages,
-                                            const double* scene_c, double* state, const double* post, hope_step_out out) {
+                                            const double* scene_c, double* state, const double* post, uint8_t* rs_flag,
+                                            hope_step_out out) {
     __shared__ double clip_lds[32 * WAVE];                    // lane-private polygon buffers of the clip
     const int idx = blockIdx.x * WAVE + threadIdx.x;
     if (idx >= n_list) return;
@@ -898,6 +968,26 @@ __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_li
     const double destx = sc[SC_DEST], desty = sc[SC_DEST + 1], desth = sc[SC_DEST + 2];
     const int packed = __double2loint(pr[7]), fl = __double2hiint(pr[7]);
     const int status = packed & 0xff, t = packed >> 8;
+    // ---- per-scene scalar outputs ------------------------------------------------------------------------
+    if (out.pose) { out.pose[3 * (size_t)scene] = st[0]; out.pose[3 * (size_t)scene + 1] = st[1]; out.pose[3 * (size_t)scene + 2] = st[2]; }
+    if (stages & HOPE_STAGE_REWARD) {
+        if (out.status) out.status[scene] = status;
+        if (out.done) out.done[scene] = status != HOPE_STATUS_CONTINUE;
+    }
+    if (out.rs_word) {       // cleared here; the Reeds-Shepp kernel fills it for eligible scenes: {NONE x 5, 0, 0, 0}
+        const unsigned long long none = (unsigned char)HOPE_RS_NONE;
+        *(unsigned long long*)(out.rs_word + 8 * (size_t)scene) = none | none << 8 | none << 16 | none << 24 | none << 32;
+    }
+    if (out.rs_lengths) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) ((OT*)out.rs_lengths)[5 * (size_t)scene + i] = (OT)0;
+    }
+    if (stages & HOPE_STAGE_RS) {                                                    // gate :293-294 (the finished step's)
+        // (one global atomicAdd per scene on a single queue counter cost ~45 us per 32 768 scenes: every XCD's
+        // atomics meet at the memory side; a flag and a compaction pass do not)
+        const double ddx = pr[3] - destx, ddy = pr[4] - desty;
+        rs_flag[scene] = t > 1 && status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
+    }
     if ((fl & POST_F_REWARD) && (stages & HOPE_STAGE_REWARD)) {
         double ri0 = 0, ri2 = 0, ri3 = 0, ri4 = 0, reward = 0;
         if (status == HOPE_STATUS_CONTINUE) {
