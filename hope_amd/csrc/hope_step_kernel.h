@@ -753,13 +753,18 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 if (dth > 3.14159265f) dth -= 6.28318531f;
                 if (dth <= -3.14159265f) dth += 6.28318531f;
                 const float span = fabsf(dth);
-                if (span > 3.13f || !(span == span)) { lo = 0; cnt = NBEAM; }
+                // all beams: span ill-defined, or an end point so close to the sensor (< 0.1 m: far inside the hull) that the
+                // float32 rounding of its coordinates could move its direction by more than the margin
+                if (span > 3.13f || !(span == span) || fminf(x1 * x1 + y1 * y1, x2 * x2 + y2 * y2) < 0.01f) { lo = 0; cnt = NBEAM; }
                 else {
                     float ts = dth >= 0 ? t1 : t2;                  // start of the arc, counter-clockwise
                     if (ts < 0) ts += 6.28318531f;
-                    const int ilo = (int)floorf((ts - MARGIN) / PITCH);
-                    const int ihi = (int)ceilf((ts + span + MARGIN) / PITCH);
+                    // beams i with theta_i = i PITCH inside [ts - MARGIN, ts + span + MARGIN]; none when the edge is seen
+                    // between two beams (float32 rounding of the quotients: ~1e-5 of a pitch, far inside the margin)
+                    const int ilo = (int)ceilf((ts - MARGIN) / PITCH);
+                    const int ihi = (int)floorf((ts + span + MARGIN) / PITCH);
                     cnt = ihi - ilo + 1;
+                    if (cnt < 0) cnt = 0;
                     if (cnt > NBEAM) cnt = NBEAM;
                     lo = ((ilo % NBEAM) + NBEAM) % NBEAM;
                 }
@@ -810,6 +815,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             ST_T(5);
         }
     }
+    const double pm0 = p.pmax[UPS * i0], pm1 = has1 ? p.pmax[UPS * i1] : 0.0;   // for the mask stage: in flight during the drain
     if (qn > 0) drain();
     const double best0 = __longlong_as_double((long long)best[i0]);
     const double best1 = has1 ? __longlong_as_double((long long)best[i1]) : INFINITY;
@@ -853,44 +859,56 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     {
         // lane-parallel activity test (one lane per coarse beam), then only the active rows are visited,
         // four at a time so that their probes are in flight together
-        const bool c0 = xs[i0] - 1e-9 < p.pmax[UPS * i0];
-        const bool c1 = has1 && xs[i1] - 1e-9 < p.pmax[UPS * i1];
+        const bool c0 = xs[i0] - 1e-9 < pm0;
+        const bool c1 = has1 && xs[i1] - 1e-9 < pm1;
         unsigned long long am[2] = {__ballot(c0), __ballot(c1)};
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             unsigned long long m = am[half];
             while (m) {
-                int ib[4];
+                constexpr int MG = 4;                              // rows probed together: their loads are in flight at once
+                int ib[MG];
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
+                for (int g = 0; g < MG; g++) {
                     if (m) { ib[g] = 64 * half + __ffsll((long long)m) - 1; m &= m - 1; }
                     else ib[g] = ib[0];                           // duplicate: min() is idempotent
                 }
                 if (lane < NACT) {
-                    const double* row[4];
-                    double xv[4], v[4];
+                    double v[MG];
+                    const int mprobe = mstep;
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        xv[g] = xs[ib[g]];
-                        row[g] = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + lane;
-                        v[g] = mstep > 0 ? row[g][(mstep - 1) * NACT] : 0.0;
-                    }
+                    for (int g = 0; g < MG; g++)
+                        v[g] = mstep > 0 ? p.tab[(size_t)(UPS * ib[g]) * NITER * NACT + lane + (mstep - 1) * NACT] : 0.0;
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
+                    for (int g = 0; g < MG; g++) {
                         if (mstep > 0) {
+                            const double xv = xs[ib[g]];
                             double bv = v[g];                     // boundary value: largest examined entry <= x
-                            if (bv > xv[g]) {
-                                int c = mstep;
+                            if (bv > xv) {
+                                const double* row = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + lane;
+                                // walk down to the first entry <= x: four rows per trip, loaded together (a dependent
+                                // load per row made this stage a chain of L2 latencies); row mstep - 1 is already known
+                                // to exceed when nothing lowered mstep since the probe
+                                int c = mstep == mprobe ? mstep - 1 : mstep;
                                 bv = -INFINITY;
                                 while (c > 0) {
-                                    bv = row[g][(c - 1) * NACT];
-                                    if (!(bv > xv[g])) break;
-                                    c--;
+                                    const double b0 = row[(c - 1) * NACT];
+                                    const double b1 = c > 1 ? row[(c - 2) * NACT] : -INFINITY;
+                                    const double b2 = c > 2 ? row[(c - 3) * NACT] : -INFINITY;
+                                    const double b3 = c > 3 ? row[(c - 4) * NACT] : -INFINITY;
+                                    bv = b0; if (!(bv > xv)) break;
+                                    if (--c == 0) break;
+                                    bv = b1; if (!(bv > xv)) break;
+                                    if (--c == 0) break;
+                                    bv = b2; if (!(bv > xv)) break;
+                                    if (--c == 0) break;
+                                    bv = b3; if (!(bv > xv)) break;
+                                    --c;
                                 }
                                 if (c == 0) bv = -INFINITY;
                                 mstep = c;
                             }
-                            if (bv > xv[g] - 1e-9) tie = true;
+                            if (bv > xv - 1e-9) tie = true;
                         }
                     }
                 }
