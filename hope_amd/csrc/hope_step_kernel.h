@@ -452,6 +452,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (p.active && !p.active[scene]) return;
 
     const int n_obst = p.n_obst[scene];
+    // the sub-step poses of this step (k_kinematics), requested together with everything else the scene needs
+    const bool moving = (p.stages & HOPE_STAGE_MOTION) && p.has_action;
+    const double kinv = (moving && lane < KIN_WORDS) ? p.kin[(size_t)scene * KIN_WORDS + lane] : 0.0;
 
     double* tile = lds;
     double* scr = lds + 8 * p.tile_cap;
@@ -483,14 +486,12 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     bool have_cs = false;
     const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
     int* nlist = keep;           // near-obstacle list (motion/status); the lidar reuses the words as keep flags
-    const bool moving = (p.stages & HOPE_STAGE_MOTION) && p.has_action;
     int apmask = 0, kf_pose = -1;    // kf_pose: the final pose is sub-step pose kf_pose of this step (-1: the pose the step started from)
     // moving: the box around every hull of this step (k_kinematics); else the hull's disc about the rear axle (3.883 m + slack)
     int n_near;
-    if (moving) {
-        const double* kb = p.kin + (size_t)scene * KIN_WORDS + 52;
-        n_near = build_near_list_box(tile, n_obst, kb[0], kb[1], kb[2], kb[3], nlist, lane);
-    } else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
+    if (moving)
+        n_near = build_near_list_box(tile, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), nlist, lane);
+    else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
     if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
     wsync();
     ST_T(0);
@@ -498,8 +499,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (moving) {
         // the ten sub-step poses (x, y, heading, cos, sin) were produced by k_kinematics (one THREAD per scene):
         // they do not depend on the collision outcome, only where we stop does
-        if (lane < 50) scr[LDS_HB + lane] = p.kin[(size_t)scene * KIN_WORDS + lane];
-        apmask = __double2loint(p.kin[(size_t)scene * KIN_WORDS + 50]);      // arrival_possible of the ten poses (k_kinematics)
+        if (lane < 50) scr[LDS_HB + lane] = kinv;
+        apmask = __builtin_amdgcn_readlane(__double2loint(kinv), 50);        // arrival_possible of the ten poses (k_kinematics)
         wsync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------
@@ -671,11 +672,19 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     ST_T(2);
     // ---- lidar (lidar_simulator.py:31-135) -----------------------------------------------------------
     // world -> ego in place: affine [a, b, -b, a, x_off, y_off] (:58-64)
+    // Only obstacles whose box comes within lidar_range of the sensor can pass the ring test of :69 (the ring lies inside
+    // its box; 1e-6 m of slack against the rounding of the ego transform), so only those are transformed and measured:
+    // a lot of 100 obstacles has a dozen within 10 m.  llist: their indices, then (compacted in place) the kept rings'.
+    int* llist = keep;
+    wsync();                                                  // the near list (same words) is dead
+    const int n_l = build_near_list(tile, n_obst, x, y, LIDAR_RANGE + 1e-6, llist, lane);
+    wsync();
     {
         const double a = ct, b = sn;
         const double x_off = -x * a - y * b;
         const double y_off = x * b - y * a;
-        for (int v = lane; v < n_slots; v += WAVE) {
+        for (int i = lane; i < 4 * n_l; i += WAVE) {
+            const int v = 4 * llist[i >> 2] + (i & 3);
             double px = tile[2 * v], py = tile[2 * v + 1];
             tile[2 * v] = a * px + b * py + x_off;
             tile[2 * v + 1] = (-b) * px + a * py + y_off;
@@ -683,18 +692,25 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     }
     wsync();
     // ring kept iff distance(ring, origin) < lidar_range (:69); 4 consecutive lanes = one ring
-    for (int base = 0; base < n_slots; base += WAVE) {
-        int e = base + lane;
+    int n_k = 0;
+    for (int base = 0; base < 4 * n_l; base += WAVE) {
+        const int i = base + lane;
+        const bool in = i < 4 * n_l;
+        const int o = in ? llist[i >> 2] : 0;
         double dd = INFINITY;
-        if (e < n_slots) {
-            int e2 = (e & ~3) | ((e + 1) & 3);
+        if (in) {
+            const int e = 4 * o + (i & 3), e2 = 4 * o + ((i + 1) & 3);
             dd = origin_seg_dist(tile[2 * e], tile[2 * e + 1], tile[2 * e2], tile[2 * e2 + 1]);
         }
         dd = fmin(dd, dpp_d<0xB1>(dd));                      // quad_perm [1,0,3,2]
         dd = fmin(dd, dpp_d<0x4E>(dd));                      // quad_perm [2,3,0,1]
-        if (e < n_slots && (e & 3) == 0) keep[e >> 2] = dd < LIDAR_RANGE;
+        const bool kq = in && (i & 3) == 0 && dd < LIDAR_RANGE;
+        const unsigned long long km = __ballot(kq);
+        if (kq) llist[n_k + __popcll(km & ((1ull << lane) - 1))] = o;   // in place: writes stay below the next chunk's reads
+        n_k += __popcll(km);
     }
     wsync();
+    const int n_kslots = 4 * n_k;
     ST_T(3);
     // beams: lane l owns beams l and l+64.  Two passes (SIMT pays for the union of lanes, and every edge is
     // crossed by SOME beam, so the two float64 divisions of a pair must not sit in the lane-per-beam loop):
@@ -741,10 +757,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     // direction flip) is paired with all 120 beams.
     {
         const float PITCH = 6.283185307179586f / NBEAM, MARGIN = 2e-3f;
-        for (int base = 0; base < n_slots && !(p.stages & 0x1000); base += WAVE) {   // 0x1000: profiling switch
-            const int e = base + lane;
+        for (int base = 0; base < n_kslots && !(p.stages & 0x1000); base += WAVE) {   // 0x1000: profiling switch
+            const int i = base + lane;
+            const int e = i < n_kslots ? 4 * llist[i >> 2] + (i & 3) : 0;
             int lo = 0, cnt = 0;
-            if (e < n_slots && keep[e >> 2]) {
+            if (i < n_kslots) {
                 const int e2 = (e & ~3) | ((e + 1) & 3);
                 const float x1 = (float)tile[2 * e], y1 = (float)tile[2 * e + 1];
                 const float x2 = (float)tile[2 * e2], y2 = (float)tile[2 * e2 + 1];
@@ -799,7 +816,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 todo &= todo - 1;
                 const int lo_e = __builtin_amdgcn_readlane(lo, el), cnt_e = __builtin_amdgcn_readlane(cnt, el);
                 if (qn + cnt_e > LQ) drain();
-                const int tag = (base + el) << 7;
+                const int tag = __builtin_amdgcn_readlane(e, el) << 7;
                 if (lane < cnt_e) {
                     int bi = lo_e + lane;
                     if (bi >= NBEAM) bi -= NBEAM;
