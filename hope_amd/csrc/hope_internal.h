@@ -15,16 +15,20 @@ struct RsWord {
     double pad;
 };
 constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generate_path
-// Per-search record, written by k_rs_words and read by k_rs_validate in ONE coalesced load (float64 words):
+// Per-search record (float64 words):
 //   [0] int2 (scene, n_obst)   [1] int2 (kept words, words the stop rule :443 lets find_rs_path test)
 //   [2..4] pose x, y, heading  [5..8] map box xmin, xmax, ymin, ymax   [9] unused
-//   [10..15] 48 bytes: push index of the k-th word heapdict pops (k < words to test)
-//   [16 + 8 i ..] word with push index i (RsWord)
-//   [400 + 40 k ..] segment table of the k-th popped word (k < words to test), written by k_rs_segs: 5 segments x 8 doubles
-//       (origin x, y, heading, cos, sin of the heading, type, length, [seg 0 only] int2 (type code, segment count))
+//   [10..15] the pop order: candidate slot (4 * family + reflection) of the k-th popped word, one byte each  -- k_rs_segs
+//   [16 + c]  key of candidate slot c: path.L / maxc when set_path kept the word, -1 otherwise               -- k_rs_words
+//   [64 + 8 c ..] the word of candidate slot c (RsWord)                                                       -- k_rs_words
+//   [448 + 40 k ..] segment table of the k-th popped word (k < words to test), written by k_rs_segs: 5 segments x 8 doubles
+//       (origin x, y, heading, cos, sin of the heading, type, length, [seg 0 only] int2 (type code, segment count));
+//       table 0 also carries cos / sin(-pose heading) in the spare words [15], [23]
 constexpr int RS_REC_HDR = 16;
 constexpr int RS_REC_ORDER = 10;
-constexpr int RS_REC_SEGS = RS_REC_HDR + 8 * RS_WORDS_PER_SCENE;
+constexpr int RS_REC_KEYS = RS_REC_HDR;
+constexpr int RS_REC_WORDS = RS_REC_KEYS + RS_WORDS_PER_SCENE;
+constexpr int RS_REC_SEGS = RS_REC_WORDS + 8 * RS_WORDS_PER_SCENE;
 constexpr int RS_SEGW = 8, RS_SEG_TABLE = 5 * RS_SEGW;
 constexpr int RS_REC_DOUBLES = RS_REC_SEGS + RS_SEG_TABLE * RS_WORDS_PER_SCENE;
 

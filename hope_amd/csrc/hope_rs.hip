@@ -372,9 +372,14 @@ __device__ __forceinline__ bool rs_dup(int n, double o0, double o1, double o2, d
     return s <= 0.01;
 }
 
+// blockIdx.y = family group: the twelve families are independent except for set_path's two cross-family de-dups
+// (g = 4 against 3, g = 6 against 5), so four waves share a group of 16 searches -- a third of the serial length each and
+// four times the waves (one wave per 16 searches left the GPU with 2.5 long waves per SIMD: 66 us per launch, hardly
+// overlapped with anything).  The heap replay (push order = slot order) runs afterwards in k_rs_segs.
+constexpr int RSA_GROUPS = 4;
+__device__ __constant__ const int rsa_group_begin[RSA_GROUPS + 1] = {0, 3, 7, 9, 12};
+
 __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
-    __shared__ double pr[RSA_SCENES][NCAND];                  // heap priorities per scene
-    __shared__ unsigned char hid[RSA_SCENES][NCAND + 2];      // heap ids (candidate call index)
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
     const int qi = blockIdx.x * RSA_SCENES + ls;
     const int count = *p.rs_count;
@@ -402,13 +407,13 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     const double YB = X * sPHI - Y * cPHI;
 
     double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
-    RsWord* words = (RsWord*)(rec + RS_REC_HDR);              // stored by PUSH index (= order of being kept)
-    int hn = 0;                                               // words kept so far = heap size while pushing (all 4 lanes)
+    RsWord* words = (RsWord*)(rec + RS_REC_WORDS);            // stored by candidate slot 4 g + q (= path order)
     double p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // previous family: my reflection's lengths, kept flag
     bool pk = false;
     const double hp = 0.5 * PI;
+    const int g_begin = rsa_group_begin[blockIdx.y], g_end = rsa_group_begin[blockIdx.y + 1];
 
-    for (int g = 0; g < 12; g++) {
+    for (int g = g_begin; g < g_end; g++) {
         const bool back = (g == 4 || g == 9 || g == 10);
         const double bx = back ? XB : X, by = back ? YB : Y;
         const double sx = (q & 1) ? -bx : bx;
@@ -477,71 +482,16 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
             if (q & 1) kept = ok && !dup && !(ek && rs_dup(n, e0, e1, e2, e3, e4, l0, l1, l2, l3, l4)) && !(L >= MAX_LENGTH);
         }
         const double Lm = L / MAXC;                            // path.L / maxc (calc_all_paths :52)
-        // ---- costQueue[path] = path.L in path order (:432-433): lane 0 of the quad pushes the kept ones -----------
-        {
-            const int k0 = quad_get<0>((int)kept), k1 = quad_get<1>((int)kept), k2 = quad_get<2>((int)kept), k3 = quad_get<3>((int)kept);
-            const double m0 = quad_get<0>(Lm), m1 = quad_get<1>(Lm), m2 = quad_get<2>(Lm), m3 = quad_get<3>(Lm);
-            if (kept) {                                       // my push index: kept words before me in call order
-                RsWord* w = words + hn + (q > 0 ? k0 : 0) + (q > 1 ? k1 : 0) + (q > 2 ? k2 : 0);
-                w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
-                w->Lm = Lm; w->code = code; w->n = n;
-            }
-            if (q == 0) {
-                int hq = hn;
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const int kk = qq == 0 ? k0 : (qq == 1 ? k1 : (qq == 2 ? k2 : k3));
-                    if (!kk) continue;
-                    const double pv = qq == 0 ? m0 : (qq == 1 ? m1 : (qq == 2 ? m2 : m3));
-                    int i = hq++;
-                    pr[ls][i] = pv; hid[ls][i] = (unsigned char)i;     // heap entries carry the push index
-                    while (i) {                               // _decrease_key: swap unless parent < child
-                        const int parent = (i - 1) >> 1;
-                        if (pr[ls][parent] < pr[ls][i]) break;
-                        const double tp = pr[ls][i]; pr[ls][i] = pr[ls][parent]; pr[ls][parent] = tp;
-                        const unsigned char ti = hid[ls][i]; hid[ls][i] = hid[ls][parent]; hid[ls][parent] = ti;
-                        i = parent;
-                    }
-                }
-            }
-            hn += k0 + k1 + k2 + k3;
+        // ---- costQueue[path] = path.L in path order (:432-433): the key of my candidate slot; k_rs_segs replays the heap ----
+        if (live) rec[RS_REC_KEYS + 4 * g + q] = kept ? Lm : -1.0;
+        if (kept) {
+            RsWord* w = words + 4 * g + q;
+            w->len[0] = l0; w->len[1] = l1; w->len[2] = l2; w->len[3] = l3; w->len[4] = l4;
+            w->Lm = Lm; w->code = code; w->n = n;
         }
         p0 = l0; p1 = l1; p2 = l2; p3 = l3; pk = kept;
     }
-
-    // ---- heapdict pop order, cut where find_rs_path's stop rule (:443) ends the search ------------------------------
-    if (q == 0 && live) {
-        const int n_kept = hn;
-        unsigned char* ord = (unsigned char*)(rec + RS_REC_ORDER);
-        int no = 0;
-        double lmin = 0;
-        while (hn > 0) {                                      // popitem
-            const double lm = pr[ls][0];
-            if (no == 0) lmin = lm;
-            if (lm > 1.6 * lmin && no + 1 > 2) break;         // this word and every later one are never tested
-            ord[no++] = hid[ls][0];
-            if (hn == 1) { hn = 0; break; }
-            hn--;
-            pr[ls][0] = pr[ls][hn]; hid[ls][0] = hid[ls][hn];
-            int i = 0;
-            for (;;) {                                        // _min_heapify
-                const int l = (i << 1) + 1, r = (i + 1) << 1;
-                int low = (l < hn && pr[ls][l] < pr[ls][i]) ? l : i;
-                if (r < hn && pr[ls][r] < pr[ls][low]) low = r;
-                if (low == i) break;
-                const double tp = pr[ls][i]; pr[ls][i] = pr[ls][low]; pr[ls][low] = tp;
-                const unsigned char ti = hid[ls][i]; hid[ls][i] = hid[ls][low]; hid[ls][low] = ti;
-                i = low;
-            }
-        }
-        // header: everything k_rs_validate needs before it can stage the obstacle tile
-        ((int2*)rec)[0] = make_int2(scene, p.n_obst[scene]);
-        ((int2*)rec)[1] = make_int2(n_kept, no);
-        rec[2] = q0x; rec[3] = q0y; rec[4] = q0w;
-        rec[5] = sc[SC_BBOX]; rec[6] = sc[SC_BBOX + 1]; rec[7] = sc[SC_BBOX + 2]; rec[8] = sc[SC_BBOX + 3];
-    }
 }
-
 
 // ================================================================================================
 // Kernel A2: segment origins of the words the search will test -- ONE LANE PER WORD (eight searches per wave)
@@ -551,16 +501,86 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 // per word (two sincos and two divisions per segment); inside the validation kernel, one wave per search, it cost the
 // whole wave ~400 instructions per tested word -- a quarter of that kernel's cycles.
 __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
+    __shared__ double keyl[8][RS_WORDS_PER_SCENE];            // candidate keys in path order
+    __shared__ double prl[8][RS_WORDS_PER_SCENE];             // heap priorities per search
+    __shared__ unsigned char hidl[8][RS_WORDS_PER_SCENE];     // heap ids (candidate slot)
+    __shared__ unsigned char ordl[8][RS_WORDS_PER_SCENE];     // pop order
+    __shared__ int ntl[8];
     const int lane = threadIdx.x, ls = lane >> 3, k0 = lane & 7;
     const int count = *p.rs_count;
+    if ((int)blockIdx.x * 8 >= count) return;
     const int qi = blockIdx.x * 8 + ls;
-    if (qi >= count) return;
-    const int slot = p.slot_base + p.slot_dir * qi;
+    const bool live = qi < count;
+    const int slot = p.slot_base + p.slot_dir * (live ? qi : 0);
     double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
-    const int n_test = __double2hiint(rec[1]);
-    const unsigned char* order = (const unsigned char*)(rec + RS_REC_ORDER);
+    const int scene = p.rs_list[live ? qi : 0];
+    const double* st = p.state + (size_t)scene * ST_WORDS;
+    // the kept candidates of the search as a bit mask (bit c = candidate slot c): eight lanes x six keys, one ballot per stride
+    unsigned long long keptm = 0;
+#pragma unroll
+    for (int j = 0; j < RS_WORDS_PER_SCENE / 8; j++) {
+        const double key = live ? rec[RS_REC_KEYS + 8 * j + k0] : -1.0;
+        keyl[ls][8 * j + k0] = key;
+        keptm |= ((__ballot(key >= 0.0) >> (8 * ls)) & 0xffull) << (8 * j);
+    }
+    __syncthreads();
+    // ---- costQueue = heapdict(); costQueue[path] = path.L in path order (:432-433), then popitem until the stop rule ----
+    // heapdict 1.0.1's array heap: push = append + sift-up that swaps unless parent < child; popitem = move the last entry
+    // to the root + strict sift-down.  Replayed by the first of the search's eight lanes.
+    if (live && k0 == 0) {
+        double* pr = prl[ls];
+        unsigned char* hid = hidl[ls];
+        int hn = 0;
+        for (unsigned long long m = keptm; m; m &= m - 1) {    // the candidates set_path kept, in path order
+            const int c = __ffsll((long long)m) - 1;
+            const double pv = keyl[ls][c];
+            int i = hn++;
+            pr[i] = pv; hid[i] = (unsigned char)c;
+            while (i) {                                       // _decrease_key: swap unless parent < child
+                const int parent = (i - 1) >> 1;
+                if (pr[parent] < pr[i]) break;
+                const double tp = pr[i]; pr[i] = pr[parent]; pr[parent] = tp;
+                const unsigned char ti = hid[i]; hid[i] = hid[parent]; hid[parent] = ti;
+                i = parent;
+            }
+        }
+        const int n_kept = hn;
+        int no = 0;
+        double lmin = 0;
+        while (hn > 0) {                                      // popitem
+            const double lm = pr[0];
+            if (no == 0) lmin = lm;
+            if (lm > 1.6 * lmin && no + 1 > 2) break;         // stop rule (:443): this word and every later one are never tested
+            ordl[ls][no++] = hid[0];
+            if (hn == 1) { hn = 0; break; }
+            hn--;
+            pr[0] = pr[hn]; hid[0] = hid[hn];
+            int i = 0;
+            for (;;) {                                        // _min_heapify
+                const int l = (i << 1) + 1, r = (i + 1) << 1;
+                int low = (l < hn && pr[l] < pr[i]) ? l : i;
+                if (r < hn && pr[r] < pr[low]) low = r;
+                if (low == i) break;
+                const double tp = pr[i]; pr[i] = pr[low]; pr[low] = tp;
+                const unsigned char ti = hid[i]; hid[i] = hid[low]; hid[low] = ti;
+                i = low;
+            }
+        }
+        ntl[ls] = no;
+        // header: everything k_rs_validate needs before it can stage the obstacle tile
+        const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+        ((int2*)rec)[0] = make_int2(scene, p.n_obst[scene]);
+        ((int2*)rec)[1] = make_int2(n_kept, no);
+        rec[2] = st[0]; rec[3] = st[1]; rec[4] = st[2];
+        rec[5] = sc[SC_BBOX]; rec[6] = sc[SC_BBOX + 1]; rec[7] = sc[SC_BBOX + 2]; rec[8] = sc[SC_BBOX + 3];
+    }
+    __syncthreads();
+    if (!live) return;
+    const int n_test = ntl[ls];
+    const unsigned char* order = ordl[ls];
+    const double q0w = st[2];
     for (int k = k0; k < n_test; k += 8) {
-        const double* W = rec + RS_REC_HDR + 8 * (int)order[k];
+        const double* W = rec + RS_REC_WORDS + 8 * (int)order[k];
         double len[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) len[i] = W[i];
@@ -593,8 +613,8 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
             }
         }
         if (k == 0) {                                    // calc_all_paths' rotation by -q0 yaw (:47-49), once per search:
-            tb[RS_SEGW + 7] = hm_cos(-rec[4]);           // spare words of table 0
-            tb[2 * RS_SEGW + 7] = hm_sin(-rec[4]);
+            tb[RS_SEGW + 7] = hm_cos(-q0w);              // spare words of table 0
+            tb[2 * RS_SEGW + 7] = hm_sin(-q0w);
         }
     }
 }
@@ -853,7 +873,7 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     }
     // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
     if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
-    hipLaunchKernelGGL(k_rs_words, dim3((p.max_queue + RSA_SCENES - 1) / RSA_SCENES), dim3(WAVE), 0, stream, p);
+    hipLaunchKernelGGL(k_rs_words, dim3((p.max_queue + RSA_SCENES - 1) / RSA_SCENES, RSA_GROUPS), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
     if (timer) timer->begin(HOPE_K_RS_SEGS, stream);
     hipLaunchKernelGGL(k_rs_segs, dim3((p.max_queue + 7) / 8), dim3(WAVE), 0, stream, p);
