@@ -374,6 +374,14 @@ __global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const 
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+template <int PART>
+static void launch_env_step(bool of64, bool af64, dim3 grid, dim3 block, size_t lds, hipStream_t sc, const StepParams& p) {
+    if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double, false, PART>), grid, block, lds, sc, p);
+    else if (of64) hipLaunchKernelGGL((k_env_step<double, float, false, PART>), grid, block, lds, sc, p);
+    else if (af64) hipLaunchKernelGGL((k_env_step<float, double, false, PART>), grid, block, lds, sc, p);
+    else hipLaunchKernelGGL((k_env_step<float, float, false, PART>), grid, block, lds, sc, p);
+}
+
 extern "C" {
 
 const char* hope_last_error(void) { return g_err.c_str(); }
@@ -452,11 +460,14 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
     if (lds > 48 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_env_step<double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (const void* f : {(const void*)k_env_step<float, float>, (const void*)k_env_step<float, float, true>,
+                              (const void*)k_env_step<float, double>, (const void*)k_env_step<double, float>,
+                              (const void*)k_env_step<double, double>,
+                              (const void*)k_env_step<float, float, false, 1>, (const void*)k_env_step<float, double, false, 1>,
+                              (const void*)k_env_step<double, float, false, 1>, (const void*)k_env_step<double, double, false, 1>,
+                              (const void*)k_env_step<float, float, false, 2>, (const void*)k_env_step<float, double, false, 2>,
+                              (const void*)k_env_step<double, float, false, 2>, (const void*)k_env_step<double, double, false, 2>})
+            HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (flags & (HOPE_F_OVERLAP | HOPE_F_GRAPH)) {
         const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
@@ -630,6 +641,10 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         n_streams = overlap ? n_chain : 1;
     }
     const bool fork = overlap && n_streams > 1;
+    // the observation half of the step kernel on its own stream, next to the Reeds-Shepp kernels of the same class
+    static const bool no_split = getenv("HOPE_NO_SPLIT") != nullptr;
+    // (measured: +4.5 % at 65 536 scenes, +3.7 % at 131 072, 0 at 16 384, -3 % at 8 192 and below: two more launches per class)
+    const bool split = fork && n_chain == 2 && want_rs && (stages & HOPE_STAGE_OBS) && !step_timing && !no_split && h->n >= 16384;
     if (fork) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         for (int i = 1; i < n_streams; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
@@ -654,13 +669,19 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
         if (tm) tm->begin(HOPE_K_STEP, sc);
-        if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double>), grid, block, lds, sc, p);
-        else if (of64) hipLaunchKernelGGL((k_env_step<double, float>), grid, block, lds, sc, p);
-        else if (af64) hipLaunchKernelGGL((k_env_step<float, double>), grid, block, lds, sc, p);
-        else if (step_timing) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sc, p);
-        else hipLaunchKernelGGL((k_env_step<float, float>), grid, block, lds, sc, p);
+        if (split) launch_env_step<1>(of64, af64, grid, block, lds, sc, p);
+        else if (step_timing && !of64 && !af64) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sc, p);
+        else launch_env_step<0>(of64, af64, grid, block, lds, sc, p);
         if (tm) tm->end(sc);
-        if (fork && (stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // the image only needs the poses
+        if (fork && n_chain == 2 && (split || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // poses final
+        if (split) {
+            hipStream_t so = h->side[3 + i];
+            HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
+            if (tm) tm->begin(HOPE_K_STEP, so);
+            launch_env_step<2>(of64, af64, grid, block, lds, so, p);
+            if (tm) tm->end(so);
+            HIPCHK(hipEventRecord(h->ev_join[3 + i], so));
+        }
         {                                                       // scalar outputs, reward / target arithmetic: one lane per scene
             dim3 pg((p.n_list + WAVE - 1) / WAVE);
             if (tm) tm->begin(HOPE_K_POST, sc);
@@ -704,6 +725,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             HIPCHK(hipEventRecord(h->ev_join[2], si));
         } else {
             if (fork) for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
+            if (split) for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
             HIPCHK(launch_bev_image(b, s, tm));
             return HOPE_OK;
         }
@@ -711,6 +733,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     if (fork) {
         for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
         if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
+        if (split) for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
     }
     return HOPE_OK;
 }

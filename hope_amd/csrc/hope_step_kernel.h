@@ -439,7 +439,11 @@ __device__ unsigned long long g_step_prof[64 * 16];
 #define ST_FLUSH() do { if (TIMING) { tsec[8] = __builtin_readcyclecounter() - tstart_; tsec[9] = 1; \
         if (lane == 0) for (int i_ = 0; i_ < 16; i_++) if (tsec[i_]) atomicAdd(&g_step_prof[(blockIdx.x & 63) * 16 + i_], tsec[i_]); } } while (0)
 
-template <typename OT, typename AT, bool TIMING = false>
+// PART: 0 = the whole scene-step; 1 = motion, status, turnover and state only (everything the Reeds-Shepp chain and k_post
+// wait for); 2 = the observation only (lidar + action mask) of the pose PART 1 left in `state`.  With HOPE_F_OVERLAP the
+// library launches 1 and 2 separately so that the observation runs NEXT TO the Reeds-Shepp kernels of the same tile class
+// (k_rs_compact / k_rs_words / k_rs_segs are short on parallelism and left the GPU half empty when they ran alone).
+template <typename OT, typename AT, bool TIMING = false, int PART = 0>
 __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -447,13 +451,13 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     unsigned long long tsec[16] = {};
     const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
     ST_T0();
-    if (p.rs_count_zero && blockIdx.x == 0 && threadIdx.x == 0) p.rs_count_zero[0] = 0;   // this class's queue length
+    if (PART != 2 && p.rs_count_zero && blockIdx.x == 0 && threadIdx.x == 0) p.rs_count_zero[0] = 0;   // this class's queue length
     const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
     if (p.active && !p.active[scene]) return;
 
     const int n_obst = p.n_obst[scene];
     // the sub-step poses of this step (k_kinematics), requested together with everything else the scene needs
-    const bool moving = (p.stages & HOPE_STAGE_MOTION) && p.has_action;
+    const bool moving = PART != 2 && (p.stages & HOPE_STAGE_MOTION) && p.has_action;
     const double kinv = (moving && lane < KIN_WORDS) ? p.kin[(size_t)scene * KIN_WORDS + lane] : 0.0;
 
     double* tile = lds;
@@ -478,11 +482,16 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     int t = p.tstep[scene];
     wsync();
 
+    double ct = 0, sn = 0;       // cos/sin of the final heading
+    if (PART == 2) {             // the pose PART 1 left behind (after a turnover: the start pose)
+        hm_sincos(h, &sn, &ct);
+        if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;
+    }
+    if (PART != 2) {
     bool arrive = false, moved = false;
     bool known_free = false;     // final pose already passed _detect_collision in the sub-step loop
     bool have_ua = false;        // overlap area of the final pose already computed
     double ua = 0.0;
-    double ct = 0, sn = 0;       // cos/sin of the final heading
     bool have_cs = false;
     const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
     int* nlist = keep;           // near-obstacle list (motion/status); the lidar reuses the words as keep flags
@@ -667,7 +676,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         }
     }
 
-    if (!(p.stages & HOPE_STAGE_OBS)) { ST_T(2); ST_FLUSH(); return; }
+    }                            // PART != 2
+    if (PART == 1 || !(p.stages & HOPE_STAGE_OBS)) { ST_T(2); ST_FLUSH(); return; }
 
     ST_T(2);
     // ---- lidar (lidar_simulator.py:31-135) -----------------------------------------------------------
