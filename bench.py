@@ -226,7 +226,9 @@ def main():
         # HIP events recorded by the library on the launch stream: around every launch of the roofline kernel inside the
         # timed region (dom_stats), around every launch of every kernel in the short pass after it (kstats).
         # `kernel_ms` is the roofline kernel's AVERAGE LAUNCH duration over the timed region (directly comparable with
-        # rocprofv3's AverageNs: k_env_step is launched once per tile class, i.e. 2 launches per bench step);
+        # rocprofv3's AverageNs: k_env_step is launched per tile class -- from 16 384 scenes on as two launches each, the
+        # motion half and the observation half (template instantiations PART 1 / 2, two rows in rocprof's table) -- i.e. 4
+        # launches per bench step at the default size; the average is over all of them);
         # `algorithmic bytes per launch` is averaged over the same launches, so achieved = bytes/launch / kernel_ms.
         per_step = {k: v[0] / max(n_break, 1) for k, v in kstats.items()}
         # The roofline is stated for the kernel that moves the algorithmic bytes of §8(d): k_env_step (k_rs_validate
@@ -302,7 +304,9 @@ def main():
                          'largest_by_time': largest,
                          'concurrent_launches': ('the launch chains of the two obstacle-tile classes run on two streams: the '
                                                  'k_env_step launches overlap each other and the other class\'s kernels, so '
-                                                 'per-launch durations include that sharing') if env.overlap else None,
+                                                 'per-launch durations include that sharing; from 16 384 scenes on k_env_step is '
+                                                 'two launches per class (motion half, then the observation half on its own stream '
+                                                 'next to the Reeds-Shepp kernels)') if env.overlap else None,
                          # the same kernel per step CALL: all its launches' bytes over the time during which at least one of them
                          # ran (the union of the launch intervals) -- what the kernel sustains while its launches overlap
                          'per_call': {'kernel_ms': dom_union[0] / max(dom_union[1], 1), 'calls': dom_union[1],

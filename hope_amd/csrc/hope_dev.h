@@ -164,6 +164,14 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// obstacle box (xmin, xmax, ymin, ymax) in float32, rounded outwards: every cull against it keeps a superset
+__device__ __forceinline__ float4 obstacle_box(const double* v) {
+    return make_float4(__double2float_rd(fmin(fmin(v[0], v[2]), fmin(v[4], v[6]))),
+                       __double2float_ru(fmax(fmax(v[0], v[2]), fmax(v[4], v[6]))),
+                       __double2float_rd(fmin(fmin(v[1], v[3]), fmin(v[5], v[7]))),
+                       __double2float_ru(fmax(fmax(v[1], v[3]), fmax(v[5], v[7]))));
+}
+
 // wave-uniform LDS synchronisation for a one-wave workgroup
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 

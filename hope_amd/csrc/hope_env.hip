@@ -59,6 +59,7 @@ struct hope_env {
     int cls_count[2] = {0, 0};
     std::vector<int32_t> n_obst_host;
     double* rs_rec = nullptr;
+    float4* obb = nullptr;          // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
     // staging for set_scenes
     void* stage = nullptr;
     size_t stage_bytes = 0;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
                                                const int32_t* pl1, int n1, const double* pverts, const double* pc,
                                                const int32_t* pnob, double* verts, double* scene_c, int32_t* n_obst,
                                                double* state, int32_t* tstep, double* traj, int32_t* traj_len,
-                                               int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode) {
+                                               int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode, float4* obb) {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (!mask[s]) return;
     const int cls = (max_obst > SMALL_TILE && n_obst[s] > SMALL_TILE) ? 1 : 0;
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
         const double2* src = (const double2*)(pverts + (size_t)j * max_obst * 8);
         double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
         for (int v = lane; v < 4 * nob; v += WAVE) dst[v] = src[v];
+        for (int o = lane; o < nob; o += WAVE) obb[(size_t)s * max_obst + o] = obstacle_box(pverts + ((size_t)j * max_obst + o) * 8);
         if (lane < SC_WORDS) c[lane] = pc[(size_t)j * SC_WORDS + lane];
         if (lane == 0) { n_obst[s] = nob; cur_pool[s] = j; }
     }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
 }
 
 // one block per uploaded scene: copy its obstacle tile
-__global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const double* verts_in, double* verts,
+__global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const double* verts_in, double* verts, float4* obb,
                                   int max_obst) {
     int k = blockIdx.x;
     int s = ids[k];
@@ -367,6 +369,8 @@ __global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const 
     double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
     int nv = 4 * nob[k];
     for (int v = threadIdx.x; v < nv; v += blockDim.x) dst[v] = src[v];
+    if (obb)
+        for (int o = threadIdx.x; o < nob[k]; o += blockDim.x) obb[(size_t)s * max_obst + o] = obstacle_box(verts_in + ((size_t)k * max_obst + o) * 8);
 }
 
 }  // namespace
@@ -420,6 +424,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         }                                                                                          \
     } while (0)
     ALLOC(h->verts, N * max_obstacles * 8 * sizeof(double));
+    ALLOC(h->obb, N * max_obstacles * sizeof(float4));
     ALLOC(h->n_obst, N * sizeof(int32_t));
     ALLOC(h->scene_c, N * SC_WORDS * sizeof(double));
     ALLOC(h->state, N * ST_WORDS * sizeof(double));
@@ -502,7 +507,7 @@ int hope_env_destroy(hope_env_t* h) {
     }
     if (h->gstream) hipStreamDestroy(h->gstream);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
-    void* ptrs[] = {h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
+    void* ptrs[] = {h->obb, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
                     h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pool_verts, h->pool_c, h->pool_nobst, h->pool_state, h->pool_t, h->pool_cls[0], h->pool_cls[1], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -561,7 +566,7 @@ int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double*
 
 static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double* start, const double* dest, const double* bbox,
                          const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
-                         int32_t* d_nobst, double* d_verts, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid);
+                         int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid);
 
 int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const double* start, const double* dest,
                         const double* bbox, const double* verts, const int32_t* n_obst) {
@@ -577,7 +582,7 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     {
         int rc = upload_scenes(h, scene_ids, n, start, dest, bbox, verts, n_obst, h->scene_c, h->state, h->tstep, h->n_obst,
-                               h->verts, h->traj, h->traj_len, h->traj_valid);
+                               h->verts, h->obb, h->traj, h->traj_len, h->traj_valid);
         if (rc != HOPE_OK) return rc;
     }
     // rebuild the dense per-class scene lists (host mirror of n_obst; N ints, reset-time only)
@@ -604,7 +609,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
                         hipStream_t s, bool overlap, int has_action, LaunchTimer* tm) {
     StepParams p;
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
-    p.verts = h->verts; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
+    p.verts = h->verts; p.obb = h->obb; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
     p.actions = actions; p.active = active; p.kin = h->kin; p.post = h->post;
     p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
@@ -644,7 +649,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     // the observation half of the step kernel on its own stream, next to the Reeds-Shepp kernels of the same class
     static const bool no_split = getenv("HOPE_NO_SPLIT") != nullptr;
     // (measured: +4.5 % at 65 536 scenes, +3.7 % at 131 072, 0 at 16 384, -3 % at 8 192 and below: two more launches per class)
-    const bool split = fork && n_chain == 2 && want_rs && (stages & HOPE_STAGE_OBS) && !step_timing && !no_split && h->n >= 16384;
+    const char* split_min = getenv("HOPE_SPLIT_MIN");      // (read per call: the tests force the split at small sizes)
+    const bool split = fork && n_chain == 2 && want_rs && (stages & HOPE_STAGE_OBS) && !step_timing && !no_split &&
+                       h->n >= (split_min ? atoi(split_min) : 16384);
     if (fork) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         for (int i = 1; i < n_streams; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
@@ -701,7 +708,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         r.max_queue = p.n_list;
         r.slot_base = (c == 0) ? ch.a : h->n - 1 - ch.a;    // the two classes fill the record storage from both ends
         r.slot_dir = (c == 0) ? 1 : -1;
-        r.verts = h->verts; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
+        r.verts = h->verts; r.obb = h->obb; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
         r.rs_count = counter; r.rs_list = qlist;
         r.rs_rec = h->rs_rec;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
@@ -801,7 +808,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
 // Shared by set_scenes and set_pool: stage the host arrays and write constants / tiles for entries ids[0..n)
 static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double* start, const double* dest, const double* bbox,
                          const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
-                         int32_t* d_nobst, double* d_verts, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid) {
+                         int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid) {
     size_t tile = (size_t)h->max_obst * 8 * sizeof(double);
     size_t o_ids = 0, o_nob = o_ids + sizeof(int32_t) * n, o_start = (o_nob + sizeof(int32_t) * n + 15) & ~(size_t)15;
     size_t o_dest = o_start + 24 * (size_t)n, o_bbox = o_dest + 24 * (size_t)n, o_verts = (o_bbox + 32 * (size_t)n + 15) & ~(size_t)15;
@@ -825,7 +832,7 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
                        (const int32_t*)(sp + o_nob), d_scene_c, d_state, d_t, d_nobst, d_traj, d_traj_len, d_traj_valid);
     if (verts)
         hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
-                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), d_verts, h->max_obst);
+                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), d_verts, d_obb, h->max_obst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return HOPE_OK;
@@ -865,7 +872,7 @@ int hope_env_set_pool(hope_env_t* h, int n_pool, const double* start, const doub
         for (int k = 0; k < m; k++) ids[k] = a + k;
         int rc = upload_scenes(h, ids.data(), m, start + 3 * (size_t)a, dest + 3 * (size_t)a, bbox + 4 * (size_t)a,
                                verts + (size_t)a * h->max_obst * 8, n_obst + a, h->pool_c, h->pool_state, h->pool_t,
-                               h->pool_nobst, h->pool_verts, nullptr, nullptr, nullptr);
+                               h->pool_nobst, h->pool_verts, nullptr, nullptr, nullptr, nullptr);
         if (rc != HOPE_OK) return rc;
     }
     std::vector<int32_t> l0, l1;
@@ -886,7 +893,7 @@ int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* str
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     hipLaunchKernelGGL(k_redraw, dim3(h->n), dim3(WAVE), 0, (hipStream_t)stream, h->max_obst, mask, seed, h->pool_cls[0],
                        h->pool_cls_n[0], h->pool_cls[1], h->pool_cls_n[1], h->pool_verts, h->pool_c, h->pool_nobst, h->verts,
-                       h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode);
+                       h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode, h->obb);
     HIPCHK(hipGetLastError());
     return HOPE_OK;
 }

@@ -38,6 +38,7 @@ struct RsParams {
     int max_queue;            // upper bound of *rs_count (= scenes in the class): grid size
     int slot_base, slot_dir;  // word storage slot of queue entry q = slot_base + slot_dir * q (classes fill from both ends)
     int obs_f64;
+    const float4* obb;        // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
     const double* verts;      // [n][max_obst][4][2] world frame
     const int32_t* n_obst;    // [n]
     const double* scene_c;    // [n][SC_WORDS]

@@ -661,13 +661,8 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
         const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
         double2* dst = (double2*)tile;
         for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
-        for (int o = lane; o < n_obst; o += WAVE) {           // obstacle boxes (xmin, xmax, ymin, ymax), rounded outwards
-            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
-            obb[o] = make_float4(__double2float_rd(fmin(fmin(v[0], v[2]), fmin(v[4], v[6]))),
-                                 __double2float_ru(fmax(fmax(v[0], v[2]), fmax(v[4], v[6]))),
-                                 __double2float_rd(fmin(fmin(v[1], v[3]), fmin(v[5], v[7]))),
-                                 __double2float_ru(fmax(fmax(v[1], v[3]), fmax(v[5], v[7]))));
-        }
+        const float4* ob = p.obb + (size_t)scene * p.max_obst;   // obstacle boxes (xmin, xmax, ymin, ymax), rounded outwards
+        for (int o = lane; o < n_obst; o += WAVE) obb[o] = ob[o];
     }
     const double q0x = readlane_d(r0, 2), q0y = readlane_d(r0, 3), q0w = readlane_d(r0, 4);
     const double xmin = readlane_d(r0, 5), xmax = readlane_d(r0, 6), ymin = readlane_d(r0, 7), ymax = readlane_d(r0, 8);

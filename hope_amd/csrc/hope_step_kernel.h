@@ -27,6 +27,7 @@ struct StepParams {
     uint32_t stages;
     int has_action;
     const double* verts;      // [n][max_obst][4][2]
+    const float4* obb;        // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
     const int32_t* n_obst;    // [n]
     const double* scene_c;    // [n][SC_WORDS]
     double* state;            // [n][ST_WORDS]
@@ -225,6 +226,31 @@ __device__ __forceinline__ int build_near_list_box(const double* tile, int n_obs
         if (near) list[cnt + __popcll(m & ((1ull << lane) - 1))] = o;
         cnt += __popcll(m);
     }
+    return cnt;
+}
+
+// The two-launch form of the step kernel never stages the whole tile: the obstacles whose precomputed box (float32, rounded
+// outwards: a superset) meets [bx0, bx1] x [by0, by1] are found from 16 bytes per obstacle, and only THEIR vertices are
+// copied to LDS, compacted: tile slot i = i-th such obstacle, list[i] = i.  Returns their number.
+__device__ __forceinline__ int stage_near(const float4* obb, const double2* src, int n_obst, double bx0, double bx1,
+                                          double by0, double by1, double* tile, int* list, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < n_obst; base += WAVE) {
+        const int o = base + lane;
+        bool near = false;
+        if (o < n_obst) {
+            const float4 bb = obb[o];
+            near = !((double)bb.x > bx1 || (double)bb.y < bx0 || (double)bb.z > by1 || (double)bb.w < by0);
+        }
+        const unsigned long long m = __ballot(near);
+        if (near) list[cnt + __popcll(m & ((1ull << lane) - 1))] = o;
+        cnt += __popcll(m);
+    }
+    wsync();
+    double2* dst = (double2*)tile;
+    for (int i = lane; i < 4 * cnt; i += WAVE) dst[i] = src[4 * list[i >> 2] + (i & 3)];
+    wsync();
+    for (int i = lane; i < cnt; i += WAVE) list[i] = i;
     return cnt;
 }
 
@@ -467,8 +493,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     // ---- stage the scene: constants (192 B), state (32 B), obstacle tile (64 B x n_obst) ---------
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const int n_slots = 4 * n_obst;
-    {
-        const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
+    const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
+    const float4* obb_s = p.obb + (size_t)scene * p.max_obst;
+    if (PART == 0) {
         double2* dst = (double2*)tile;
         for (int v = lane; v < n_slots; v += WAVE) dst[v] = src[v];   // 16 B/lane, coalesced
     }
@@ -498,9 +525,13 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     int apmask = 0, kf_pose = -1;    // kf_pose: the final pose is sub-step pose kf_pose of this step (-1: the pose the step started from)
     // moving: the box around every hull of this step (k_kinematics); else the hull's disc about the rear axle (3.883 m + slack)
     int n_near;
-    if (moving)
-        n_near = build_near_list_box(tile, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), nlist, lane);
-    else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
+    if (PART == 0) {
+        if (moving)
+            n_near = build_near_list_box(tile, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), nlist, lane);
+        else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
+    } else if (moving)
+        n_near = stage_near(obb_s, src, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), tile, nlist, lane);
+    else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
     if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
     wsync();
     ST_T(0);
@@ -639,7 +670,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         box = make_box(x, y, ct, sn);
         // the action-less step's status decides whether _get_reward runs (it only touches accum_arrive_reward)
         wsync();
-        const int n_near0 = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
+        const int n_near0 = PART == 0 ? build_near_list(tile, n_obst, x, y, 3.9, nlist, lane)
+                                      : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
         wsync();
         const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
         bool cont = !detect_collision(box, tile, nlist, n_near0, lane) && !(x > xmax || x < xmin || y > ymax || y < ymin);
@@ -687,7 +719,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     // a lot of 100 obstacles has a dozen within 10 m.  llist: their indices, then (compacted in place) the kept rings'.
     int* llist = keep;
     wsync();                                                  // the near list (same words) is dead
-    const int n_l = build_near_list(tile, n_obst, x, y, LIDAR_RANGE + 1e-6, llist, lane);
+    const double lr = LIDAR_RANGE + 1e-6;
+    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane)
+                              : build_near_list(tile, n_obst, x, y, lr, llist, lane);
     wsync();
     {
         const double a = ct, b = sn;

@@ -432,9 +432,19 @@ def test_full_size_properties_64k():
 def test_overlap_and_graph_modes_equal_the_plain_launch():
     """HOPE_F_OVERLAP (two tile classes on two streams) and HOPE_F_GRAPH (hipGraph replay of the step) only change how
     the same kernels are launched: every output must be bit-identical to the plain stream-ordered launch, including the
-    image, across steps with auto-reset and a changing action buffer."""
+    image, across steps with auto-reset and a changing action buffer.  HOPE_SPLIT_MIN=1 forces the two-launch form of the step
+    kernel (motion / observation on separate streams), which the library otherwise uses from 16 384 scenes on."""
+    import os
     from hope_amd import ParkingBatch
     from hope_amd.scenes import SceneSource
+    os.environ['HOPE_SPLIT_MIN'] = '1'
+    try:
+        _overlap_modes_body(ParkingBatch, SceneSource)
+    finally:
+        del os.environ['HOPE_SPLIT_MIN']
+
+
+def _overlap_modes_body(ParkingBatch, SceneSource):
     n = 3072
     src = SceneSource(seed=5)
     scenes = [src.draw() for _ in range(n)]
@@ -672,3 +682,19 @@ def test_float32_action_rescale_is_the_float32_box_arithmetic():
     assert differs > 0                      # the float64 rescale is a different (documented) arithmetic
     for e in (a, b, c):
         e.close()
+
+
+def test_two_launch_step_kernel_parity_with_rs_search():
+    """The motion / observation halves of the step kernel launched separately (the default from 16 384 scenes on; forced
+    here): every output equals the oracle exactly, Reeds-Shepp search included."""
+    import os
+    os.environ['HOPE_SPLIT_MIN'] = '1'
+    try:
+        env, orc, rng = make_pair(1536, seed=31, level='mixed')
+        s = rollout(env, orc, rng, steps=8, tol=TOL64, with_rs=True)
+        print('two-launch parity:', s)
+        assert s['status_mismatch'] == 0 and s['mask_mismatch'] == 0 and s['rs_flag_mismatch'] == 0 and s['rs_word_mismatch'] == 0
+        assert max(s['pose_err'], s['lidar_err'], s['target_err'], s['reward_err'], s['rinfo_err'], s['rs_len_err']) <= TOL64
+        env.close()
+    finally:
+        del os.environ['HOPE_SPLIT_MIN']
