@@ -320,10 +320,17 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
 // Reeds-Shepp work queues: the flagged scenes of each tile class (blockIdx.y), compacted.  Each block scans its share
 // of the class's scene list (thread = a few consecutive entries, block-wide exclusive scan) and reserves one
 // contiguous range of the queue with a single atomicAdd.
-constexpr int COMPACT_BLOCKS = 16, COMPACT_THREADS = 1024;
+// Small workgroups on purpose: the kernel runs while other streams keep every CU busy with one-wave workgroups, and a
+// 1024-thread workgroup then waits for 16 free wave slots on ONE CU (measured: up to 0.4 ms of queueing).
+constexpr int COMPACT_BLOCKS = 64, COMPACT_THREADS = 256;
+// The gate itself (car_parking_base.py:293-294: t > 1, status CONTINUE, closer than RS_MAX_DIST to the dest -- of the
+// finished step, from k_env_step's hand-over record) is evaluated here, and the Reeds-Shepp outputs of every scene of the
+// class are cleared here, so that the chain motion -> compact -> words -> segs -> validate does not wait for k_post.
+template <typename OT>
 __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list0, int n0, const int32_t* list1, int n1,
-                                                                 const uint8_t* flag, const uint8_t* active, int32_t* rs_list,
-                                                                 int stride, int32_t* rs_count) {
+                                                                 uint8_t* flag, const uint8_t* active, int32_t* rs_list,
+                                                                 int stride, int32_t* rs_count, const double* post,
+                                                                 const double* scene_c, int8_t* rs_word, void* rs_lengths) {
     __shared__ int wsum[COMPACT_THREADS / WAVE];
     __shared__ int base;
     const int c = blockIdx.y;
@@ -337,7 +344,22 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
     int cnt = 0;
     for (int i = a; i < b; i++) {
         const int s = list[i];
-        cnt += flag[s] && (!active || active[s]);
+        if (active && !active[s]) continue;
+        const double* pr = post + (size_t)s * POST_WORDS;
+        const double* sc = scene_c + (size_t)s * SC_WORDS;
+        const int packed = __double2loint(pr[7]);
+        const int status = packed & 0xff, t = packed >> 8;
+        const double ddx = pr[3] - sc[SC_DEST], ddy = pr[4] - sc[SC_DEST + 1];
+        const bool gate = t > 1 && status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
+        flag[s] = gate;
+        cnt += gate;
+        // cleared here; k_rs_validate fills them for the scenes whose search finds a path: {NONE x 5, 0, 0, 0}
+        const unsigned long long none = (unsigned char)HOPE_RS_NONE;
+        *(unsigned long long*)(rs_word + 8 * (size_t)s) = none | none << 8 | none << 16 | none << 24 | none << 32;
+        if (rs_lengths) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) ((OT*)rs_lengths)[5 * (size_t)s + k] = (OT)0;
+        }
     }
     // exclusive scan over the block: inside the wave by shuffles, across the 16 waves through LDS
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
     int o = base + woff + incl - cnt;
     for (int i = a; i < b; i++) {
         const int s = list[i];
-        if (flag[s] && (!active || active[s])) out[o++] = s;
+        if ((!active || active[s]) && flag[s]) out[o++] = s;
     }
 }
 
@@ -479,8 +501,15 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming));
+        // HOPE_PRIO=1 (experiment, rejected): highest stream priority for the launch chains (the critical path), lowest for
+        // the observation / image streams [2], [3], [4].  Measured 0.80 -> 1.08 ms per step at 65 536 scenes: the second
+        // chain's kernels then wait hundreds of microseconds between launches behind the first chain's.
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        static const bool use_prio = getenv("HOPE_PRIO") != nullptr;
         for (int i = 1; i < hope_env::MAX_CHAINS; i++) {
-            HIPCHK(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+            const int prio = !use_prio ? 0 : ((i >= 2 && i <= 4) ? prio_lo : prio_hi);
+            HIPCHK(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, prio));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
     }
@@ -681,26 +710,28 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else launch_env_step<0>(of64, af64, grid, block, lds, sc, p);
         if (tm) tm->end(sc);
         if (fork && n_chain == 2 && (split || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // poses final
+        hipStream_t so = split ? h->side[3 + i] : sc;           // two-launch form: everything the search does not wait for
+        if (split) HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
+        {                                                       // scalar outputs, reward / target arithmetic: one lane per scene
+            dim3 pg((p.n_list + WAVE - 1) / WAVE);
+            if (tm) tm->begin(HOPE_K_POST, so);
+            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
+            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
+            if (tm) tm->end(so);
+        }
         if (split) {
-            hipStream_t so = h->side[3 + i];
-            HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
             if (tm) tm->begin(HOPE_K_STEP, so);
             launch_env_step<2>(of64, af64, grid, block, lds, so, p);
             if (tm) tm->end(so);
             HIPCHK(hipEventRecord(h->ev_join[3 + i], so));
         }
-        {                                                       // scalar outputs, reward / target arithmetic: one lane per scene
-            dim3 pg((p.n_list + WAVE - 1) / WAVE);
-            if (tm) tm->begin(HOPE_K_POST, sc);
-            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
-            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, sc, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
-            if (tm) tm->end(sc);
-        }
         if (!want_rs) continue;
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
-        hipLaunchKernelGGL(k_rs_compact, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list,
-                           (const int32_t*)nullptr, 0, h->rs_flag, active, qlist, h->n, counter);
+        if (of64) hipLaunchKernelGGL(k_rs_compact<double>, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list,
+                           (const int32_t*)nullptr, 0, h->rs_flag, active, qlist, h->n, counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
+        else hipLaunchKernelGGL(k_rs_compact<float>, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list,
+                           (const int32_t*)nullptr, 0, h->rs_flag, active, qlist, h->n, counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
         if (tm) tm->end(sc);
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;

@@ -1053,19 +1053,15 @@ __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_li
         if (out.status) out.status[scene] = status;
         if (out.done) out.done[scene] = status != HOPE_STATUS_CONTINUE;
     }
-    if (out.rs_word) {       // cleared here; the Reeds-Shepp kernel fills it for eligible scenes: {NONE x 5, 0, 0, 0}
-        const unsigned long long none = (unsigned char)HOPE_RS_NONE;
-        *(unsigned long long*)(out.rs_word + 8 * (size_t)scene) = none | none << 8 | none << 16 | none << 24 | none << 32;
-    }
-    if (out.rs_lengths) {
+    if (!(stages & HOPE_STAGE_RS)) {                     // (with the Reeds-Shepp stage k_rs_compact clears them, ahead of the search)
+        if (out.rs_word) {
+            const unsigned long long none = (unsigned char)HOPE_RS_NONE;
+            *(unsigned long long*)(out.rs_word + 8 * (size_t)scene) = none | none << 8 | none << 16 | none << 24 | none << 32;
+        }
+        if (out.rs_lengths) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) ((OT*)out.rs_lengths)[5 * (size_t)scene + i] = (OT)0;
-    }
-    if (stages & HOPE_STAGE_RS) {                                                    // gate :293-294 (the finished step's)
-        // (one global atomicAdd per scene on a single queue counter cost ~45 us per 32 768 scenes: every XCD's
-        // atomics meet at the memory side; a flag and a compaction pass do not)
-        const double ddx = pr[3] - destx, ddy = pr[4] - desty;
-        rs_flag[scene] = t > 1 && status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
+            for (int i = 0; i < 5; i++) ((OT*)out.rs_lengths)[5 * (size_t)scene + i] = (OT)0;
+        }
     }
     if ((fl & POST_F_REWARD) && (stages & HOPE_STAGE_REWARD)) {
         double ri0 = 0, ri2 = 0, ri3 = 0, ri4 = 0, reward = 0;
