@@ -621,6 +621,22 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
         l0.reserve(h->n); l1.reserve(h->n);
         const bool two = h->max_obst > SMALL_TILE;
         for (int i = 0; i < h->n; i++) (two && h->n_obst_host[i] > SMALL_TILE ? l1 : l0).push_back(i);
+        // Two launch chains run concurrently (HOPE_F_OVERLAP): the step ends with the longer one running alone.  A scene with
+        // few obstacles may run in the large-tile launches too (it only gets more LDS than it needs), so the small-tile class
+        // hands scenes over until the large-tile chain holds `frac` of all scenes (HOPE_CLS1_FRAC, default below).
+        if (two && (h->flags & HOPE_F_OVERLAP)) {
+            const char* fr = getenv("HOPE_CLS1_FRAC");
+            // measured (mixed scene set, 25 % large-tile scenes by themselves): 0.42 gives +1 / +4 / +4 % at 4 096 / 8 192 / 16 384
+            // scenes, 0 at 32 768, -3 % at 65 536 (the moved scenes lose occupancy there and nothing is left to hide)
+            const double frac = fr ? atof(fr) : (h->n < 32768 ? 0.42 : 0.0);
+            const size_t want1 = (size_t)(frac * h->n);
+            if (l1.size() < want1) {
+                const size_t move = std::min(l0.size(), want1 - l1.size());
+                l1.insert(l1.end(), l0.end() - move, l0.end());
+                l0.resize(l0.size() - move);
+                std::sort(l1.begin(), l1.end());
+            }
+        }
         h->cls_count[0] = (int)l0.size(); h->cls_count[1] = (int)l1.size();
         if (!l0.empty()) HIPCHK(hipMemcpy(h->cls_list[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         if (!l1.empty()) HIPCHK(hipMemcpy(h->cls_list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
