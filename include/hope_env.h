@@ -70,11 +70,20 @@ extern "C" {
 #define HOPE_F_ACTION_F64 0x2   /* action buffer is float64; default float32 */
 #define HOPE_F_PROFILE 0x4      /* record HIP events around every kernel launch (hope_env_kernel_ms) */
 #define HOPE_F_IMAGE 0x8        /* keep vehicle.trajectory (last 20 poses/scene) so that HOPE_STAGE_IMG can be used */
-#define HOPE_F_OVERLAP 0x10     /* launch the two obstacle-tile classes of a step on two streams (fork / join with events):
-                                   at <= 16 k scenes per GPU one class alone cannot fill the 1024 SIMDs */
+#define HOPE_F_OVERLAP 0x10     /* launch the two obstacle-tile classes of a step on two streams (fork / join with events),
+                                   and from 16 k scenes on the observation half of the step kernel on further streams
+                                   next to the Reeds-Shepp kernels: one chain alone leaves issue slots idle */
 #define HOPE_F_GRAPH 0x20       /* capture the launches of a step into a hipGraph on a library stream (ordered against the
                                    caller's stream with two events) and replay it while the arguments repeat: same
                                    actions / active / out pointers and stages.  Not combinable with HOPE_F_PROFILE */
+
+/* Environment variables read by the library (tuning / diagnostics only; results never depend on them):
+ *   HOPE_SPLIT_MIN   scenes per handle from which HOPE_F_OVERLAP launches k_env_step as a motion and an observation
+ *                    launch (default 16384); HOPE_NO_SPLIT: never
+ *   HOPE_CLS1_FRAC   share of the scenes the large-tile launch chain should hold after the small-tile class has handed
+ *                    scenes over (default 0.42 below 32768 scenes, else 0 = no hand-over); read by hope_env_set_scenes
+ *   HOPE_CHAINS, HOPE_BALANCE, HOPE_PRIO, HOPE_RS_OCC   rejected launch / build variants kept for experiments
+ *   HOPE_STEP_TIMING, HOPE_RS_TIMING, HOPE_RS_DEBUG      instrumented kernel builds and profiling switches (tools/) */
 
 /* hope_env_step stage mask */
 #define HOPE_STAGE_MOTION 0x1   /* kinematics + arrival + collision sub-step loop (CarParking.step :255-277) */
