@@ -306,7 +306,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         bool near = active && !((double)bb.x > hmaxx || (double)bb.y < hminx || (double)bb.z > hmaxy || (double)bb.w < hminy);
         if (!__any(near)) continue;
         if (near) {
-#pragma unroll
+#pragma unroll 1
             for (int j = 0; j < 4; j++) {
                 double x1 = o[2 * j], y1 = o[2 * j + 1], x2 = o[2 * ((j + 1) & 3)], y2 = o[2 * ((j + 1) & 3) + 1];
                 double exmin = fmin(x1, x2), exmax = fmax(x1, x2), eymin = fmin(y1, y2), eymax = fmax(y1, y2);
