@@ -322,64 +322,50 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
 // contiguous range of the queue with a single atomicAdd.
 // Small workgroups on purpose: the kernel runs while other streams keep every CU busy with one-wave workgroups, and a
 // 1024-thread workgroup then waits for 16 free wave slots on ONE CU (measured: up to 0.4 ms of queueing).
-constexpr int COMPACT_BLOCKS = 64, COMPACT_THREADS = 256;
+constexpr int COMPACT_THREADS = 256;
 // The gate itself (car_parking_base.py:293-294: t > 1, status CONTINUE, closer than RS_MAX_DIST to the dest -- of the
 // finished step, from k_env_step's hand-over record) is evaluated here, and the Reeds-Shepp outputs of every scene of the
 // class are cleared here, so that the chain motion -> compact -> words -> segs -> validate does not wait for k_post.
+// One thread per scene: the queue is sorted by scene inside each block's 256 scenes; the blocks append in arrival order.
 template <typename OT>
-__global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list0, int n0, const int32_t* list1, int n1,
-                                                                 uint8_t* flag, const uint8_t* active, int32_t* rs_list,
-                                                                 int stride, int32_t* rs_count, const double* post,
+__global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list, int n, uint8_t* flag, const uint8_t* active,
+                                                                 int32_t* out, int32_t* rs_count, const double* post,
                                                                  const double* scene_c, int8_t* rs_word, void* rs_lengths) {
     __shared__ int wsum[COMPACT_THREADS / WAVE];
     __shared__ int base;
-    const int c = blockIdx.y;
-    const int32_t* list = c ? list1 : list0;
-    const int n = c ? n1 : n0;
-    int32_t* out = rs_list + (size_t)c * stride;
-    const int per_block = (n + COMPACT_BLOCKS - 1) / COMPACT_BLOCKS;
-    const int b0 = blockIdx.x * per_block, b1 = min(n, b0 + per_block);
-    const int per = (per_block + COMPACT_THREADS - 1) / COMPACT_THREADS;
-    const int a = b0 + threadIdx.x * per, b = min(b1, a + per);
-    int cnt = 0;
-    for (int i = a; i < b; i++) {
-        const int s = list[i];
-        if (active && !active[s]) continue;
-        const double* pr = post + (size_t)s * POST_WORDS;
-        const double* sc = scene_c + (size_t)s * SC_WORDS;
-        const int packed = __double2loint(pr[7]);
-        const int status = packed & 0xff, t = packed >> 8;
-        const double ddx = pr[3] - sc[SC_DEST], ddy = pr[4] - sc[SC_DEST + 1];
-        const bool gate = t > 1 && status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
-        flag[s] = gate;
-        cnt += gate;
-        // cleared here; k_rs_validate fills them for the scenes whose search finds a path: {NONE x 5, 0, 0, 0}
-        const unsigned long long none = (unsigned char)HOPE_RS_NONE;
-        *(unsigned long long*)(rs_word + 8 * (size_t)s) = none | none << 8 | none << 16 | none << 24 | none << 32;
-        if (rs_lengths) {
+    const int i = blockIdx.x * COMPACT_THREADS + threadIdx.x;
+    int s = -1;
+    bool gate = false;
+    if (i < n) {
+        s = list[i];
+        if (!active || active[s]) {
+            const double* pr = post + (size_t)s * POST_WORDS;
+            const double* sc = scene_c + (size_t)s * SC_WORDS;
+            const int packed = __double2loint(pr[7]);
+            const int status = packed & 0xff, t = packed >> 8;
+            const double ddx = pr[3] - sc[SC_DEST], ddy = pr[4] - sc[SC_DEST + 1];
+            gate = t > 1 && status == HOPE_STATUS_CONTINUE && sqrt(ddx * ddx + ddy * ddy) < RS_MAX_DIST;
+            flag[s] = gate;
+            // cleared here; k_rs_validate fills them for the scenes whose search finds a path: {NONE x 5, 0, 0, 0}
+            const unsigned long long none = (unsigned char)HOPE_RS_NONE;
+            *(unsigned long long*)(rs_word + 8 * (size_t)s) = none | none << 8 | none << 16 | none << 24 | none << 32;
+            if (rs_lengths) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) ((OT*)rs_lengths)[5 * (size_t)s + k] = (OT)0;
+                for (int k = 0; k < 5; k++) ((OT*)rs_lengths)[5 * (size_t)s + k] = (OT)0;
+            }
         }
     }
-    // exclusive scan over the block: inside the wave by shuffles, across the 16 waves through LDS
+    // exclusive scan over the block: inside the wave by ballot, across the 4 waves through LDS
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-    }
-    if (lane == WAVE - 1) wsum[wave] = incl;
+    const unsigned long long m = __ballot(gate);
+    const int before = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) wsum[wave] = __popcll(m);
     __syncthreads();
     int woff = 0, total = 0;
     for (int w = 0; w < COMPACT_THREADS / WAVE; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
-    if (threadIdx.x == 0) base = total ? atomicAdd(rs_count + c, total) : 0;
+    if (threadIdx.x == 0) base = total ? atomicAdd(rs_count, total) : 0;
     __syncthreads();
-    int o = base + woff + incl - cnt;
-    for (int i = a; i < b; i++) {
-        const int s = list[i];
-        if ((!active || active[s]) && flag[s]) out[o++] = s;
-    }
+    if (gate) out[base + woff + before] = s;
 }
 
 // one block per uploaded scene: copy its obstacle tile
@@ -744,10 +730,13 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (!want_rs) continue;
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
-        if (of64) hipLaunchKernelGGL(k_rs_compact<double>, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list,
-                           (const int32_t*)nullptr, 0, h->rs_flag, active, qlist, h->n, counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
-        else hipLaunchKernelGGL(k_rs_compact<float>, dim3(COMPACT_BLOCKS, 1), dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list,
-                           (const int32_t*)nullptr, 0, h->rs_flag, active, qlist, h->n, counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
+        {
+            const dim3 cg((p.n_list + COMPACT_THREADS - 1) / COMPACT_THREADS);
+            if (of64) hipLaunchKernelGGL(k_rs_compact<double>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active, qlist,
+                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
+            else hipLaunchKernelGGL(k_rs_compact<float>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active, qlist,
+                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
+        }
         if (tm) tm->end(sc);
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
