@@ -9,9 +9,10 @@ MAX over ranks, rank 0 prints ONE JSON line.
 A "step" = one pass of the full hot path (CarParkingWrapper.step: kinematics + collision sub-steps,
 lidar, action mask, reward, Reeds-Shepp feasibility search) over a batch of `--scenes` synthetic
 scenes PER GPU (weak scaling; default 65 536 = BASELINE.json's "64k scenes"), including the
-episode turnover the reference's loop performs (`reset` of finished episodes on the same map and its
-action-less observation step), fused into the step kernel (HOPE_AUTO_RESET).  Inputs (scene tiles, actions) are resident in HBM when the timed
-region starts.  Independent scenes shard over ranks with no data-path collective.
+episode turnover the reference's loop performs: `reset` of finished episodes -- on a NEW map drawn from a
+device-resident pool of generated scenes (HOPE_AUTO_REDRAW; `--same-map`: on the same map) -- and its action-less
+observation step, fused into the step kernel (HOPE_AUTO_RESET).  Inputs (scene tiles, the scene pool, actions) are
+resident in HBM when the timed region starts.  Independent scenes shard over ranks with no data-path collective.
 """
 import argparse
 import json
@@ -43,10 +44,11 @@ def parse():
     ap.add_argument('--horizon', type=int, default=8, help='PPO steps per update / SAC ring depth')
     ap.add_argument('--mini-batch', type=int, default=16384, help='PPO mini-batch / SAC batch (transitions per rank)')
     ap.add_argument('--mini-epoch', type=int, default=2, help='PPO epochs per update (reference: 10)')
-    ap.add_argument('--fresh-scenes', action='store_true',
-                    help='episode turnover on a NEW map (the reference draws a new case every episode): finished scenes draw '
-                         'from a device-resident pool of --pool generated scenes (hope_env_redraw + reset_obs inside the timed '
-                         'region); default = restart on the same map, fused into the step')
+    ap.add_argument('--same-map', action='store_true',
+                    help='finished episodes restart on the SAME map (HOPE_AUTO_RESET alone).  Default: episode turnover on a '
+                         'NEW map, as the reference draws a new case every episode -- finished scenes draw from a '
+                         'device-resident pool of --pool generated scenes inside the step kernel (HOPE_AUTO_REDRAW)')
+    ap.add_argument('--fresh-scenes', action='store_true', help='(the default now; kept for old command lines)')
     ap.add_argument('--pool', type=int, default=8192)
     ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (small batches: launch latency); '
                     'per-kernel HIP events are unavailable then, the roofline is stated on the whole step')
@@ -148,13 +150,16 @@ def main():
         # episode turnover is fused into the step (HOPE_AUTO_RESET = step + restart(done) + reset_obs(active=done))
         env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
 
-    if args.fresh_scenes:
+    fresh = not args.same_map
+    if fresh:
         pool_scenes = make_scenes(args.pool, args.mix, rng)
         env.set_pool(pool_scenes)
 
+        env.set_redraw_seed(args.seed * 7919 + 1)
+
         def one_step(i):  # noqa: F811
-            env.step(act_bank[i % len(act_bank)], stages=stages)
-            env.turnover(seed=args.seed * 7919 + i)
+            # the new map is drawn inside the step kernel (HOPE_AUTO_REDRAW = step + redraw(done) + reset_obs(active=done))
+            env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, fresh=True)
 
     trainer = None
     if args.policy == 'hope':
@@ -165,11 +170,11 @@ def main():
         torch.manual_seed(args.seed)                                  # identical initial weights on every rank
         if args.algo == 'ppo':
             agent = A.BatchedPPO(device=dev, use_img=args.image, mini_batch=args.mini_batch, mini_epoch=args.mini_epoch)
-            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=args.fresh_scenes)
+            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=fresh)
         else:
             agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
             trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac',
-                                 fresh_scenes=args.fresh_scenes)
+                                 fresh_scenes=fresh)
         one_step = lambda i: trainer.step()  # noqa: E731
 
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY
@@ -244,7 +249,7 @@ def main():
         # Memory-side traffic and instruction counts are NOT measured in this run: they come from the PMC passes committed
         # under profiles/ (tools/collect_profiles.sh: separate rocprofv3 --pmc passes of this same command) and are
         # labelled as such.  They describe the default workload only.
-        default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and not args.fresh_scenes)
+        default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and fresh)
         traffic = traffic_source = None
         pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_image.json' if args.image else 'r02_pmc_traffic.json')
         if os.path.exists(pmc) and default_workload and not args.graph:
@@ -296,8 +301,8 @@ def main():
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
-                       'episode_turnover': (f'new map from a device-resident pool of {args.pool} scenes (hope_env_redraw + reset_obs)'
-                                            if args.fresh_scenes else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),
+                       'episode_turnover': (f'new map from a device-resident pool of {args.pool} scenes (drawn inside the step kernel: HOPE_AUTO_REDRAW)'
+                                            if fresh else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': dom,

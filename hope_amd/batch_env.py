@@ -134,13 +134,19 @@ class ParkingBatch:
                 'hope_env_reset_obs')
         return self
 
-    def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False):
+    def set_redraw_seed(self, seed):
+        """seed of the draws of step(..., auto_reset=True, fresh=True)"""
+        L.check(self.lib.hope_env_set_redraw_seed(self.h, C.c_uint64(int(seed) & (2 ** 64 - 1))), 'hope_env_set_redraw_seed')
+        return self
+
+    def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False, fresh=False):
         """actions: [N, 2] (steer, speed) in [-1, 1] on this device.  auto_reset=True: finished scenes restart inside
-        the step (their lidar / action_mask / target are the new episode's first observation)."""
+        the step (their lidar / action_mask / target are the new episode's first observation) -- on the same map, or with
+        fresh=True on a NEW map drawn from the device-resident scene pool (set_pool), like step() + turnover() in one call."""
         if self.image and (stages & L.STAGE_ALL) == L.STAGE_ALL:
             stages |= L.STAGE_IMG                    # USE_IMG (configs.py:100): the image is part of the observation
         if auto_reset:
-            stages |= L.AUTO_RESET
+            stages |= L.AUTO_RESET | (L.AUTO_REDRAW if fresh else 0)
         stages |= self._action_bits
         assert actions.shape == (self.n, 2) and actions.dtype == self.action_dtype and actions.is_contiguous()
         assert actions.device == self.device

@@ -164,6 +164,12 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {        // splitmix64 finaliser
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 // obstacle box (xmin, xmax, ymin, ymax) in float32, rounded outwards: every cull against it keeps a superset
 __device__ __forceinline__ float4 obstacle_box(const double* v) {
     return make_float4(__double2float_rd(fmin(fmin(v[0], v[2]), fmin(v[4], v[6]))),

@@ -59,6 +59,7 @@ struct hope_env {
     int cls_count[2] = {0, 0};
     std::vector<int32_t> n_obst_host;
     double* rs_rec = nullptr;
+    uint64_t redraw_seed = 0;       // HOPE_AUTO_REDRAW
     float4* obb = nullptr;          // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
     // staging for set_scenes
     void* stage = nullptr;
@@ -273,12 +274,6 @@ __global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, dou
 // New map at episode turnover (map.reset + vehicle.reset, car_parking_base.py:127-137), without the host: a finished scene
 // (mask) takes a pool entry of ITS tile class -- the dense per-class launch lists stay valid -- picked by a counter-based
 // hash of (seed, scene, episodes drawn so far), copies its obstacle tile and constants and restarts.  One wave per scene.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {        // splitmix64 finaliser
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask, uint64_t seed, const int32_t* pl0, int n0,
                                                const int32_t* pl1, int n1, const double* pverts, const double* pc,
                                                const int32_t* pnob, double* verts, double* scene_c, int32_t* n_obst,
@@ -645,6 +640,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
+    p.pool_verts = h->pool_verts; p.pool_c = h->pool_c; p.pool_nobst = h->pool_nobst;
+    p.pool_cls[0] = h->pool_cls[0]; p.pool_cls[1] = h->pool_cls[1]; p.pool_cls_n[0] = h->pool_cls_n[0]; p.pool_cls_n[1] = h->pool_cls_n[1];
+    p.cur_pool = h->cur_pool; p.episode = h->episode; p.redraw_seed = h->redraw_seed;
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 block(WAVE);
     // One chain of launches per tile class (scenes with few obstacles get a small LDS tile and therefore more resident
@@ -788,6 +786,10 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_step: hope_env_set_scenes has not been called");
     if (has_action && !actions) return fail(HOPE_EINVAL, "hope_env_step: actions is null");
     if (stages & HOPE_STAGE_RS) stages |= HOPE_STAGE_REWARD;       // the RS gate needs the status
+    if (stages & HOPE_AUTO_REDRAW) {
+        if (!(stages & HOPE_AUTO_RESET)) return fail(HOPE_EINVAL, "hope_env_step: HOPE_AUTO_REDRAW needs HOPE_AUTO_RESET");
+        if (h->pool_n <= 0) return fail(HOPE_ESTATE, "hope_env_step: HOPE_AUTO_REDRAW without a scene pool (hope_env_set_pool)");
+    }
     if (stages & HOPE_STAGE_IMG) {
         if (!h->traj) return fail(HOPE_ESTATE, "hope_env_step: HOPE_STAGE_IMG needs a handle created with HOPE_F_IMAGE");
         if (!out->img) return fail(HOPE_EINVAL, "hope_env_step: HOPE_STAGE_IMG without out->img");
@@ -918,6 +920,14 @@ int hope_env_set_pool(hope_env_t* h, int n_pool, const double* start, const doub
     if (!l0.empty()) HIPCHK(hipMemcpy(h->pool_cls[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!l1.empty()) HIPCHK(hipMemcpy(h->pool_cls[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     h->pool_n = n_pool;
+    drop_graphs(h);                                         // the pool pointers are kernel arguments of the captured launches
+    return HOPE_OK;
+}
+
+int hope_env_set_redraw_seed(hope_env_t* h, uint64_t seed) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_set_redraw_seed: null handle");
+    h->redraw_seed = seed;
+    drop_graphs(h);                                         // the seed is a kernel argument of the captured launches
     return HOPE_OK;
 }
 

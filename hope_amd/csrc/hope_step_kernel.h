@@ -43,6 +43,15 @@ struct StepParams {
     const double* hull_base;  // [NBEAM]
     const double* beam_ab;    // [NBEAM][2]
     hope_step_out out;
+    // HOPE_AUTO_REDRAW: the device-resident scene pool (hope_env_set_pool), or null pointers
+    const double* pool_verts; // [pool_n][max_obst][8]
+    const double* pool_c;     // [pool_n][SC_WORDS]
+    const int32_t* pool_nobst;
+    const int32_t* pool_cls[2];
+    int pool_cls_n[2];
+    int32_t* cur_pool;        // [n]
+    uint32_t* episode;        // [n]
+    unsigned long long redraw_seed;
     double* post;             // [n][POST_WORDS] per-scene hand-over to k_post (reward / target arithmetic, lane = scene)
     uint8_t* rs_flag;         // [n] 1: the scene passes the Reeds-Shepp gate this step (k_rs_compact builds the queues)
     int32_t* rs_count_zero;   // this tile class's RS queue counter, cleared here for the k_rs_compact that follows; or null
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
     if (p.active && !p.active[scene]) return;
 
-    const int n_obst = p.n_obst[scene];
+    int n_obst = p.n_obst[scene];
     // the sub-step poses of this step (k_kinematics), requested together with everything else the scene needs
     const bool moving = PART != 2 && (p.stages & HOPE_STAGE_MOTION) && p.has_action;
     const double kinv = (moving && lane < KIN_WORDS) ? p.kin[(size_t)scene * KIN_WORDS + lane] : 0.0;
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     double* dbox = scr + LDS_DBOX;
     if (lane < 8) dbox[lane] = sc[SC_DBOX + lane];
     const double destx = sc[SC_DEST], desty = sc[SC_DEST + 1], desth = sc[SC_DEST + 2];
-    const double dest_area = sc[SC_DAREA];
+    double dest_area = sc[SC_DAREA];
     double* st = p.state + (size_t)scene * ST_WORDS;
     double x = st[0], y = st[1], h = st[2], accum = st[3];
     const double prev_x = x, prev_y = y, prev_h = h;      // prev_state (car_parking_base.py:255)
@@ -663,6 +672,35 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     // ---- fused episode turnover (HOPE_AUTO_RESET): CarParking.reset on the same map + its action-less step -------
     const bool turnover = (p.stages & HOPE_AUTO_RESET) && (p.stages & HOPE_STAGE_REWARD) && status != HOPE_STATUS_CONTINUE;
     if (turnover) {
+        // HOPE_AUTO_REDRAW: a NEW map first (map.reset, car_parking_base.py:134): a pool entry of this scene's tile class,
+        // picked exactly as hope_env_redraw picks it, copied into the scene's slots by this wave; the rest of the turnover
+        // (and of this kernel, in the one-launch form) then works on the new scene, whose whole tile is staged in LDS
+        bool redrawn = false;
+        if ((p.stages & HOPE_AUTO_REDRAW) && p.pool_verts) {
+            const int cls = (p.max_obst > SMALL_TILE && n_obst > SMALL_TILE) ? 1 : 0;
+            const int cnt = p.pool_cls_n[cls];
+            if (cnt > 0) {
+                const uint32_t ep = p.episode[scene];
+                const int j = p.pool_cls[cls][(int)(mix64(p.redraw_seed ^ mix64(((uint64_t)scene << 32) | ep)) % (uint64_t)cnt)];
+                const int nob = p.pool_nobst[j];
+                const double2* psrc = (const double2*)(p.pool_verts + (size_t)j * p.max_obst * 8);
+                double2* gdst = (double2*)(const_cast<double*>(p.verts) + (size_t)scene * p.max_obst * 8);
+                double2* ldst = (double2*)tile;
+                wsync();
+                for (int v = lane; v < 4 * nob; v += WAVE) { const double2 q2 = psrc[v]; gdst[v] = q2; ldst[v] = q2; }
+                float4* gobb = const_cast<float4*>(p.obb) + (size_t)scene * p.max_obst;
+                for (int o = lane; o < nob; o += WAVE) gobb[o] = obstacle_box(p.pool_verts + ((size_t)j * p.max_obst + o) * 8);
+                const double* pc = p.pool_c + (size_t)j * SC_WORDS;
+                if (lane < SC_WORDS) const_cast<double*>(p.scene_c)[(size_t)scene * SC_WORDS + lane] = pc[lane];
+                if (lane == 0) { const_cast<int32_t*>(p.n_obst)[scene] = nob; p.cur_pool[scene] = j; p.episode[scene] = ep + 1; }
+                sc = pc;                                                // the new scene's constants, straight from the pool
+                if (lane < 8) dbox[lane] = sc[SC_DBOX + lane];
+                dest_area = sc[SC_DAREA];
+                n_obst = nob;
+                redrawn = true;
+                wsync();
+            }
+        }
         x = sc[SC_START]; y = sc[SC_START + 1]; h = sc[SC_START + 2];
         accum = 0.0;
         t = 1;                                                          // reset: t = 0, then step() -> t = 1
@@ -670,8 +708,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         box = make_box(x, y, ct, sn);
         // the action-less step's status decides whether _get_reward runs (it only touches accum_arrive_reward)
         wsync();
-        const int n_near0 = PART == 0 ? build_near_list(tile, n_obst, x, y, 3.9, nlist, lane)
-                                      : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
+        const int n_near0 = (PART == 0 || redrawn) ? build_near_list(tile, n_obst, x, y, 3.9, nlist, lane)
+                                                   : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
         wsync();
         const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
         bool cont = !detect_collision(box, tile, nlist, n_near0, lane) && !(x > xmax || x < xmin || y > ymax || y < ymin);

@@ -148,6 +148,8 @@ class HopeRollout:
         self.successes = torch.zeros((), dtype=torch.int64, device=dev)
         self.reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
         self.steps = 0
+        if fresh_scenes and hasattr(env, 'set_redraw_seed'):
+            env.set_redraw_seed(seed * 1000003 + 17)
         env.reset_obs()
         agent.observe(self._raw_obs())
 
@@ -170,9 +172,8 @@ class HopeRollout:
             from .policy import gaussian_log_prob
             log_prob = gaussian_log_prob(mean, agent.log_std.expand_as(mean), action)
         self.ring.write_before(nobs, action, log_prob)              # copies: env.step overwrites the buffers in place
-        if self.fresh:
-            env.step(action.to(env.action_dtype).contiguous())
-            env.turnover(seed=self.seed * 1000003 + self.steps)
+        if self.fresh:                                # new map per episode, drawn inside the step kernel (HOPE_AUTO_REDRAW)
+            env.step(action.to(env.action_dtype).contiguous(), auto_reset=True, fresh=True)
         else:
             env.step(action.to(env.action_dtype).contiguous(), auto_reset=True)
         self.ring.write_after(env.reward, env.done)

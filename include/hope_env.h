@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 3
+#define HOPE_ABI_VERSION 4
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -111,6 +111,12 @@ extern "C" {
  * the new episode's first observation.  Equivalent to hope_env_step + hope_env_restart(done) +
  * hope_env_reset_obs(active = done) without the extra launches. */
 #define HOPE_AUTO_RESET 0x20
+/* modifier bit, with HOPE_AUTO_RESET: the finished scene continues on a NEW map, as CarParking.reset does
+ * (map.reset, car_parking_base.py:134): a pool entry of its obstacle-tile class (hope_env_set_pool), chosen exactly as
+ * hope_env_redraw chooses it -- by a counter-based hash of (the seed of hope_env_set_redraw_seed, scene, episodes drawn
+ * so far) -- is copied into the scene inside the step kernel.  Equivalent to hope_env_step + hope_env_redraw(done, seed) +
+ * hope_env_reset_obs(active = done) without the extra launches.  HOPE_ESTATE without a pool. */
+#define HOPE_AUTO_REDRAW 0x100
 
 typedef struct hope_env hope_env_t;
 
@@ -182,6 +188,8 @@ int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
  * hope_env_reset_obs(active = mask) for the first observation.  The host refills / replaces the pool whenever it likes. */
 int hope_env_set_pool(hope_env_t *h, int n_pool, const double *start, const double *dest, const double *bbox,
                       const double *verts, const int32_t *n_obst);
+/* seed of HOPE_AUTO_REDRAW's draws (default 0) */
+int hope_env_set_redraw_seed(hope_env_t *h, uint64_t seed);
 int hope_env_redraw(hope_env_t *h, const uint8_t *mask, uint64_t seed, void *stream);
 /* pool entry each scene currently holds (-1: as uploaded by hope_env_set_scenes); host-synchronous */
 int hope_env_download_pool_index(hope_env_t *h, int32_t *out /*[N]*/);

@@ -95,7 +95,7 @@ def rollout(env, orc, rng, steps, tol, with_rs=False, stages=None):
 def test_library_is_native():
     from hope_amd import load_library
     L = load_library()
-    assert L.hope_abi_version() == 3
+    assert L.hope_abi_version() == 4
 
 
 def test_step_parity_f64_dlp():
@@ -698,3 +698,50 @@ def test_two_launch_step_kernel_parity_with_rs_search():
         env.close()
     finally:
         del os.environ['HOPE_SPLIT_MIN']
+
+
+def test_fused_new_map_turnover_equals_step_plus_turnover():
+    """HOPE_AUTO_REDRAW (a new map drawn inside the step kernel) == hope_env_step + hope_env_redraw(done, seed) +
+    hope_env_reset_obs(active = done) with the same seed: every output, the state and the drawn pool entries, in the
+    one-launch and in the two-launch form of the step kernel, image included."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import SceneSource
+    n, mo, P = 2048, 128, 500
+    src = SceneSource(seed=41)
+    scenes = [src.draw() for _ in range(n)]
+    pool = [src.draw() for _ in range(P)]
+    names = ('lidar', 'action_mask', 'target', 'reward', 'reward_info', 'status', 'done', 'pose', 'rs_word', 'rs_lengths', 'img')
+    for split in (False, True):
+        if split:
+            os.environ['HOPE_SPLIT_MIN'] = '1'
+        try:
+            a = ParkingBatch(n, mo, obs_dtype=torch.float64, image=True)          # fused
+            b = ParkingBatch(n, mo, obs_dtype=torch.float64, image=True)          # step, then turnover
+            rng = np.random.default_rng(42)
+            t0 = rng.integers(180, 200, n)
+            for e in (a, b):
+                e.set_scenes(np.arange(n), scenes)
+                e.set_pool(pool)
+                e.reset_obs()
+                e.upload_state(t=t0)                                              # many episodes run out of time
+            a.set_redraw_seed(777)
+            g = torch.Generator(device='cuda').manual_seed(9)
+            turned = 0
+            for it in range(24):
+                act = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+                a.step(act, auto_reset=True, fresh=True)
+                b.step(act)
+                turned += int(b.done.sum().item())
+                b.turnover(seed=777)
+                torch.cuda.synchronize()
+                for k in names:
+                    assert torch.equal(getattr(a, k), getattr(b, k)), (split, it, k)
+                pa, ta, aa = a.download_state()
+                pb, tb, ab = b.download_state()
+                assert np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(aa, ab)
+                assert np.array_equal(a.pool_index(), b.pool_index())
+            assert turned > 500
+            a.close(); b.close()
+        finally:
+            os.environ.pop('HOPE_SPLIT_MIN', None)

@@ -42,7 +42,7 @@ py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
   for NS in 4096 8192 16384 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --steps 40 --warmup 10 | tail -1; done
   echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 | tail -1
   echo "== --scenes 8192 --graph"; py $R/bench.py --scenes 8192 --graph --no-cpu-baseline --steps 40 --warmup 10 | tail -1
-  echo "== --fresh-scenes"; py $R/bench.py --fresh-scenes --no-cpu-baseline --steps 40 --warmup 10 | tail -1
+  echo "== --same-map"; py $R/bench.py --same-map --no-cpu-baseline --steps 40 --warmup 10 | tail -1
   echo "== config 4 share: --policy hope --algo rollout --scenes 8192 --image"; py $R/bench.py --policy hope --algo rollout --scenes 8192 --image --no-cpu-baseline | tail -1
   echo "== --policy hope --algo rollout (65536 scenes, no image)"; py $R/bench.py --policy hope --algo rollout --no-cpu-baseline | tail -1
   echo "== config 5 share: --policy hope --algo ppo --scenes 16384"; py $R/bench.py --policy hope --algo ppo --scenes 16384 --no-cpu-baseline --steps 32 --warmup 16 | tail -1
