@@ -63,6 +63,13 @@ def parse():
     ap.add_argument('--cpu-scenes', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=12)
     ap.add_argument('--seed', type=int, default=42)
+    ap.add_argument('--witness', type=int, default=1024,
+                    help='after the timed region: this many random scene slots of the TIMED configuration are rebuilt in the CPU '
+                         'oracle from the state on the device and one more fused step is compared (parity_check); 0 = off')
+    ap.add_argument('--repeat-passes', type=int, default=5,
+                    help='extra passes of --repeat-steps steps after the timed region (outside the driver-timed K steps): '
+                         'their run-to-run spread and the steady-state episode population are reported')
+    ap.add_argument('--repeat-steps', type=int, default=200)
     return ap.parse_args()
 
 
@@ -151,9 +158,11 @@ def main():
         env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
 
     fresh = not args.same_map
+    pool_packed = None
     if fresh:
         pool_scenes = make_scenes(args.pool, args.mix, rng)
-        env.set_pool(pool_scenes)
+        pool_packed = pack_scenes(pool_scenes, args.max_obst)
+        env.set_pool(pool_packed)
 
         env.set_redraw_seed(args.seed * 7919 + 1)
 
@@ -219,6 +228,35 @@ def main():
         kstats = env.kernel_ms(reset=True)
     done_frac = float(env.done.float().mean().item())
     rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
+    # ---- outside the driver-timed K steps: run-to-run spread over longer passes (SURVEY.md §8(d) asks for >= 200 timed steps,
+    # median of 5; the driver's command fixes K), at the episode population those passes converge to (OUTTIME needs t > 200)
+    repeat = None
+    if args.repeat_passes > 0 and trainer is None:
+        if not args.graph:
+            env.profile_kernels([dom])                       # the configuration of the timed region
+        ms = []
+        dsum = 0.0
+        for r in range(args.repeat_passes):
+            torch.cuda.synchronize(dev)
+            tr = time.perf_counter()
+            for i in range(args.repeat_steps):
+                one_step(i)
+            torch.cuda.synchronize(dev)
+            ms.append((time.perf_counter() - tr) / args.repeat_steps * 1e3)
+            dsum += float(env.done.float().mean().item())
+            if not args.graph:
+                env.kernel_union_ms(reset=True)
+                env.kernel_ms(reset=True)
+        sm = sorted(ms)
+        repeat = {'passes': args.repeat_passes, 'steps_per_pass': args.repeat_steps, 'ms_per_step': ms, 'min': sm[0],
+                  'median': sm[len(sm) // 2], 'max': sm[-1], 'spread': (sm[-1] - sm[0]) / sm[len(sm) // 2],
+                  'env_steps_per_s_median': N / (sm[len(sm) // 2] * 1e-3), 'done_frac_at_pass_ends': dsum / args.repeat_passes,
+                  'note': 'this rank, after the driver-timed region; not part of `value`'}
+    # ---- in-run correctness witness of exactly this configuration (after all timing)
+    parity = None
+    if args.witness > 0 and trainer is None and rank == 0:
+        parity = parity_witness(env, stages, fresh, (start, dest, bbox, verts, nob, nvert), len(uniq), pool_packed,
+                                act_bank[3], args.witness, args.seed + 1234)
     if dist is not None:
         tt = torch.tensor([elapsed], device='cpu' if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -327,6 +365,8 @@ def main():
                          'algorithmic_bytes_per_bench_step': bytes_per_launch,
                          'ms_per_bench_step_by_kernel': per_step, 'breakdown_steps': n_break},
         }
+        result['repeat'] = repeat
+        result['parity_check'] = parity
         if trainer is not None:
             from hope_amd.policy import count_parameters
             result['metric'] = 'env+agent steps/sec (full CarParking step + HOPE transformer policy' + \
@@ -345,6 +385,96 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def parity_witness(env, stages, fresh, init_packed, n_uniq, pool_packed, act, k, seed):
+    """In-run correctness witness of the TIMED configuration (float32 observations and actions, the launch form the library
+    picked for this batch size, HOPE_AUTO_RESET [| HOPE_AUTO_REDRAW]): `k` random scene slots are rebuilt in the CPU oracle
+    from what is on the device after the timed region -- pose / t / accumulator (hope_env_download_state) and the map each
+    slot holds now (hope_env_download_pool_index) -- then ONE more fused step runs on the GPU over the whole batch and in the
+    oracle on those slots, with the same actions.  Scenes whose episode ends in that step are followed through the turnover:
+    the oracle resets them on the map the kernel drew.  The oracle is the checker here, nothing else (it runs after the
+    timed region).  The GPU computes in float64 and stores float32, so every float32 output must equal float32(oracle)."""
+    import torch
+    from hope_amd import _lib as L
+    from hope_amd import tables as T
+    from oracle import oracle as O
+    N = env.n
+    k = min(k, N)
+    rng = np.random.default_rng(seed)
+    ids = np.sort(rng.choice(N, k, replace=False))
+    with_rs = bool(stages & L.STAGE_RS)
+    with_obs = bool(stages & L.STAGE_OBS)
+    t = T.all_tables()
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    torch.cuda.synchronize(env.device)
+
+    def maps(slots, pidx):
+        """(start, dest, bbox, verts, n_obst, nvert) of the map each slot holds: pool entry pidx, or (pidx < 0) the scene it got
+        from set_scenes"""
+        out = []
+        for j, a_init in enumerate(init_packed):
+            v = a_init[slots % n_uniq]
+            if pool_packed is not None:
+                sel = (pidx >= 0).reshape((-1,) + (1,) * (v.ndim - 1))
+                v = np.where(sel, pool_packed[j][np.maximum(pidx, 0)], v)
+            out.append(v)
+        return out
+
+    pose, tt, acc = env.download_state()
+    pidx = env.pool_index()[ids] if pool_packed is not None else np.full(k, -1)
+    start, dest, bbox, verts, nob, nvert = maps(ids, pidx)
+    orc = O.BatchOracle(k, env.max_obst, omp=True)
+    orc.set_scenes(np.arange(k), start, dest, bbox, verts, nvert, nob)
+    orc.pose[:], orc.t[:], orc.accum[:] = pose[ids], tt[ids], acc[ids]
+    env.step(act, stages=stages, auto_reset=True, fresh=fresh)
+    torch.cuda.synchronize(env.device)
+    a64 = act[torch.from_numpy(ids).to(act.device)].double().cpu().numpy()
+    o = {kk: vv.copy() for kk, vv in orc.step(a64, with_rs=with_rs).items()}
+    sel = torch.from_numpy(ids).to(env.device)
+    g = {kk: getattr(env, kk)[sel].cpu().numpy() for kk in ('status', 'reward', 'reward_info', 'lidar', 'action_mask', 'target',
+                                                            'rs_word', 'rs_lengths', 'done')}
+    done = o['status'] != 1
+    res = {'scenes': int(k), 'turnovers': int(done.sum()), 'status_mismatch': int((g['status'] != o['status']).sum()),
+           'done_mismatch': int((g['done'].astype(bool) != done).sum())}
+    err, f32bad = 0.0, 0
+
+    def cont(name, got, want):
+        nonlocal err, f32bad
+        if got.size:
+            err = max(err, float(np.abs(got.astype(np.float64) - want).max()))
+            f32bad += int((got != want.astype(got.dtype)).sum())
+    cont('reward', g['reward'], o['reward'])
+    cont('reward_info', g['reward_info'], o['reward_info'])
+    if with_rs:
+        res['rs_mismatch'] = int(((g['rs_word'][:, 6] != o['rs_found']) | (g['rs_word'][:, :5] != o['rs_ctypes']).any(axis=1)).sum())
+        res['rs_found'] = int(o['rs_found'].sum())
+        cont('rs_lengths', g['rs_lengths'], o['rs_lengths'])
+    # observation + state: the scenes that go on, then the ones that were turned over (new episode's first observation)
+    pose2, tt2, acc2 = env.download_state()
+    go = ~done
+    state_bad = int((pose2[ids][go] != orc.pose[go]).any(axis=1).sum() + (tt2[ids][go] != orc.t[go]).sum() + (acc2[ids][go] != orc.accum[go]).sum())
+    mask_bad = 0
+    if with_obs:
+        cont('lidar', g['lidar'][go], o['lidar'][go])
+        cont('target', g['target'][go], o['target'][go])
+        mask_bad += int((g['action_mask'][go] != o['mask'][go].astype(g['action_mask'].dtype)).any(axis=1).sum())
+    if done.any():
+        dl = np.nonzero(done)[0]
+        pidx2 = env.pool_index()[ids][dl] if (pool_packed is not None and fresh) else pidx[dl]
+        s2, d2, b2, v2, n2, nv2 = maps(ids[dl], pidx2)
+        orc2 = O.BatchOracle(len(dl), env.max_obst, omp=True)
+        orc2.set_scenes(np.arange(len(dl)), s2, d2, b2, v2, nv2, n2)
+        o2 = orc2.reset_obs(with_rs=False)
+        state_bad += int((pose2[ids][dl] != orc2.pose).any(axis=1).sum() + (tt2[ids][dl] != orc2.t).sum() + (acc2[ids][dl] != orc2.accum).sum())
+        if with_obs:
+            cont('lidar', g['lidar'][dl], o2['lidar'])
+            cont('target', g['target'][dl], o2['target'])
+            mask_bad += int((g['action_mask'][dl] != o2['mask'].astype(g['action_mask'].dtype)).any(axis=1).sum())
+    res.update({'mask_mismatch': mask_bad, 'state_mismatch': state_bad, 'max_abs_err': err, 'f32_value_mismatch': f32bad,
+                'checker': 'oracle/hope_oracle.c (CPU, float64) on the device state after the timed region + one more fused step; '
+                           'float32 outputs compared with float32(oracle) exactly (f32_value_mismatch) and with the float64 value (max_abs_err)'})
+    return res
 
 
 def cpu_baseline(args, uniq, stages):

@@ -50,7 +50,9 @@ def _global_mean_std(x):
         D.dist.all_reduce(s)
     n = s[2]
     mean = s[0] / n
-    var = (s[1] - n * mean * mean) / (n - 1)
+    # a single transition has no spread: std = 0 (torch's unbiased std would be NaN and poison the advantages; the
+    # normalisation's own epsilon then makes them 0)
+    var = (s[1] - n * mean * mean) / torch.clamp(n - 1, min=1)
     return mean.to(x.dtype), torch.sqrt(torch.clamp(var, min=0)).to(x.dtype)
 
 

@@ -33,17 +33,28 @@ class _Opaque:
         self.__dict__.update(state if isinstance(state, dict) else {'state': state})
 
 
-# globals a HOPE checkpoint legitimately refers to besides the reference's own classes: tensor / storage rebuilders,
-# optimizers (the 'optimizer' tuple), containers and numpy scalars / arrays.  Anything else is refused, so that loading an
-# untrusted file cannot import and call arbitrary code (weights_only=False is needed for the StateNorm instance).
-_ALLOWED_PREFIX = ('torch._utils.', 'torch.optim.', 'torch.nn.', 'torch.storage.', 'torch._tensor.', 'numpy.core.multiarray.',
-                   'numpy._core.multiarray.', 'numpy.core.numeric.', 'numpy._core.numeric.')
-_ALLOWED = {'collections.OrderedDict', 'collections.defaultdict', 'collections.deque', 'builtins.dict', 'builtins.list',
-            'builtins.tuple', 'builtins.set', 'builtins.int', 'builtins.float', 'builtins.bool', 'builtins.str',
-            'builtins.complex', 'builtins.slice', 'builtins.range', 'builtins.bytes', 'builtins.bytearray', '_codecs.encode', 'numpy.dtype', 'numpy.ndarray', 'torch.Tensor', 'torch.Size',
-            'torch.device', 'torch.dtype', 'torch.serialization._get_layout', 'torch.FloatStorage', 'torch.DoubleStorage',
-            'torch.LongStorage', 'torch.IntStorage', 'torch.HalfStorage', 'torch.BoolStorage', 'torch.ByteStorage',
-            'torch.BFloat16Storage', 'torch.float32', 'torch.float64', 'torch.int64', 'torch.int32', 'torch.uint8'}
+# Globals a HOPE checkpoint legitimately refers to besides the reference's own classes: tensor / storage rebuilders, the
+# optimizer classes of the 'optimizer' tuple, containers and numpy scalars / arrays -- an EXPLICIT list of names.  Anything
+# else is refused, so that loading an untrusted file cannot import and call arbitrary code (weights_only=False is needed for
+# the StateNorm instance).  No module prefixes: e.g. torch._utils._import_dotted_name returns any importable callable and
+# torch.storage._load_from_bytes is an unrestricted torch.load, both reachable through a whole-module allowance.
+_ALLOWED = {
+    'collections.OrderedDict', 'collections.defaultdict', 'collections.deque', 'builtins.dict', 'builtins.list',
+    'builtins.tuple', 'builtins.set', 'builtins.frozenset', 'builtins.int', 'builtins.float', 'builtins.bool', 'builtins.str',
+    'builtins.complex', 'builtins.slice', 'builtins.range', 'builtins.bytes', 'builtins.bytearray', '_codecs.encode',
+    # tensors and storages
+    'torch._utils._rebuild_tensor_v2', 'torch._utils._rebuild_tensor', 'torch._utils._rebuild_parameter',
+    'torch._utils._rebuild_parameter_with_state', 'torch._tensor._rebuild_from_type_v2', 'torch.nn.parameter.Parameter',
+    'torch.storage.UntypedStorage', 'torch.storage.TypedStorage', 'torch.Tensor', 'torch.Size', 'torch.device', 'torch.dtype',
+    'torch.serialization._get_layout', 'torch.FloatStorage', 'torch.DoubleStorage', 'torch.LongStorage', 'torch.IntStorage',
+    'torch.HalfStorage', 'torch.BoolStorage', 'torch.ByteStorage', 'torch.BFloat16Storage', 'torch.float32', 'torch.float64',
+    'torch.int64', 'torch.int32', 'torch.uint8',
+    # optimizer objects (sac_agent.py:339-355 / ppo_agent.py:351-371 store them whole)
+    'torch.optim.adam.Adam', 'torch.optim.adamw.AdamW', 'torch.optim.sgd.SGD', 'torch.optim.rmsprop.RMSprop',
+    # numpy arrays / scalars inside the StateNorm instance
+    'numpy.dtype', 'numpy.ndarray', 'numpy.core.multiarray._reconstruct', 'numpy.core.multiarray.scalar',
+    'numpy._core.multiarray._reconstruct', 'numpy._core.multiarray.scalar', 'numpy.core.numeric._frombuffer',
+    'numpy._core.numeric._frombuffer'}
 
 
 class _Unpickler(pickle.Unpickler):
@@ -53,7 +64,7 @@ class _Unpickler(pickle.Unpickler):
         if mod.split('.')[0] in ('model', 'configs', 'env', 'evaluation', 'train'):
             return type(name, (_Opaque,), {'__module__': mod})
         full = f'{mod}.{name}'.replace('__builtin__.', 'builtins.')       # protocol-2 pickles name the py2 module
-        if full in _ALLOWED or any(full.startswith(p) for p in _ALLOWED_PREFIX):
+        if full in _ALLOWED:
             return super().find_class(mod, name)
         raise pickle.UnpicklingError(f'hope_amd.checkpoint: refusing to load global {full!r} from a checkpoint')
 

@@ -542,6 +542,12 @@ int hope_debug_rs_prof(uint64_t* out, int reset) {
     return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_prof: ") + hipGetErrorString(e));
 }
 
+int hope_debug_rs_log(int32_t* out, int cap, int32_t* n, int reset) {
+    if (!out || !n || cap < 0) return fail(HOPE_EINVAL, "hope_debug_rs_log: bad argument");
+    hipError_t e = rs_log_read(out, cap, n, reset);
+    return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_log: ") + hipGetErrorString(e));
+}
+
 int hope_env_num_scenes(const hope_env_t* h) { return h ? h->n : HOPE_EINVAL; }
 int hope_env_max_obstacles(const hope_env_t* h) { return h ? h->max_obst : HOPE_EINVAL; }
 const char* hope_env_device_arch(const hope_env_t* h) { return h ? h->arch : ""; }

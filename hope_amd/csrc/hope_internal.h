@@ -77,6 +77,7 @@ struct LaunchTimer {
 // launches the Reeds-Shepp feasibility kernels over the scenes queued in rs_list (hope_rs.hip)
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);   // one tile class
 hipError_t rs_prof_read(unsigned long long* out /*[16]*/, int reset);   // HOPE_RS_TIMING cycle accounting
+hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset);   // HOPE_RS_TIMING per-search log
 size_t rs_lds_bytes(int max_obst);
 size_t rs_rec_bytes_per_scene();
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer);

@@ -248,6 +248,10 @@ __device__ __forceinline__ double wave_min_d(double v) {
 // [5] pose_hits: candidate loop [6] whole wave [8] waves [9] words tested [10] generator rounds [11] passes [12] passes with
 // candidates [13] candidate obstacles visited
 __device__ unsigned long long g_rs_prof[64 * 16];       // 64 shards (block index mod 64), summed by the host
+// per-search log of the instrumented build (tools/rs_tail.py): cycles, words tested, samples tested, found
+constexpr int RS_LOG_CAP = 1 << 21;
+__device__ int g_rs_log_n;
+__device__ int4 g_rs_log[RS_LOG_CAP];
 #define RS_T0() unsigned long long t0_ = TIMING ? __builtin_readcyclecounter() : 0
 #define RS_T(i) do { if (TIMING) { const unsigned long long t1_ = __builtin_readcyclecounter(); tsec[i] += t1_ - t0_; t0_ = t1_; } } while (0)
 
@@ -814,8 +818,11 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     if (TIMING) {
         tsec[6] = __builtin_readcyclecounter() - tstart_;
         tsec[8] = 1;
-        if (lane == 0)
+        if (lane == 0) {
             for (int i = 0; i < 16; i++) if (tsec[i]) atomicAdd(&g_rs_prof[(blockIdx.x & 63) * 16 + i], tsec[i]);
+            const int li = atomicAdd(&g_rs_log_n, 1);
+            if (li < RS_LOG_CAP) g_rs_log[li] = make_int4((int)tsec[6], (int)tsec[9] | (n_paths << 8) | ((p.tile_cap > 32) << 16), (int)tsec[11], found >= 0);
+        }
     }
     if (found < 0) return;
 
@@ -852,6 +859,17 @@ hipError_t rs_prof_read(unsigned long long* out, int reset) {
         for (auto& v : buf) v = 0;
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_rs_prof), buf, sizeof(buf));
     }
+    return e;
+}
+
+hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_rs_log_n), sizeof(int));
+    if (e != hipSuccess) return e;
+    const int m = *n < cap ? (*n < RS_LOG_CAP ? *n : RS_LOG_CAP) : cap;
+    if (m > 0) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_log), sizeof(int4) * (size_t)m);
+    if (e == hipSuccess && reset) { const int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_rs_log_n), &z, sizeof(int)); }
     return e;
 }
 

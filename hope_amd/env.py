@@ -29,7 +29,6 @@ from .rs_path import PATH, TYPE_NAMES
 NUM_STEP, STEP_LENGTH, LIDAR_NUM, LIDAR_RANGE, N_DISCRETE_ACTION = 10, 5e-2, 120, 10.0, 42
 VALID_SPEED, VALID_STEER = [-2.5, 2.5], [-0.75, 0.75]
 MAX_DIST_TO_DEST, TOLERANT_TIME = 20, 200
-REWARD_RATIO = 0.1
 REWARD_WEIGHT = OrderedDict({'time_cost': 1, 'rs_dist_reward': 0, 'dist_reward': 5, 'angle_reward': 0,
                              'box_union_reward': 10})
 
@@ -199,21 +198,43 @@ class CarParking:
         self._batch.set_scenes([0], [scene])
         return self.step()[0]
 
+    def _last_reset_obs(self, img_chw):
+        """the observation of the reset just done, in the wrapper's layout (buffers still hold it: no second launch)"""
+        b = self._batch
+        obs = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
+        if self.use_img_observation:
+            im = b.img[0] if img_chw else b.img[0].permute(1, 2, 0)
+            obs['img'] = im.cpu().numpy().astype(np.float64) / 255.0
+        if self.use_lidar_observation:
+            obs['lidar'] = b.lidar[0].cpu().numpy()
+        if self.use_action_mask:
+            obs['action_mask'] = b.action_mask[0].cpu().numpy()
+        obs['target'] = b.target[0].cpu().numpy()
+        return obs
+
     # -- the step ---------------------------------------------------------------------------------------
     def step(self, action=None):
         """action: physical (steer [rad], speed [m/s]) or None (the reset observation)."""
+        return self._step(action, physical=True)
+
+    def _step(self, action=None, physical=True, img_chw=False):
+        """physical=False: `action` is the wrapper's [-1, 1] action and the kernel applies action_rescale itself
+        (k_kinematics); img_chw=True: obs['img'] stays channel-first as k_bev_image writes it (what the wrapper returns)."""
         torch, b = self._torch, self._batch
         assert self.vehicle.state is not None
+        speed = steer = 0.0
         if action is not None:
-            a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 2), device=b.device)
-            b.step(a, stages=L.STAGE_ALL | L.ACTION_PHYSICAL)
+            act = np.asarray(action, dtype=np.float64).reshape(2)
+            a = torch.as_tensor(act.reshape(1, 2), device=b.device)
+            b.step(a, stages=L.STAGE_ALL | (L.ACTION_PHYSICAL if physical else 0))
+            if not physical:                                # State.steering / State.speed hold the physical values
+                act = np.clip(act, -1, 1) * np.array([VALID_STEER[1], VALID_SPEED[1]])
+            steer, speed = float(np.clip(act[0], *VALID_STEER)), float(np.clip(act[1], *VALID_SPEED))
         else:
             b.reset_obs()
         torch.cuda.synchronize(b.device)
         pose = b.pose[0].cpu().numpy()
         self.t += 1
-        speed = float(np.clip(action[1], *VALID_SPEED)) if action is not None else 0
-        steer = float(np.clip(action[0], *VALID_STEER)) if action is not None else 0
         prev = self.vehicle.state.get_pos()
         self.vehicle.state = State([pose[0], pose[1], pose[2], speed, steer])
         self.vehicle.box = self.vehicle.state.create_box()
@@ -224,7 +245,8 @@ class CarParking:
             self.vehicle.trajectory.append(self.vehicle.state)
         observation = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
         if self.use_img_observation:                       # processed_img / 255.0, (W, H, C)  observation_processor.py:14
-            observation['img'] = b.img[0].permute(1, 2, 0).cpu().numpy().astype(np.float64) / 255.0
+            im = b.img[0] if img_chw else b.img[0].permute(1, 2, 0)
+            observation['img'] = im.cpu().numpy().astype(np.float64) / 255.0
         if self.use_lidar_observation:
             observation['lidar'] = b.lidar[0].cpu().numpy()
         if self.use_action_mask:
@@ -239,6 +261,8 @@ class CarParking:
             n = int(w[5])
             info['path_to_dest'] = PATH(b.rs_lengths[0, :n].cpu().numpy(), [TYPE_NAMES[int(c)] for c in w[:n]],
                                         self.vehicle.state.get_pos())
+        # what the wrapper adds on top (env_wrapper.py:10-35,80) leaves the kernels ready-made: k_post's shaped reward and done
+        self._wrapped = (float(b.reward[0].item()), bool(b.done[0].item()))
         return observation, reward_info, status, info
 
     def render(self, mode='human'):
@@ -251,42 +275,15 @@ class CarParking:
 
 
 # ---- env_wrapper.py ----------------------------------------------------------------------------------
-def reward_shaping(*args):                                # env_wrapper.py:10-35
-    obs, reward_info, status, info = args
-    if status == Status.CONTINUE:
-        reward = 0
-        for k in REWARD_WEIGHT.keys():
-            reward += REWARD_WEIGHT[k] * reward_info[k]
-    elif status == Status.OUTBOUND:
-        reward = -50
-    elif status == Status.OUTTIME:
-        reward = -1
-    elif status == Status.ARRIVED:
-        reward = 50
-    elif status == Status.COLLIDED:
-        reward = -50
-    reward *= REWARD_RATIO
-    info['status'] = status
-    return obs, reward, status, info
+class CarParkingWrapper:
+    """CarParkingWrapper (env_wrapper.py:58-85; gym.Wrapper attribute pass-through).  Its three functions are NOT re-derived
+    on the host: handed the wrapper's [-1, 1] action the step kernels apply `action_rescale` themselves (k_kinematics;
+    env_wrapper.py:37-50), k_post emits the shaped reward of `reward_shaping` (:10-35) and `done` (:80), and the image
+    leaves k_bev_image channel-first, which is `observation_rescale`'s transpose (:52-55).  A caller that passes its own
+    `action_func(action, action_space)` / `reward_func(obs, reward_info, status, info)` / `observation_func(obs)` gets
+    them applied on the host instead (the reference's constructor signature)."""
 
-
-def action_rescale(action, action_space, raw_action_range=(-1, 1), explore=True, epsilon=0.0):   # :37-50
-    action = np.clip(action, *raw_action_range)
-    action = action * (action_space.high - action_space.low) / 2 + (action_space.high + action_space.low) / 2
-    if explore and np.random.random() < epsilon:
-        action = action_space.sample()
-    return action
-
-
-def observation_rescale(obs):                             # :52-55
-    if obs['img'] is not None:
-        obs['img'] = obs['img'].transpose((2, 0, 1))
-    return obs
-
-
-class CarParkingWrapper:                                  # :58-85 (gym.Wrapper attribute pass-through)
-    def __init__(self, env, action_func=action_rescale, reward_func=reward_shaping,
-                 observation_func=observation_rescale):
+    def __init__(self, env, action_func=None, reward_func=None, observation_func=None):
         self.env = env
         self.reward_func, self.action_func, self.obs_func = reward_func, action_func, observation_func
         self.observation_shape = {k: env.observation_space[k].shape for k in env.observation_space}
@@ -299,15 +296,26 @@ class CarParkingWrapper:                                  # :58-85 (gym.Wrapper 
             raise AttributeError(name)
         return getattr(self.env, name)
 
+    def _obs(self, obs):
+        return obs if self.obs_func is None else self.obs_func(obs)
+
     def step(self, action=None):
-        if action is None:
-            return self.obs_func(self.env.step()[0])
-        action = self.action_func(action, self.env.action_space)
-        returns = self.env.step(action)
-        obs, reward, status, info = self.reward_func(*returns)
-        obs = self.obs_func(obs)
-        done = False if status == Status.CONTINUE else True
-        return obs, reward, done, info
+        chw = self.obs_func is None
+        if action is None:                                 # env_wrapper.py:74-75
+            return self._obs(self.env._step(None, img_chw=chw)[0])
+        if self.action_func is None:
+            np.random.random()                             # the reference's rescale draws from the global RNG every call (:48)
+            obs, reward_info, status, info = self.env._step(action, physical=False, img_chw=chw)
+        else:
+            obs, reward_info, status, info = self.env._step(self.action_func(action, self.env.action_space), img_chw=chw)
+        if self.reward_func is None:
+            reward, done = self.env._wrapped
+            info['status'] = status
+        else:
+            obs, reward, status, info = self.reward_func(obs, reward_info, status, info)
+            done = status != Status.CONTINUE
+        return self._obs(obs), reward, done, info
 
     def reset(self, *args):
-        return self.obs_func(self.env.reset(*args))
+        self.env.reset(*args)                              # (its own observation is rebuilt below in the wrapper's layout)
+        return self._obs(self.env._last_reset_obs(self.obs_func is None))

@@ -234,6 +234,9 @@ int hope_debug_math(int fn, int n, const double *a, const double *b, double *out
  * launches when the environment variable HOPE_RS_TIMING is set (hope_amd/csrc/hope_rs.hip lists the sections); zeros
  * otherwise.  Host-synchronous.  tools/rs_timing.py prints the breakdown. */
 int hope_debug_rs_prof(uint64_t *out /*[16]*/, int reset);
+/* Per-search log of the same instrumented build: up to cap records of 4 int32 {wave cycles, words tested | words allowed << 8 |
+ * large-tile class << 16, passes, found}; *n = records logged since the last reset.  Host-synchronous.  tools/rs_tail.py. */
+int hope_debug_rs_log(int32_t *out /*[cap][4]*/, int cap, int32_t *n, int reset);
 /* the same for k_env_step (environment variable HOPE_STEP_TIMING; float32 observation / action handles); tools/step_timing.py */
 int hope_debug_step_prof(uint64_t *out /*[16]*/, int reset);
 

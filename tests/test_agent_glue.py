@@ -1,6 +1,7 @@
 """Batched agent glue against reference-generated vectors (tests/golden/agent_glue.npz:
 RsPlanner.set_rs_path, ActionMask.choose_action's probability vector, StateNorm)."""
 import numpy as np
+import pytest
 import torch
 
 from hope_amd import agent_glue as G
@@ -169,3 +170,19 @@ def test_checkpoint_loader_refuses_foreign_globals(tmp_path):
     torch.save({'actor_net': {'weight': torch.zeros(2)}, 'configs': Evil()}, str(path))
     with pytest.raises(pickle.UnpicklingError, match='refusing'):
         load_hope_checkpoint(str(path))
+
+
+@pytest.mark.parametrize('glob', ['torch._utils._import_dotted_name', 'torch.storage._load_from_bytes', 'torch._utils.importlib',
+                                  'torch.optim.lr_scheduler.LambdaLR', 'numpy.core.multiarray.fromfile'])
+def test_checkpoint_loader_has_no_module_wide_allowances(glob):
+    """the allow-list is a set of names.  A pickle that names a callable living in an otherwise trusted module
+    (torch._utils._import_dotted_name returns ANY importable callable; torch.storage._load_from_bytes is an unrestricted
+    torch.load) must be refused before anything is imported or called."""
+    import io
+    import pickle
+    from hope_amd.checkpoint import _Unpickler
+    mod, name = glob.rsplit('.', 1)
+    # GLOBAL mod name ; MARK ; STRING 'os.getcwd' ; TUPLE ; REDUCE ; STOP  -- hand-built, nothing imported on this side
+    blob = b'c' + mod.encode() + b'\n' + name.encode() + b"\n(S'os.getcwd'\ntR."
+    with pytest.raises(pickle.UnpicklingError, match='refusing'):
+        _Unpickler(io.BytesIO(blob)).load()

@@ -277,3 +277,12 @@ def test_ppo_trainer_two_ranks_stay_in_sync():
     [p.join(60) for p in ps]
     assert res[0][3] == res[1][3] == 1
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_advantage_normalisation_survives_a_single_transition():
+    """N*T == 1 must not turn the advantages into NaN (unbiased std of one element)."""
+    from hope_amd.agents import _global_mean_std
+    m, s = _global_mean_std(torch.tensor([0.25]))
+    assert torch.isfinite(m) and torch.isfinite(s) and float(s) == 0.0 and float(m) == 0.25
+    m, s = _global_mean_std(torch.tensor([1.0, 3.0]))
+    assert abs(float(m) - 2.0) < 1e-7 and abs(float(s) - torch.tensor([1.0, 3.0]).std().item()) < 1e-7

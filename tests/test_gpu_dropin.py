@@ -185,3 +185,50 @@ def test_batched_rollout_loop_runs_and_parks():
     print('rollout:', st)
     assert st['episodes'] > 100 and st['success_rate'] > 0.02
     env.close()
+
+
+def test_wrapper_with_caller_supplied_functions_equals_the_fused_default():
+    """CarParkingWrapper(env, action_func, reward_func, observation_func) (env_wrapper.py:59-66): the default (None) takes
+    action_rescale / reward_shaping / the image transpose from the kernels; caller-supplied functions run on the host.  The
+    reference's own three functions, restated here as the caller's, must give the same (obs, reward, done, info)."""
+    from hope_amd.env import CarParking, CarParkingWrapper, Status
+    from hope_amd.scenes import DlpScenePool
+    weight = dict(time_cost=1, rs_dist_reward=0, dist_reward=5, angle_reward=0, box_union_reward=10)
+    terminal = {Status.OUTBOUND: -50, Status.OUTTIME: -1, Status.ARRIVED: 50, Status.COLLIDED: -50}
+
+    def act_f(a, space):
+        a = np.clip(a, -1, 1)
+        return a * (space.high - space.low) / 2 + (space.high + space.low) / 2
+
+    def rew_f(obs, ri, status, info):
+        r = sum(weight[k] * ri[k] for k in weight) if status == Status.CONTINUE else terminal[status]
+        info['status'] = status
+        return obs, r * 0.1, status, info
+
+    def obs_f(obs):
+        if obs['img'] is not None:
+            obs['img'] = obs['img'].transpose((2, 0, 1))
+        return obs
+    pool = DlpScenePool()
+    rng = np.random.default_rng(5)
+    a, b = CarParking(verbose=False), CarParking(verbose=False)
+    wa, wb = CarParkingWrapper(a), CarParkingWrapper(b, act_f, rew_f, obs_f)
+    ended = 0
+    for ep in range(3):
+        scene = pool.sample(rng=rng)
+        a.reset_to_scene(scene); b.reset_to_scene(scene)
+        oa, ob = wa.step(), wb.step()
+        for k in oa:
+            assert np.array_equal(oa[k], ob[k]), k
+        for it in range(40):
+            act = rng.uniform(-1.2, 1.2, 2)
+            ra, rb = wa.step(act), wb.step(act)
+            for k in ra[0]:
+                assert np.array_equal(ra[0][k], rb[0][k]), k
+            assert ra[0]['img'].shape == (3, 64, 64)
+            assert abs(ra[1] - rb[1]) <= 1e-15 and ra[2] == rb[2] and ra[3]['status'] == rb[3]['status']
+            if ra[2]:
+                ended += 1
+                break
+    print('episodes ended:', ended)
+    wa.close(); wb.close()

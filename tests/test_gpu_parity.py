@@ -223,7 +223,7 @@ def test_step_parity_f32_outputs():
 def test_motion_only_config2():
     """BASELINE config 2: kinematics + OBB collision only (4096 mixed scenes), flags bit-exact."""
     from hope_amd import _lib as L
-    env, orc, rng = make_pair(4096, seed=13)
+    env, orc, rng = make_pair(4096, seed=13, level='mixed')       # mixed difficulty, as BASELINE config 2 says
     stages = L.STAGE_MOTION | L.STAGE_REWARD
     stats = new_stats()
     for it in range(6):
@@ -745,3 +745,48 @@ def test_fused_new_map_turnover_equals_step_plus_turnover():
             a.close(); b.close()
         finally:
             os.environ.pop('HOPE_SPLIT_MIN', None)
+
+
+def test_headline_configuration_has_an_oracle_witness_65536_scenes():
+    """the configuration bench.py times -- 65 536 scenes, float32 observations and actions, the step
+    kernel in two launches per tile class on concurrent streams, HOPE_AUTO_RESET | HOPE_AUTO_REDRAW from a device pool --
+    compared with the oracle DIRECTLY, through bench.py's own witness (parity_witness: 1 024 random slots rebuilt in the
+    oracle from the device state, one fused step, turnovers followed onto the drawn map), over 32 steps so that episodes end."""
+    import bench
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scenes import SceneSource, pack_scenes
+    n, mo, P, U = 65536, 128, 2048, 1024
+    src = SceneSource(seed=61)
+    uniq = [src.draw() for _ in range(U)]
+    pool = [src.draw() for _ in range(P)]
+    init = pack_scenes(uniq, mo)
+    pool_packed = pack_scenes(pool, mo)
+    env = ParkingBatch(n, mo, obs_dtype=torch.float32, action_dtype=torch.float32)
+    assert env.overlap                                            # the default launch form: two chains, split step kernel
+    reps = n // U
+    for a in range(0, n, 8192):
+        sl = np.arange(a, a + 8192) % U
+        env.set_scene_arrays(np.arange(a, a + 8192), init[0][sl], init[1][sl], init[2][sl], init[3][sl], init[4][sl])
+    env.set_pool(pool_packed)
+    env.set_redraw_seed(99)
+    env.reset_obs()
+    rng = np.random.default_rng(62)
+    env.upload_state(t=rng.integers(1, 201, n))                  # a steady-state age mix: OUTTIME fires during the test
+    g = torch.Generator(device=env.device).manual_seed(63)
+    tot = dict(turnovers=0, status_mismatch=0, done_mismatch=0, mask_mismatch=0, rs_mismatch=0, state_mismatch=0,
+               f32_value_mismatch=0, rs_found=0)
+    worst = 0.0
+    for it in range(32):
+        act = torch.rand((n, 2), device=env.device, generator=g) * 2 - 1
+        if it % 4 == 3:                                           # plain steps in between, so that states drift apart
+            env.step(act, auto_reset=True, fresh=True)
+            continue
+        r = bench.parity_witness(env, L.STAGE_ALL, True, init, U, pool_packed, act, 1024, seed=1000 + it)
+        for k in tot:
+            tot[k] += r[k]
+        worst = max(worst, r['max_abs_err'])
+    print('headline witness:', tot, 'max_abs_err', worst)
+    assert tot['turnovers'] > 100 and tot['rs_found'] > 50
+    assert all(tot[k] == 0 for k in ('status_mismatch', 'done_mismatch', 'mask_mismatch', 'rs_mismatch', 'state_mismatch', 'f32_value_mismatch'))
+    assert worst < TOL32
+    env.close()

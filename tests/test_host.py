@@ -125,18 +125,17 @@ def test_normal_generator_scenes_are_valid():
         assert rings_intersect(a, b) == O.ring_intersects(a, b)
 
 
-def test_wrapper_functions_match_reference_vectors(gold):
+def test_wrapper_surface_is_built_on_kernel_outputs():
+    """The wrapper's reward_shaping / action_rescale are not re-derived on the host: the arithmetic lives in
+    the kernels (pinned to the reference's vectors through the oracle, tests/test_oracle_golden.py, and to the oracle
+    on the GPU, tests/test_gpu_dropin.py); the module keeps the reference's class surface and the Status values."""
+    import inspect
     from hope_amd import env as E
-    g = gold('wrapper_reward.npz')
-    space = E.Box(np.array([-0.75, -2.5]), np.array([0.75, 2.5]))
-    for i in range(len(g['act_in'])):
-        assert np.abs(E.action_rescale(g['act_in'][i].copy(), space) - g['act_rescaled'][i]).max() < 2e-7
-    keys = list(E.REWARD_WEIGHT.keys())
-    for i in range(len(g['reward_info'])):
-        ri = dict(zip(keys, map(float, g['reward_info'][i])))
-        for j, st in enumerate([E.Status.CONTINUE, E.Status.ARRIVED, E.Status.COLLIDED, E.Status.OUTBOUND, E.Status.OUTTIME]):
-            assert abs(E.reward_shaping(None, ri, st, {})[1] - g['shaped'][i, j]) < 1e-15
     assert [s.value for s in E.Status] == [1, 2, 3, 4, 5]
+    assert not hasattr(E, 'reward_shaping') and not hasattr(E, 'action_rescale')
+    sig = inspect.signature(E.CarParkingWrapper.__init__)
+    assert list(sig.parameters)[1:] == ['env', 'action_func', 'reward_func', 'observation_func']     # env_wrapper.py:59-60
+    assert list(E.REWARD_WEIGHT.keys()) == ['time_cost', 'rs_dist_reward', 'dist_reward', 'angle_reward', 'box_union_reward']
 
 
 def test_rs_path_sampler_matches_reference_vectors(gold):
