@@ -19,7 +19,7 @@ ABI_VERSION = 4
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',
            'hope_env_set_scenes', 'hope_env_step', 'hope_env_reset_obs', 'hope_env_download_state',
-           'hope_env_upload_state', 'hope_env_restart', 'hope_env_set_pool', 'hope_env_redraw', 'hope_env_set_redraw_seed', 'hope_env_download_pool_index', 'hope_env_kernel_ms', 'hope_env_kernel_union_ms', 'hope_env_profile_kernels', 'hope_debug_math', 'hope_debug_rs_prof', 'hope_debug_rs_log', 'hope_debug_step_prof', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
+           'hope_env_upload_state', 'hope_env_restart', 'hope_env_set_pool', 'hope_env_redraw', 'hope_env_set_redraw_seed', 'hope_env_download_pool_index', 'hope_env_kernel_ms', 'hope_env_kernel_union_ms', 'hope_env_profile_kernels', 'hope_debug_math', 'hope_debug_rs_prof', 'hope_debug_rs_log', 'hope_debug_rs_filter_stats', 'hope_debug_rs_filter_dump', 'hope_debug_step_prof', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
 
 
 class HopeError(RuntimeError):

@@ -542,6 +542,18 @@ int hope_debug_rs_prof(uint64_t* out, int reset) {
     return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_prof: ") + hipGetErrorString(e));
 }
 
+int hope_debug_rs_filter_stats(uint64_t* out, int reset) {
+    if (!out) return fail(HOPE_EINVAL, "hope_debug_rs_filter_stats: null argument");
+    hipError_t e = rs_fstat_read((unsigned long long*)out, reset);
+    return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_filter_stats: ") + hipGetErrorString(e));
+}
+
+int hope_debug_rs_filter_dump(double* out) {
+    if (!out) return fail(HOPE_EINVAL, "hope_debug_rs_filter_dump: null argument");
+    hipError_t e = rs_fdump_read(out);
+    return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_filter_dump: ") + hipGetErrorString(e));
+}
+
 int hope_debug_rs_log(int32_t* out, int cap, int32_t* n, int reset) {
     if (!out || !n || cap < 0) return fail(HOPE_EINVAL, "hope_debug_rs_log: bad argument");
     hipError_t e = rs_log_read(out, cap, n, reset);
@@ -664,6 +676,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     int n_chain = 0, n_streams = 1;
     const int subs = overlap ? h->sub_chains : 1;
     static const int balance = getenv("HOPE_BALANCE") ? atoi(getenv("HOPE_BALANCE")) : 100;
+    // experiment: 1 = the chain of the class with more scenes is enqueued first; 2 = and the other chain starts only when the
+    // first chain's motion launch is done (its kinematics / motion kernels then do not share the GPU with the critical ones)
+    const int order_mode = getenv("HOPE_ORDER") ? atoi(getenv("HOPE_ORDER")) : 0;
     if (overlap && subs == 1 && n_cls == 2 && balance < 100 && h->cls_count[0] > 0 && h->cls_count[1] > 0) {
         // two streams, three chains: the large-tile class, then the tail of the small-tile class behind it on the side stream,
         // the head of the small-tile class on the caller's stream -- so that both streams finish together
@@ -673,11 +688,15 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (cut < h->cls_count[0]) chains[n_chain++] = {0, cut, h->cls_count[0], 1};
         n_streams = 2;
     } else {
-        for (int c = n_cls - 1; c >= 0; c--)
+        // the class with more scenes first: its chain is the step's critical path (HOPE_ORDER=0: the large-tile class first)
+        const bool big_first = n_cls == 2 && order_mode > 0 && h->cls_count[0] > h->cls_count[1];
+        for (int cc = n_cls - 1; cc >= 0; cc--) {
+            const int c = big_first ? (n_cls - 1 - cc) : cc;
             for (int j = 0; j < subs; j++) {
                 const int a = (int)((long long)h->cls_count[c] * j / subs), b = (int)((long long)h->cls_count[c] * (j + 1) / subs);
                 if (b > a) { chains[n_chain] = {c, a, b, overlap ? n_chain : 0}; n_chain++; }
             }
+        }
         n_streams = overlap ? n_chain : 1;
     }
     const bool fork = overlap && n_streams > 1;
@@ -701,6 +720,8 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         p.n_list = ch.b - ch.a;
         p.rs_flag = h->rs_flag;
         p.rs_count_zero = want_rs ? counter : nullptr;
+        if (order_mode >= 2 && fork && n_chain == 2 && i == 1 && (split || (stages & HOPE_STAGE_IMG)))
+            HIPCHK(hipStreamWaitEvent(sc, h->ev_step[0], 0));   // staggered: behind the first chain's motion launch
         if ((stages & HOPE_STAGE_MOTION) && has_action) {       // this class's sub-step poses head its chain
             dim3 kg((p.n_list + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
             if (tm) tm->begin(HOPE_K_KINEMATICS, sc);

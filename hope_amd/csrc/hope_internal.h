@@ -21,15 +21,17 @@ constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generat
 //   [10..15] the pop order: candidate slot (4 * family + reflection) of the k-th popped word, one byte each  -- k_rs_segs
 //   [16 + c]  key of candidate slot c: path.L / maxc when set_path kept the word, -1 otherwise               -- k_rs_words
 //   [64 + 8 c ..] the word of candidate slot c (RsWord)                                                       -- k_rs_words
-//   [448 + 40 k ..] segment table of the k-th popped word (k < words to test), written by k_rs_segs: 5 segments x 8 doubles
+//   [448 + 50 k ..] segment table of the k-th popped word (k < words to test), written by k_rs_segs: 5 segments x 8 doubles
 //       (origin x, y, heading, cos, sin of the heading, type, length, [seg 0 only] int2 (type code, segment count));
-//       table 0 also carries cos / sin(-pose heading) in the spare words [15], [23]
+//       table 0 also carries cos / sin(-pose heading) in the spare words [15], [23];
+//       then 5 x 2 doubles = 5 x 4 floats for the float32 filter of k_rs_validate: per segment the origin in the frame
+//       "world minus the search's start position" [m] and cos / sin of the WORLD heading at the origin
 constexpr int RS_REC_HDR = 16;
 constexpr int RS_REC_ORDER = 10;
 constexpr int RS_REC_KEYS = RS_REC_HDR;
 constexpr int RS_REC_WORDS = RS_REC_KEYS + RS_WORDS_PER_SCENE;
 constexpr int RS_REC_SEGS = RS_REC_WORDS + 8 * RS_WORDS_PER_SCENE;
-constexpr int RS_SEGW = 8, RS_SEG_TABLE = 5 * RS_SEGW;
+constexpr int RS_SEGW = 8, RS_SEG_F32 = 5 * RS_SEGW, RS_SEG_TABLE = RS_SEG_F32 + 5 * 2;
 constexpr int RS_REC_DOUBLES = RS_REC_SEGS + RS_SEG_TABLE * RS_WORDS_PER_SCENE;
 
 struct RsParams {
@@ -77,6 +79,8 @@ struct LaunchTimer {
 // launches the Reeds-Shepp feasibility kernels over the scenes queued in rs_list (hope_rs.hip)
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);   // one tile class
 hipError_t rs_prof_read(unsigned long long* out /*[16]*/, int reset);   // HOPE_RS_TIMING cycle accounting
+hipError_t rs_fstat_read(unsigned long long* out /*[16]*/, int reset);    // float32-filter statistics (HOPE_RS_DEBUG & 0x4000)
+hipError_t rs_fdump_read(double* out /*[64][16]*/);
 hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset);   // HOPE_RS_TIMING per-search log
 size_t rs_lds_bytes(int max_obst);
 size_t rs_rec_bytes_per_scene();

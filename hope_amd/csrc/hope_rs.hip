@@ -260,7 +260,7 @@ __device__ int4 g_rs_log[RS_LOG_CAP];
 // Obstacles are culled per call: the union box of the active lanes' hulls is wave-reduced, one lane per
 // obstacle compares its precomputed box (obb, in LDS) with it, and only the survivors (cand[], usually 0-3)
 // are visited.  A pair whose boxes do not overlap cannot pass the reference's box tests, so this is exact.
-template <bool TIMING>
+template <bool TIMING, bool FULL = false>
 __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, double wyaw, const double* tile,
                                           const float4* obb, int* cand, int n_obst, double xmin, double xmax,
                                           double ymin, double ymax, int lane, unsigned long long* tsec) {
@@ -282,7 +282,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         hminy = fmin(fmin(vy[0], vy[1]), fmin(vy[2], vy[3]));
         hmaxy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
     }
-    if (__any(bad)) return bad;
+    if (!FULL && __any(bad)) return bad;
     // union box of the pass: float, rounded outwards (only used to cull whole obstacles, so a superset is exact)
     float ulox = active ? __double2float_rd(hminx) : INFINITY, uhix = active ? __double2float_ru(hmaxx) : -INFINITY;
     float uloy = active ? __double2float_rd(hminy) : INFINITY, uhiy = active ? __double2float_ru(hmaxy) : -INFINITY;
@@ -300,7 +300,7 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
         nc += __popcll(m);
     }
     RS_T(4);
-    if (nc == 0) return false;
+    if (nc == 0) return bad;                              // (bad: only with FULL, which does not leave early)
     if (TIMING) { tsec[12] += 1; tsec[13] += nc; }
     wsync();
     for (int ci = 0; ci < nc; ci++) {
@@ -332,12 +332,12 @@ __device__ __forceinline__ bool pose_hits(bool active, double wx, double wy, dou
                     bool cy = !(raw_y > eymax) && !(raw_y < eymin) && !(raw_y > vmaxy) && !(raw_y < vminy);
                     if (cx && cy) bad = true;
                 }
-                if (__any(bad)) break;                        // (the lanes that are near this obstacle)
+                if (!FULL && __any(bad)) break;               // (the lanes that are near this obstacle)
             }
         }
         // one colliding sample condemns the path: the remaining candidates need not be looked at (the first-segment cache
         // may then learn a farther colliding sample than the nearest one -- still a true collision, only less pruning)
-        if (__any(bad)) break;
+        if (!FULL && __any(bad)) break;
     }
     wsync();
     RS_T(5);
@@ -583,6 +583,8 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     const int n_test = ntl[ls];
     const unsigned char* order = ordl[ls];
     const double q0w = st[2];
+    double sq0, cq0;                                      // world heading of the start pose: rotation local course -> world
+    hm_sincos(q0w, &sq0, &cq0);
     for (int k = k0; k < n_test; k += 8) {
         const double* W = rec + RS_REC_WORDS + 8 * (int)order[k];
         double len[5];
@@ -602,6 +604,13 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
                 double* sp_ = tb + RS_SEGW * i;
                 sp_[0] = ox; sp_[1] = oy; sp_[2] = hy; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = (double)m; sp_[6] = l;
                 if (i == 0) sp_[7] = w6;
+                {   // float32 filter row: origin rotated into the world axes (still relative to the start position), and the
+                    // world heading at the origin by angle addition (only ever used with error margins)
+                    const float fox = (float)(cq0 * ox - sq0 * oy), foy = (float)(sq0 * ox + cq0 * oy);
+                    const float fc = (float)(c_oy * cq0 - s_oy * sq0), fs = (float)(s_oy * cq0 + c_oy * sq0);
+                    tb[RS_SEG_F32 + 2 * i] = __hiloint2double(__float_as_int(foy), __float_as_int(fox));
+                    tb[RS_SEG_F32 + 2 * i + 1] = __hiloint2double(__float_as_int(fs), __float_as_int(fc));
+                }
                 if (m == TS) {                                   // interpolate(l) = next origin (:512-513)
                     ox = ox + l / MAXC * c_oy;
                     oy = oy + l / MAXC * s_oy;
@@ -617,8 +626,8 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
             }
         }
         if (k == 0) {                                    // calc_all_paths' rotation by -q0 yaw (:47-49), once per search:
-            tb[RS_SEGW + 7] = hm_cos(-q0w);              // spare words of table 0
-            tb[2 * RS_SEGW + 7] = hm_sin(-q0w);
+            tb[RS_SEGW + 7] = cq0;                       // hm_cos(-q0w): spare words of table 0 (hm_sincos is exactly even / odd)
+            tb[2 * RS_SEGW + 7] = -sq0;                  // hm_sin(-q0w)
         }
     }
 }
@@ -842,11 +851,535 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
     if (lane == 6) p.rs_word[8 * (size_t)scene + 6] = 1;
 }
 
+
+// ================================================================================================
+// Kernel B': the same search with a float32 FILTER in front of the float64 arithmetic
+// ================================================================================================
+// k_rs_validate above evaluates every sample's pose, hull and edge tests in float64 (two hm_sincos per sample, ~250 float64
+// instructions per candidate obstacle).  Almost every pass either contains samples that are DEEP inside an obstacle or is
+// clear by centimetres, so this kernel decides those in float32 with explicit error margins and runs the reference
+// arithmetic (exact_pass: the float64 code of the kernel above, unchanged) only for samples it cannot decide:
+//   * frame: world axes, origin at the search's start position (coordinates stay below ~100 m: float32 ulp <= 8e-6 m);
+//     obstacle vertices are converted once per search, the sample poses come from k_rs_segs' float32 segment rows;
+//   * per sample and candidate obstacle the four vertices are taken into the CAR frame, where the hull is the axis-aligned
+//     rectangle |u| <= HL, |w| <= HW, and every obstacle edge is classified against it with margin FEPS:
+//       clear    separated from the rectangle inflated by FEPS on one of the three SAT axes of (segment, rectangle), or
+//                both end points inside the rectangle deflated by FEPS (edge inside the hull: boundaries do not meet);
+//       hit      meets the deflated rectangle with an end point outside the inflated one (it crosses the hull boundary),
+//                AND the crossing is robust for the reference's tolerance-free test (:518-526, the intersection of the two
+//                LINES must lie inside both edges' coordinate boxes): no hull corner within FEPS of the edge's line, the
+//                edge not within FKAPPA (sine) of parallel to a hull side its line crosses, neither edge axis-parallel in
+//                the world frame (a degenerate coordinate box is met only by bit-equality) -- then the exact intersection
+//                point lies >= 1e-7 m inside both boxes, eight orders above the rounding of raw_x / raw_y;
+//       else     undecided.
+//   * float32 error budget (FEPS = 1e-3 m is ~8x the bound): pd -> float 5e-7 (x 3 m/unit), native sin / cos 4e-6 (x 3 m,
+//     and x 3.9 m lever arm on the heading), ~10 roundings of <= 100 m quantities at 6e-6 each: <= 1.2e-4 m in total.
+// A pass with a `hit` sample condemns the word at once; a pass with undecided samples and no hit re-evaluates just those
+// samples in float64; a pass whose samples are all clear is clear.  Identical results to k_rs_validate by construction
+// (the tests run both kernels on the same queues: tests/test_gpu_parity.py); HOPE_RS_EXACT=1 selects the kernel above.
+constexpr float FEPS = 1e-3f, FKAPPA = 2e-2f, FETA_EDGE = 1e-2f, FETA_HULL = 2e-3f;
+constexpr float F_INV_MAXC = (float)(1.0 / MAXC);
+constexpr float F_HL = (float)(0.5 * (CAR_XF - CAR_XR)), F_HW = (float)CAR_YH, F_MID = (float)(0.5 * (CAR_XF + CAR_XR));
+constexpr int RS_TAB = 256;
+constexpr int RSF_OCC = 4;                 // waves per SIMD the register allocation of k_rs_validate_f aims at
+__device__ double g_rs_steps[RS_TAB];     // first-segment samples: T[k] = step added k + 1 times in sequence (every word's
+                                          // first segment starts with pd = d and walks pd += d: the same chain for all)
+__device__ unsigned long long g_rs_fstat[16];
+__device__ double g_rs_fdump[64 * 16];    // self-check: details of the first 64 contradicted verdicts   // [0] passes [1] passes decided by a float32 hit [2] passes that ran exact_pass
+                                               // [3] undecided samples [4] float32 "hit" that exact says clear (must stay 0)
+                                               // [5] float32 "clear" that exact says hit (must stay 0) [6] samples checked
+                                               // [8..12] passes with an undecided edge because: not a certain crossing / axis-parallel
+                                               // obstacle edge / axis-parallel hull / hull corner near the line / shallow angle
+
+// the float64 evaluation of the queued samples `idx` (one per lane, -1: none): interpolate (:510-537), calc_all_paths'
+// rotation (:47-49) and is_traj_valid's tests -- exactly the per-pass body of k_rs_validate.  Rare: out of line, reads the
+// obstacle tile and boxes from global memory.
+template <bool FULL>
+__device__ __noinline__ bool exact_pass(int idx, const double* segp, const double* qpd, const unsigned char* qseg, double c_q,
+                                        double s_q, double q0x, double q0y, double q0w, const double* verts_g,
+                                        const float4* obb_g, int* cand, int n_obst, double xmin, double xmax, double ymin,
+                                        double ymax, int lane) {
+    const bool active = idx >= 0;
+    double px = 0, py = 0, pyaw = 0;
+    if (active) {
+        const double spd = qpd[idx];
+        const double* sp_ = segp + RSB_SEGW * (int)qseg[idx];
+        const int m = (int)sp_[5];
+        interpolate(spd, m, sp_[0], sp_[1], sp_[2], sp_[3], -sp_[4], sp_[3], sp_[4], px, py, pyaw);
+    }
+    const double wx = c_q * px + s_q * py + q0x;
+    const double wy = -s_q * px + c_q * py + q0y;
+    const double wyaw = pi_2_pi(pyaw + q0w);
+    unsigned long long tsec[16];
+    return pose_hits<false, FULL>(active, wx, wy, wyaw, verts_g, obb_g, cand, n_obst, xmin, xmax, ymin, ymax, lane, tsec);
+}
+
+// The reference arithmetic for the samples the float32 filter left undecided, and only for the edges it left open (ua / ub:
+// obstacle | edge mask << 8): every other edge of these samples is certainly clear.  Same expressions as pose_hits.  Out of
+// line: it runs in a few per cent of the passes and must not cost the common path registers.
+__device__ __noinline__ bool exact_edges(bool unc, int sidx, int ua, int ub, const double* segp, const double* qpd,
+                                         const unsigned char* qseg, const double* tile64, double c_q, double s_q, double q0x,
+                                         double q0y, double q0w, double xmin, double xmax, double ymin, double ymax) {
+    bool bad = false;
+    // The reference arithmetic, for the undecided samples and only for the edges the filter left open: every
+    // other edge of these samples is certainly clear.  Same expressions as pose_hits (k_rs_validate's).
+    if (unc) {
+        double px = 0, py = 0, pyaw = 0;
+        {
+            const double spd = qpd[sidx];
+            const double* sp_ = segp + RSB_SEGW * (int)qseg[sidx];
+            interpolate(spd, (int)sp_[5], sp_[0], sp_[1], sp_[2], sp_[3], -sp_[4], sp_[3], sp_[4], px, py, pyaw);
+        }
+        const double wx = c_q * px + s_q * py + q0x;
+        const double wy = -s_q * px + c_q * py + q0y;
+        const double wyaw = pi_2_pi(pyaw + q0w);
+        bad = wx < xmin || wx > xmax || wy < ymin || wy > ymax;             // :462-464
+        double st_, ct_;
+        hm_sincos(wyaw, &st_, &ct_);
+        double vx[4], vy[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            vx[k] = ct_ * car_x(k) - st_ * car_y(k) + wx;                   // :468-471
+            vy[k] = st_ * car_x(k) + ct_ * car_y(k) + wy;
+        }
+        const double hminx = fmin(fmin(vx[0], vx[1]), fmin(vx[2], vx[3])), hmaxx = fmax(fmax(vx[0], vx[1]), fmax(vx[2], vx[3]));
+        const double hminy = fmin(fmin(vy[0], vy[1]), fmin(vy[2], vy[3])), hmaxy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
+#pragma unroll 1
+        for (int slot = 0; slot < 2; slot++) {
+            const int rec_ = slot ? ub : ua;
+            if (rec_ < 0) continue;
+            const double* o = tile64 + 8 * (rec_ & 0xff);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                if (!((rec_ >> (8 + j)) & 1)) continue;
+                const double x1 = o[2 * j], y1 = o[2 * j + 1], x2 = o[2 * ((j + 1) & 3)], y2 = o[2 * ((j + 1) & 3) + 1];
+                const double exmin = fmin(x1, x2), exmax = fmax(x1, x2), eymin = fmin(y1, y2), eymax = fmax(y1, y2);
+                if (exmin > hmaxx || exmax < hminx || eymin > hmaxy || eymax < hminy) continue;
+                const double d_ = y2 - y1, e_ = x1 - x2, f_ = y1 * x2 - x1 * y2;                  // :504-506
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int k2 = (k + 1) & 3;
+                    const double ax1 = vx[k], ay1 = vy[k], ax2 = vx[k2], ay2 = vy[k2];
+                    const double vminx = fmin(ax1, ax2), vmaxx = fmax(ax1, ax2), vminy = fmin(ay1, ay2), vmaxy = fmax(ay1, ay2);
+                    if (vminx > exmax || vmaxx < exmin || vminy > eymax || vmaxy < eymin) continue;
+                    const double a_ = ay2 - ay1, b_ = ax1 - ax2, c_ = ay1 * ax2 - ax1 * ay2;      // :477-479
+                    const double det = a_ * e_ - b_ * d_;
+                    if (det == 0) continue;
+                    const double raw_x = (b_ * f_ - c_ * e_) / det;
+                    const double raw_y = (c_ * d_ - a_ * f_) / det;
+                    const bool cx_ = !(raw_x > exmax) && !(raw_x < exmin) && !(raw_x > vmaxx) && !(raw_x < vminx);
+                    const bool cy_ = !(raw_y > eymax) && !(raw_y < eymin) && !(raw_y > vmaxy) && !(raw_y < vminy);
+                    if (cx_ && cy_) bad = true;
+                }
+            }
+        }
+    }
+    return bad;
+}
+
+template <int OCC, bool TIMING, bool STATS>
+__global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f64) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    unsigned long long tsec[16] = {};
+    const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
+    RS_T0();
+    const int count = *p.rs_count;
+    if ((int)blockIdx.x >= count) return;
+    const int qidx = scene_of_block(blockIdx.x, count);
+    const int slot = p.slot_base + p.slot_dir * qidx;
+    // LDS: float2 V[4 cap] | float4 box[cap] | float64 tile 8 cap + world boxes float4[cap] (filled when the first pass needs the
+    //      float64 arithmetic) | scratch doubles: segment table 50, sample queue pd[256], bad1[8] | int cand[cap] | bytes: qseg[256],
+    //      edge flags[cap]
+    float2* fv = (float2*)lds;
+    float4* fbox = (float4*)(lds + 4 * p.tile_cap);
+    double* tile64 = lds + 6 * p.tile_cap;
+    float4* obb64 = (float4*)(lds + 14 * p.tile_cap);
+    double* scr = lds + 16 * p.tile_cap;
+    bool have_tile64 = false;
+    double* segp = scr + RSB_SEG;
+    double* qpd = scr + RSB_QPD;
+    int* cand = (int*)(scr + RSB_WORDS);
+    unsigned char* qseg = (unsigned char*)(cand + ((p.tile_cap + 3) & ~3));
+    unsigned char* eflag = qseg + RSB_QCAP;
+
+    const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
+    const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
+    const double* tables = rec + RS_REC_SEGS;
+    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
+    const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);
+    if (n_paths == 0) return;
+    const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
+    const int n_obst = __builtin_amdgcn_readlane(__double2hiint(r0), 0);
+    const double q0x = readlane_d(r0, 2), q0y = readlane_d(r0, 3), q0w = readlane_d(r0, 4);
+    const double xmin = readlane_d(r0, 5), xmax = readlane_d(r0, 6), ymin = readlane_d(r0, 7), ymax = readlane_d(r0, 8);
+    const double* verts_g = p.verts + (size_t)scene * p.max_obst * 8;
+    const float4* obb_g = p.obb + (size_t)scene * p.max_obst;
+    // first-segment samples: lane holds T[lane], T[64 + lane], ... (in flight during the staging)
+    const double T0 = g_rs_steps[lane], T1 = g_rs_steps[WAVE + lane], T2 = g_rs_steps[2 * WAVE + lane], T3 = g_rs_steps[3 * WAVE + lane];
+    // map box relative to the start position: the rear axle must stay inside (:462-464)
+    const float fxmin = (float)(xmin - q0x), fxmax = (float)(xmax - q0x), fymin = (float)(ymin - q0y), fymax = (float)(ymax - q0y);
+    const double step = RS_STEP * MAXC;
+    // Obstacle vertices relative to the start position, float32 (subtraction in float64: one rounding, <= 4e-6 m); lane = vertex,
+    // so a quad of lanes holds one obstacle: its box and its edges' flags come from quad DPP, no second pass over the tile.
+    for (int base = 0; base < 4 * n_obst; base += WAVE) {
+        const int v = base + lane;
+        const bool in = v < 4 * n_obst;
+        const double2 q = in ? ((const double2*)verts_g)[v] : make_double2(0.0, 0.0);
+        const float fx = (float)(q.x - q0x), fy = (float)(q.y - q0y);
+        if (in) fv[v] = make_float2(fx, fy);
+        // An edge's coordinate box must not be degenerate: both extents >= FETA_EDGE.  One degenerate case IS robust: an edge that
+        // lies exactly on the world line y = 0 (or x = 0): then f = y1 x2 - x1 y2 and d = y2 - y1 are exact zeros, raw_y = -a f / det
+        // is an exact (signed) zero and passes the box test y_min = y_max = 0 whatever the rounding -- the back wall of every
+        // generated lot (parking_map_normal.py:70-78) has its top edge there.
+        const double x2 = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(q.x), 0x39, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(q.x), 0x39, 0xf, 0xf, true));
+        const double y2 = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(q.y), 0x39, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(q.y), 0x39, 0xf, 0xf, true));   // quad_perm [1,2,3,0]: the ring's next vertex
+        const bool wide_x = fabs(x2 - q.x) >= (double)FETA_EDGE, wide_y = fabs(y2 - q.y) >= (double)FETA_EDGE;
+        const bool zero_line = (q.y == 0.0 && y2 == 0.0 && wide_x) || (q.x == 0.0 && x2 == 0.0 && wide_y);
+        const unsigned long long rb = __ballot(in && ((wide_x && wide_y) || zero_line));
+        float mnx = fminf(fx, dpp_f<0xB1>(fx)), mxx = fmaxf(fx, dpp_f<0xB1>(fx)), mny = fminf(fy, dpp_f<0xB1>(fy)), mxy = fmaxf(fy, dpp_f<0xB1>(fy));
+        mnx = fminf(mnx, dpp_f<0x4E>(mnx)); mxx = fmaxf(mxx, dpp_f<0x4E>(mxx)); mny = fminf(mny, dpp_f<0x4E>(mny)); mxy = fmaxf(mxy, dpp_f<0x4E>(mxy));
+        if (in && (lane & 3) == 0) {
+            fbox[v >> 2] = make_float4(mnx, mxx, mny, mxy);
+            eflag[v >> 2] = (unsigned char)((rb >> lane) & 0xF);
+        }
+    }
+    int found = -1;
+    double* bad1 = scr + RSB_BAD;
+    if (lane < 6) bad1[lane] = INFINITY;
+    wsync();
+    RS_T(0);
+    const double c_q = readlane_d(tb, RS_SEGW + 7), s_q = readlane_d(tb, 2 * RS_SEGW + 7);   // cos / sin(-q0 yaw) (k_rs_segs)
+    const bool paranoid = (obs_f64 & 0x2000) != 0;        // self-check: float64 for every sample, disagreements counted
+    unsigned long long st_pass = 0, st_hit = 0, st_exact = 0, st_unc = 0, st_bad_hit = 0, st_bad_clear = 0, st_samples = 0;
+    unsigned long long st_why[5] = {};
+    for (int idx = 1; idx <= n_paths; idx++) {
+        const double tcur = tb;
+        if (idx < n_paths && lane < RS_SEG_TABLE) tb = tables[RS_SEG_TABLE * idx + lane];      // prefetch the next word's
+        const double len0 = readlane_d(tcur, 6), w6 = readlane_d(tcur, 7);
+        const int code = __double2loint(w6), nseg = __double2hiint(w6);
+        const int cls1 = type_of(code, 0) * 2 + (len0 > 0.0 ? 1 : 0);
+        if (fabs(len0) >= bad1[cls1]) continue;           // contains a sample already known to collide
+        bool invalid = false;
+        if (lane < RS_SEG_TABLE) segp[lane] = tcur;
+        if (TIMING) tsec[9] += 1;
+        if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
+        int nq = 1;
+        wsync();
+        RS_T(1);
+        const int win = 128;
+        int i = 0, t_off = 0;                              // t_off: first-segment samples taken from the table so far
+        bool seg_open = false, finished = false;
+        double pd = 0, ll = 0.0, lprev = 0.0, d = 0, l = 0;
+        while (!invalid && (!finished || nq > 0)) {
+            while (!finished && nq + WAVE + 1 <= win) {
+                if (TIMING) tsec[10] += 1;
+                if (!seg_open) {
+                    l = segp[RSB_SEGW * i + 6];
+                    d = l > 0.0 ? step : -step;
+                    if (i >= 1 && (lprev * l) > 0) pd = -d - ll; else pd = d - ll;
+                    lprev = l;
+                    seg_open = true;
+                }
+                double mine, t = pd;
+                int ncap;
+                if (i == 0 && t_off + WAVE <= RS_TAB) {
+                    // first segment: pd = d, d + d, ... is the same chain for every word of every search -> table
+                    const double v = t_off == 0 ? T0 : (t_off == WAVE ? T1 : (t_off == 2 * WAVE ? T2 : T3));
+                    mine = d > 0.0 ? v : -v;
+                    ncap = WAVE;
+                    t_off += WAVE;
+                    if (t_off < RS_TAB) {                         // the chain's next value: lane 0 of the next chunk
+                        const double nx = readlane_d(t_off == WAVE ? T1 : (t_off == 2 * WAVE ? T2 : T3), 0);
+                        t = d > 0.0 ? nx : -nx;
+                    } else t = readlane_d(mine, WAVE - 1) + d;
+                } else {
+                    // `pd += d` chain (sequential rounding kept), see k_rs_validate
+                    mine = pd;
+                    double last = pd;
+                    ncap = 0;
+                    for (int j0 = 0; j0 < WAVE; j0 += 8) {
+                        if ((lane >> 3) == (j0 >> 3)) mine = t;
+#pragma unroll
+                        for (int jj = 0; jj < 7; jj++) t = t + d;
+                        last = t;
+                        t = t + d;
+                        ncap = j0 + 8;
+                        if (__any(fabs(last) > fabs(l))) break;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 7; k++)
+                        if (k < (lane & 7)) mine = mine + d;
+                }
+                const bool in_seg = lane < ncap && fabs(mine) <= fabs(l);
+                const unsigned long long valid = (ncap == WAVE) ? ~0ull : ((1ull << ncap) - 1);
+                const unsigned long long fail = ~__ballot(in_seg) & valid;
+                const int cnt = fail ? (__ffsll((long long)fail) - 1) : ncap;
+                if (lane < cnt) { qpd[nq + lane] = mine; qseg[nq + lane] = (unsigned char)i; }
+                nq += cnt;
+                if (fail) {
+                    pd = __shfl(mine, cnt);
+                    ll = l - pd - d;
+                    seg_open = false;
+                    if (i == nseg - 1) {
+                        if (lane == 0) { qpd[nq] = l; qseg[nq] = (unsigned char)i; }
+                        nq += 1;
+                        finished = true;
+                    }
+                    i++;
+                } else pd = t;
+            }
+            wsync();
+            RS_T(2);
+            const int n_all = nq;
+            const int n = finished ? n_all : (n_all & ~(WAVE - 1));
+            const int stride = (n + WAVE - 1) >> 6;                  // 1 .. 3 (n <= 192): no integer divisions below
+            const int n_coarse = stride == 1 ? n : (stride == 2 ? (n + 1) >> 1 : ((n + 2) * 171) >> 9);      // ceil(n / stride)
+            const int n_rest = n - n_coarse;
+            for (int rnd = 0; rnd == 0 || (rnd - 1) * WAVE < n_rest; rnd++) {
+                int sidx;
+                if (rnd == 0) sidx = (lane < n_coarse) ? stride * lane : -1;
+                else { const int r = (rnd - 1) * WAVE + lane; sidx = r < n_rest ? r + (stride == 2 ? r : r >> 1) + 1 : -1; }
+                const bool active = sidx >= 0;
+                if (TIMING) tsec[11] += 1;
+                // ---- float32 pose in the start-position frame ----
+                float X = 0, Y = 0, hc = 1, hs = 0;
+                int sg0 = 0;
+                if (active) {
+                    const float lf = (float)qpd[sidx];
+                    sg0 = (int)qseg[sidx];
+                    const float4 row = ((const float4*)(segp + RS_SEG_F32))[sg0];        // Ox, Oy, cos, sin of the world heading
+                    const int m = type_of(code, sg0);
+                    const float rev = lf * 0.15915494309189535f;
+                    const float sl = m == TS ? 0.0f : __builtin_amdgcn_sinf(rev), cl = m == TS ? 1.0f : __builtin_amdgcn_cosf(rev);
+                    const float sgn = m == TR ? -1.0f : 1.0f;
+                    const float ldx = m == TS ? lf * F_INV_MAXC : sl * F_INV_MAXC;
+                    const float ldy = sgn * (1.0f - cl) * F_INV_MAXC;
+                    X = row.x + (row.z * ldx - row.w * ldy);
+                    Y = row.y + (row.w * ldx + row.z * ldy);
+                    const float ss = sgn * sl;                                               // heading + l (L), - l (R)
+                    hc = row.z * cl - row.w * ss;
+                    hs = row.w * cl + row.z * ss;
+                }
+                RS_T(3);
+                // out of the map box: decided / undecided with margin
+                int why_cnt = 0, hit_rec = -1;
+                int ua = -1, ub = -1;                              // undecided edges of this lane: obstacle | edge mask << 8, two obstacles
+                bool uover = false;                                // ... more than two: the generic float64 pass
+                bool hit = active && (X < fxmin - FEPS || X > fxmax + FEPS || Y < fymin - FEPS || Y > fymax + FEPS);
+                bool unc = active && !hit && (X < fxmin + FEPS || X > fxmax - FEPS || Y < fymin + FEPS || Y > fymax - FEPS);
+                // hull box (inflated by FEPS): centre + |cos|, |sin| extents
+                const float cx = X + hc * F_MID, cy = Y + hs * F_MID;
+                const float ex = fabsf(hc) * F_HL + fabsf(hs) * F_HW + FEPS, ey = fabsf(hs) * F_HL + fabsf(hc) * F_HW + FEPS;
+                const float lox = cx - ex, hix = cx + ex, loy = cy - ey, hiy = cy + ey;
+                const float ulox = wave_min_f(active ? lox : INFINITY), uhix = wave_max_f(active ? hix : -INFINITY);
+                const float uloy = wave_min_f(active ? loy : INFINITY), uhiy = wave_max_f(active ? hiy : -INFINITY);
+                int nc = 0;
+                for (int base = 0; base < n_obst; base += WAVE) {
+                    const int o = base + lane;
+                    bool near = false;
+                    if (o < n_obst) {
+                        const float4 bb = fbox[o];
+                        near = !(bb.x > uhix || bb.y < ulox || bb.z > uhiy || bb.w < uloy);
+                    }
+                    const unsigned long long mm = __ballot(near);
+                    if (near) cand[nc + __popcll(mm & ((1ull << lane) - 1))] = o;
+                    nc += __popcll(mm);
+                }
+                RS_T(4);
+                if (nc > 0 && !__any(hit)) {
+                    if (TIMING) { tsec[12] += 1; tsec[13] += nc; }
+                    wsync();
+                    const bool hull_ok = fminf(fabsf(hc), fabsf(hs)) >= FETA_HULL;      // no hull edge axis-parallel in the world
+                    for (int ci = 0; ci < nc; ci++) {
+                        const int r = cand[ci];
+                        const float4 bb = fbox[r];
+                        const bool near = active && !(bb.x > hix || bb.y < lox || bb.z > hiy || bb.w < loy);
+                        if (!__any(near)) continue;
+                        // the four vertices in the car frame (origin = hull centre)
+                        const float4 v01 = ((const float4*)fv)[2 * r], v23 = ((const float4*)fv)[2 * r + 1];
+                        float u[4], w[4];
+                        {
+                            const float dx0 = v01.x - cx, dy0 = v01.y - cy, dx1 = v01.z - cx, dy1 = v01.w - cy;
+                            const float dx2 = v23.x - cx, dy2 = v23.y - cy, dx3 = v23.z - cx, dy3 = v23.w - cy;
+                            u[0] = hc * dx0 + hs * dy0; w[0] = hc * dy0 - hs * dx0;
+                            u[1] = hc * dx1 + hs * dy1; w[1] = hc * dy1 - hs * dx1;
+                            u[2] = hc * dx2 + hs * dy2; w[2] = hc * dy2 - hs * dx2;
+                            u[3] = hc * dx3 + hs * dy3; w[3] = hc * dy3 - hs * dx3;
+                        }
+                        const float umin = fminf(fminf(u[0], u[1]), fminf(u[2], u[3])), umax = fmaxf(fmaxf(u[0], u[1]), fmaxf(u[2], u[3]));
+                        const float wmin = fminf(fminf(w[0], w[1]), fminf(w[2], w[3])), wmax = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+                        // whole obstacle beyond one side of the (inflated) rectangle: clear
+                        const bool maybe = near && !(umin > F_HL + FEPS || umax < -F_HL - FEPS || wmin > F_HW + FEPS || wmax < -F_HW - FEPS);
+                        if (!__any(maybe)) continue;
+                        // phase 1, branch-free: which edges are NOT certainly clear of the hull
+                        const int efl = (int)eflag[r];
+                        float g[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) g[k] = fmaxf(fabsf(u[k]) - F_HL, fabsf(w[k]) - F_HW);    // > 0 outside
+                        float nu[4], nw[4], dn[4], esep[4];        // edge normal, |C| - (A + B), separation on the rectangle's axes
+                        float dist[4];
+                        int open = 0;                              // bit k: edge k undecided so far
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int k2 = (k + 1) & 3;
+                            nu[k] = w[k2] - w[k]; nw[k] = u[k] - u[k2];                       // normal of the edge (not normalised)
+                            dist[k] = fabsf(__builtin_fmaf(nu[k], u[k], nw[k] * w[k]));       // |n . P|: distance of the edge's LINE from the centre
+                            dn[k] = dist[k] - __builtin_fmaf(fabsf(nu[k]), F_HL, fabsf(nw[k]) * F_HW);   // minus the rectangle's radius along n
+                            const float eu0 = fminf(u[k], u[k2]), eu1 = fmaxf(u[k], u[k2]);
+                            const float ew0 = fminf(w[k], w[k2]), ew1 = fmaxf(w[k], w[k2]);
+                            esep[k] = fmaxf(fmaxf(eu0 - F_HL, -F_HL - eu1), fmaxf(ew0 - F_HW, -F_HW - ew1));
+                            const float mg = FEPS * (fabsf(nu[k]) + fabsf(nw[k]));
+                            // separated on the edge's normal or on a rectangle axis (inflated), or wholly inside (deflated)
+                            const bool clear = dn[k] > mg || esep[k] > FEPS || fmaxf(g[k], g[k2]) < -FEPS;
+                            open |= (maybe && !clear) ? (1 << k) : 0;
+                        }
+                        // phase 2, only for edges some lane still has open: a certain AND robust crossing, or undecided
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (!__any((open >> k) & 1)) continue;
+                            const int k2 = (k + 1) & 3;
+                            const float n1 = fabsf(nu[k]) + fabsf(nw[k]), mg = FEPS * n1;
+                            // meets the deflated rectangle, both end points off the boundary, one of them outside
+                            const bool cross = dn[k] < -mg && esep[k] < -FEPS && fminf(fabsf(g[k]), fabsf(g[k2])) > FEPS && fmaxf(g[k], g[k2]) > FEPS;
+                            // Robustness for the tolerance-free reference test.  With A = |nu| HL, B = |nw| HW the edge's line n . p = C is at
+                            // | |C| - (A + B) | and | |C| - |A - B| | (times 1 / |n|) from the nearest hull corners, it crosses a side u = +-HL iff
+                            // | |C| - A | <= B and a side w = +-HW iff | |C| - B | <= A (margin added: "may cross").
+                            const float A = fabsf(nu[k]) * F_HL, B = fabsf(nw[k]) * F_HW;
+                            const bool corners_ok = fminf(fabsf(dn[k]), fabsf(dist[k] - fabsf(A - B))) > mg;
+                            const bool cross_u = fabsf(dist[k] - A) <= B + mg, cross_w = fabsf(dist[k] - B) <= A + mg;
+                            const bool angle_ok = (!cross_u || fabsf(nw[k]) >= FKAPPA * n1) && (!cross_w || fabsf(nu[k]) >= FKAPPA * n1);
+                            const bool certain = cross && corners_ok && angle_ok && hull_ok && ((efl >> k) & 1);
+                            const bool mine_open = (open >> k) & 1;
+                            if (mine_open && certain) { hit = true; if (STATS && hit_rec < 0) hit_rec = r * 4 + k; }
+                            if (STATS && mine_open && !certain) why_cnt |= 1 << (!cross ? 0 : !((efl >> k) & 1) ? 1 : !hull_ok ? 2 : !corners_ok ? 3 : 4);
+                            // (the record of the undecided edges only matters while no sample of the pass is a certain hit)
+                            if (!__any(hit) && mine_open && !certain) {
+                                unc = true;
+                                if (ua < 0) ua = r | (0x100 << k);
+                                else if ((ua & 0xff) == r) ua |= 0x100 << k;
+                                else if (ub < 0) ub = r | (0x100 << k);
+                                else if ((ub & 0xff) == r) ub |= 0x100 << k;
+                                else uover = true;
+                            }
+                        }
+                        if (__any(hit)) break;                   // one certain collision condemns the word
+                    }
+                    wsync();
+                }
+                RS_T(5);
+                // ---- decision of the pass ----
+                bool bad = hit;
+                const bool any_hit = __any(hit);
+                const bool need64 = (STATS && paranoid) || (!any_hit && __any(unc));
+                if (need64 && !have_tile64) {                    // the float64 tile and its world boxes, once per search
+                    const double2* src = (const double2*)verts_g;
+                    double2* dst = (double2*)tile64;
+                    for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
+                    for (int o = lane; o < n_obst; o += WAVE) obb64[o] = obb_g[o];
+                    have_tile64 = true;
+                    wsync();
+                }
+                if (STATS) {
+                    st_pass += 1;
+                    if (any_hit) st_hit += 1;
+                    if (!any_hit && __any(unc)) {
+                        const unsigned long long wm = __ballot(why_cnt != 0);
+                        int wor = 0;
+                        for (int b = 0; b < 5; b++) if (__any((why_cnt >> b) & 1)) wor |= 1 << b;
+                        for (int b = 0; b < 5; b++) st_why[b] += (wor >> b) & 1;
+                        (void)wm;
+                    }
+                }
+                if (STATS && paranoid) {                         // float64 for every sample; compare with the float32 verdicts
+                    const bool ex = exact_pass<true>(active ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, tile64, obb64, cand, n_obst, xmin, xmax, ymin, ymax, lane);
+                    st_samples += __popcll(__ballot(active));
+                    st_bad_hit += __popcll(__ballot(active && hit && !ex));
+                    if (active && ((hit && !ex) || (!any_hit && !hit && !unc && ex))) {
+                        const int di = (int)atomicAdd(&g_rs_fstat[15], 1ull);
+                        if (di < 64) {
+                            double px = 0, py = 0, pyaw = 0;
+                            const double spd = qpd[sidx];
+                            const double* sp_ = segp + RSB_SEGW * (int)qseg[sidx];
+                            interpolate(spd, (int)sp_[5], sp_[0], sp_[1], sp_[2], sp_[3], -sp_[4], sp_[3], sp_[4], px, py, pyaw);
+                            const double wyaw = pi_2_pi(pyaw + q0w);
+                            double* dd = g_rs_fdump + 16 * di;
+                            dd[0] = scene; dd[1] = idx; dd[2] = spd; dd[3] = (double)qseg[sidx]; dd[4] = X; dd[5] = Y; dd[6] = hc; dd[7] = hs;
+                            dd[8] = c_q * px + s_q * py; dd[9] = -s_q * px + c_q * py; dd[10] = hm_cos(wyaw); dd[11] = hm_sin(wyaw);
+                            dd[12] = hit ? 1.0 : 0.0; dd[13] = (double)why_cnt; dd[14] = sp_[5]; dd[15] = (double)hit_rec;
+                        }
+                    }
+                    // (a pass stops at its first certain hit: samples it did not finish looking at have no verdict)
+                    if (!any_hit) st_bad_clear += __popcll(__ballot(active && !hit && !unc && ex));
+                    bad = ex;
+                } else if (!any_hit && __any(unc)) {
+                    if (STATS) { st_exact += 1; st_unc += __popcll(__ballot(unc)); }
+                    bad = exact_edges(unc, sidx, ua, ub, segp, qpd, qseg, tile64, c_q, s_q, q0x, q0y, q0w, xmin, xmax, ymin, ymax);
+                    if (__any(uover))                            // (a sample with open edges on more than two obstacles: rare)
+                        bad = exact_pass<false>(uover ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, tile64, obb64, cand, n_obst, xmin, xmax, ymin, ymax, lane) || bad;
+                }
+                if (TIMING) t0_ = __builtin_readcyclecounter();
+                if (__any(bad)) {
+                    const double mine1 = (bad && active && qseg[sidx] == 0) ? fabs(qpd[sidx]) : INFINITY;
+                    const double v = fmin(bad1[cls1], wave_min_d(mine1));
+                    wsync();
+                    if (lane < 6 && (lane == cls1 || v == 0.0)) bad1[lane] = fmin(bad1[lane], v);
+                    invalid = true;
+                    break;
+                }
+            }
+            {   // carry the untested tail to the front of the queue
+                const int rem = n_all - n;
+                double cd = 0;
+                unsigned char cs = 0;
+                if (lane < rem) { cd = qpd[n + lane]; cs = qseg[n + lane]; }
+                wsync();
+                if (lane < rem) { qpd[lane] = cd; qseg[lane] = cs; }
+                nq = rem;
+            }
+            wsync();
+        }
+        if (!invalid) { found = idx - 1; break; }
+    }
+    if (STATS && lane == 0) {                              // statistics of the filter (tools/rs_filter_stats.py, the soak test)
+        for (int b = 0; b < 5; b++) atomicAdd(&g_rs_fstat[8 + b], st_why[b]);
+        atomicAdd(&g_rs_fstat[0], st_pass); atomicAdd(&g_rs_fstat[1], st_hit); atomicAdd(&g_rs_fstat[2], st_exact);
+        atomicAdd(&g_rs_fstat[3], st_unc); atomicAdd(&g_rs_fstat[4], st_bad_hit); atomicAdd(&g_rs_fstat[5], st_bad_clear);
+        atomicAdd(&g_rs_fstat[6], st_samples);
+    }
+    if (TIMING) {
+        tsec[6] = __builtin_readcyclecounter() - tstart_;
+        tsec[8] = 1;
+        if (lane == 0) {
+            for (int i = 0; i < 16; i++) if (tsec[i]) atomicAdd(&g_rs_prof[(blockIdx.x & 63) * 16 + i], tsec[i]);
+            const int li = atomicAdd(&g_rs_log_n, 1);
+            if (li < RS_LOG_CAP) g_rs_log[li] = make_int4((int)tsec[6], (int)tsec[9] | (n_paths << 8) | ((p.tile_cap > 32) << 16), (int)tsec[11], found >= 0);
+        }
+    }
+    if (found < 0) return;
+    const double wlen = lane < 5 ? segp[RSB_SEGW * lane + 6] : 0.0;
+    const int code = __double2loint(segp[7]), nseg = __double2hiint(segp[7]);
+    if (lane < 5) {
+        double lm = lane < nseg ? wlen / MAXC : 0.0;
+        if (p.rs_lengths) {
+            if (obs_f64 & 1) ((double*)p.rs_lengths)[5 * (size_t)scene + lane] = lm;
+            else ((float*)p.rs_lengths)[5 * (size_t)scene + lane] = (float)lm;
+        }
+        p.rs_word[8 * (size_t)scene + lane] = lane < nseg ? (int8_t)type_of(code, lane) : (int8_t)HOPE_RS_NONE;
+    }
+    if (lane == 5) p.rs_word[8 * (size_t)scene + 5] = (int8_t)nseg;
+    if (lane == 6) p.rs_word[8 * (size_t)scene + 6] = 1;
+}
+
 }  // namespace
 
-size_t rs_lds_bytes(int max_obst) {
+static size_t rs_lds_bytes_exact(int max_obst) {
     return (size_t)(10 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP;
 }
+static size_t rs_lds_bytes_filter(int max_obst) {
+    return (size_t)(16 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP + (size_t)((max_obst + 3) & ~3);
+}
+size_t rs_lds_bytes(int max_obst) { return rs_lds_bytes_filter(max_obst); }    // the larger of the two
 size_t rs_rec_bytes_per_scene() { return sizeof(double) * RS_REC_DOUBLES; }
 
 hipError_t rs_prof_read(unsigned long long* out, int reset) {
@@ -862,6 +1395,12 @@ hipError_t rs_prof_read(unsigned long long* out, int reset) {
     return e;
 }
 
+hipError_t rs_fdump_read(double* out /*[64][16]*/) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_fdump), sizeof(double) * 64 * 16);
+}
+
 hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset) {
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
@@ -873,17 +1412,51 @@ hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset) {
     return e;
 }
 
+hipError_t rs_fstat_read(unsigned long long* out /*[16]*/, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_fstat), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_rs_fstat), z, sizeof(z));
+    }
+    return e;
+}
+
+// first-segment sample table of k_rs_validate_f: step added k + 1 times, sequentially, in float64 (the reference's `pd += d`)
+static hipError_t rs_init_tables() {
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    double tab[RS_TAB];
+    const volatile double step = RS_STEP * MAXC;          // (volatile: every addition rounds to float64, whatever the host compiler does)
+    volatile double t = step;
+    for (int k = 0; k < RS_TAB; k++) { tab[k] = t; t = t + step; }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_rs_steps), tab, sizeof(tab));
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    return e;
+}
+
 hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer) {
     if (p.max_queue <= 0) return hipSuccess;
-    size_t lds = rs_lds_bytes(p.tile_cap);
-    // register budget of the validation kernel: 4 waves / SIMD (128 VGPRs, some spills) or 3 (168 VGPRs); HOPE_RS_OCC picks
+    // (read per call: the tests switch kernels inside one process)
     static const bool timing = getenv("HOPE_RS_TIMING") != nullptr;      // cycle accounting build (tools/rs_timing.py)
-    static const int occ = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 3;   // the 4-wave build (50 spilled VGPRs) hung on the GPU: kept for experiments only
+    const bool exact = getenv("HOPE_RS_EXACT") != nullptr;               // the all-float64 validation kernel (the float32 filter's reference)
+    const int occ = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 0;   // exact kernel: 3 (168 VGPRs, default) or 4 (128, spills); filter: 4 (default), 5, 6
+    const int dbg = getenv("HOPE_RS_DEBUG") ? (int)strtol(getenv("HOPE_RS_DEBUG"), nullptr, 0) : 0;   // profiling / self-check switches
+    const bool stats = (dbg & 0x6000) != 0;                              // float32-filter statistics / self-check build
+    const size_t lds = exact ? rs_lds_bytes_exact(p.tile_cap) : rs_lds_bytes_filter(p.tile_cap);
+    const void* vk = exact ? (timing ? (const void*)k_rs_validate<3, true> : occ != 4 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>)
+                           : (timing ? (const void*)k_rs_validate_f<RSF_OCC, true, false> : stats ? (const void*)k_rs_validate_f<RSF_OCC, false, true>
+                              : occ == 5 ? (const void*)k_rs_validate_f<5, false, false>
+                              : occ == 3 ? (const void*)k_rs_validate_f<3, false, false> : (const void*)k_rs_validate_f<RSF_OCC, false, false>);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(timing ? (const void*)k_rs_validate<3, true> : occ == 3 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(vk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    if (!exact) { hipError_t e = rs_init_tables(); if (e != hipSuccess) return e; }
     // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
     if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
     hipLaunchKernelGGL(k_rs_words, dim3((p.max_queue + RSA_SCENES - 1) / RSA_SCENES, RSA_GROUPS), dim3(WAVE), 0, stream, p);
@@ -891,11 +1464,17 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->begin(HOPE_K_RS_SEGS, stream);
     hipLaunchKernelGGL(k_rs_segs, dim3((p.max_queue + 7) / 8), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
-    static const int dbg = getenv("HOPE_RS_DEBUG") ? atoi(getenv("HOPE_RS_DEBUG")) : 0;   // profiling switches
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
-    if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
-    else if (occ == 3) hipLaunchKernelGGL((k_rs_validate<3, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
-    else hipLaunchKernelGGL((k_rs_validate<4, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, (p.obs_f64 ? 1 : 0) | dbg);
+    const int flags = (p.obs_f64 ? 1 : 0) | dbg;
+    if (exact) {
+        if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+        else if (occ != 4) hipLaunchKernelGGL((k_rs_validate<3, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+        else hipLaunchKernelGGL((k_rs_validate<4, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    } else if (timing) hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, true, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    else if (stats) hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, false, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    else if (occ == 5) hipLaunchKernelGGL((k_rs_validate_f<5, false, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    else if (occ == 3) hipLaunchKernelGGL((k_rs_validate_f<3, false, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    else hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, false, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }

@@ -82,6 +82,7 @@ extern "C" {
  *                    launch (default 16384); HOPE_NO_SPLIT: never
  *   HOPE_CLS1_FRAC   share of the scenes the large-tile launch chain should hold after the small-tile class has handed
  *                    scenes over (default 0.42 below 32768 scenes, else 0 = no hand-over); read by hope_env_set_scenes
+ *   HOPE_RS_EXACT    validate Reeds-Shepp words with the all-float64 kernel (the reference of the default kernel's float32 filter)
  *   HOPE_CHAINS, HOPE_BALANCE, HOPE_PRIO, HOPE_RS_OCC   rejected launch / build variants kept for experiments
  *   HOPE_STEP_TIMING, HOPE_RS_TIMING, HOPE_RS_DEBUG      instrumented kernel builds and profiling switches (tools/) */
 
@@ -234,6 +235,14 @@ int hope_debug_math(int fn, int n, const double *a, const double *b, double *out
  * launches when the environment variable HOPE_RS_TIMING is set (hope_amd/csrc/hope_rs.hip lists the sections); zeros
  * otherwise.  Host-synchronous.  tools/rs_timing.py prints the breakdown. */
 int hope_debug_rs_prof(uint64_t *out /*[16]*/, int reset);
+/* Statistics of k_rs_validate's float32 filter, accumulated while the environment variable HOPE_RS_DEBUG has bit 0x4000 set:
+ * [0] passes [1] passes decided by a certain float32 hit [2] passes that re-evaluated undecided samples in float64 [3] those
+ * samples; with bit 0x2000 (self-check: float64 for EVERY sample) also [4] float32 "hit" verdicts float64 contradicts, [5] float32
+ * "clear" verdicts float64 contradicts (both must stay 0), [6] samples checked; [8..12] passes left undecided because of: no certain crossing / an
+ * axis-parallel obstacle edge / an axis-parallel hull / a hull corner near the edge line / a shallow crossing angle.  Host-synchronous. */
+int hope_debug_rs_filter_stats(uint64_t *out /*[16]*/, int reset);
+/* details of the first 64 contradicted verdicts of the self-check (16 doubles each; tools/rs_filter_stats.py --check) */
+int hope_debug_rs_filter_dump(double *out /*[64][16]*/);
 /* Per-search log of the same instrumented build: up to cap records of 4 int32 {wave cycles, words tested | words allowed << 8 |
  * large-tile class << 16, passes, found}; *n = records logged since the last reset.  Host-synchronous.  tools/rs_tail.py. */
 int hope_debug_rs_log(int32_t *out /*[cap][4]*/, int cap, int32_t *n, int reset);

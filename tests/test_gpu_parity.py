@@ -790,3 +790,74 @@ def test_headline_configuration_has_an_oracle_witness_65536_scenes():
     assert all(tot[k] == 0 for k in ('status_mismatch', 'done_mismatch', 'mask_mismatch', 'rs_mismatch', 'state_mismatch', 'f32_value_mismatch'))
     assert worst < TOL32
     env.close()
+
+
+def _rs_filter_stats(reset=True):
+    import ctypes as C
+    from hope_amd import load_library
+    out = (C.c_uint64 * 16)()
+    assert load_library().hope_debug_rs_filter_stats(out, int(reset)) == 0
+    v = list(out)
+    d = dict(zip(('passes', 'hit_passes', 'exact_passes', 'undecided_samples', 'bad_hit', 'bad_clear', 'samples'), v[:7]))
+    d['undecided_because'] = dict(zip(('no_certain_crossing', 'axis_parallel_edge', 'axis_parallel_hull', 'corner_near_line', 'shallow_angle'), v[8:13]))
+    return d
+
+
+def test_rs_float32_filter_equals_the_float64_kernel_and_never_contradicts_it():
+    """The default validation kernel decides most samples in float32 with error margins and falls back to the float64
+    arithmetic for the rest (hope_rs.hip, k_rs_validate_f).  (a) Its outputs equal the all-float64 kernel's (HOPE_RS_EXACT)
+    on the same states over a mixed 16 384-scene rollout; (b) self-check mode evaluates EVERY sample in float64 too and counts
+    float32 verdicts the float64 arithmetic contradicts: none, in either direction; (c) the filter does decide most passes."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import SceneSource
+    n, mo = 16384, 128
+    src = SceneSource(seed=71)
+    uniq = [src.draw() for _ in range(1024)]
+    rng = np.random.default_rng(72)
+    for k in range(0, len(uniq), 2):          # half of them start near the destination: tight surroundings, found paths
+        s = uniq[k]
+        r, a = rng.uniform(0.0, 7.0), rng.uniform(0, 2 * np.pi)
+        s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.5])
+    scenes = [uniq[i % len(uniq)] for i in range(n)]
+    env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
+    for a in range(0, n, 8192):
+        env.set_scenes(np.arange(a, a + 8192), scenes[a:a + 8192])
+    env.reset_obs()
+    names = ('rs_word', 'rs_lengths', 'status', 'reward', 'lidar', 'action_mask')
+    g = torch.Generator(device=env.device).manual_seed(73)
+    found = searches = 0
+    try:
+        for it in range(14):
+            act = torch.rand((n, 2), device=env.device, generator=g, dtype=torch.float64) * 2.4 - 1.2
+            pose, t, acc = env.download_state()
+            os.environ['HOPE_RS_EXACT'] = '1'
+            env.step(act)
+            torch.cuda.synchronize()
+            ref = {k: getattr(env, k).clone() for k in names}
+            del os.environ['HOPE_RS_EXACT']
+            env.upload_state(pose=pose, t=t, accum=acc)
+            os.environ['HOPE_RS_DEBUG'] = '0x6000' if it % 2 else '0x4000'          # statistics; odd steps: self-check of every sample
+            env.step(act)
+            torch.cuda.synchronize()
+            for k in names:
+                assert torch.equal(getattr(env, k), ref[k]), (it, k)
+            found += int((env.rs_word[:, 6] > 0).sum())
+            searches += int(((env.status == 1)).sum())
+        st = _rs_filter_stats()
+    finally:
+        os.environ.pop('HOPE_RS_EXACT', None)
+        os.environ.pop('HOPE_RS_DEBUG', None)
+    print('float32 filter:', st, 'found', found)
+    if st['bad_hit'] or st['bad_clear']:
+        import ctypes as C
+        from hope_amd import load_library
+        dump = np.zeros((64, 16))
+        load_library().hope_debug_rs_filter_dump(dump.ctypes.data_as(C.c_void_p))
+        np.set_printoptions(precision=9, linewidth=250, suppress=True)
+        print(dump[:min(64, st['bad_hit'] + st['bad_clear'])])
+        np.save('gpurun_out/rs_filter_dump.npy', dump)
+    assert found > 2000
+    assert st['samples'] > 1_000_000 and st['bad_hit'] == 0 and st['bad_clear'] == 0
+    assert st['passes'] > 100_000 and st['exact_passes'] < 0.35 * st['passes']
+    env.close()
