@@ -124,10 +124,13 @@ def main():
         from hope_amd.dist import shard_range
         lo, hi = shard_range(args.scenes, rank, world)
         N = hi - lo
-    rng = np.random.default_rng(args.seed + rank)
-    uniq = make_scenes(min(N, args.unique), args.mix, rng)
-    start, dest, bbox, verts, nob, nvert = pack_scenes(uniq, args.max_obst)
-    reps = (N + len(uniq) - 1) // len(uniq)
+    from hope_amd.scene_gen import generate_arrays, mixed_arrays
+    levels = {'mixed': ('Normal', 'Complex', 'Extrem', 'dlp'), 'dlp': ('dlp',), 'normal': ('Normal', 'Complex', 'Extrem')}[args.mix]
+    n_uniq = min(N, args.unique)
+    # initial maps: native multi-threaded generator for Normal / Complex / Extrem (hope_scenegen_generate), host DLP sampler
+    start, dest, bbox, verts, nob, nvert = mixed_arrays(n_uniq, levels=levels, seed=args.seed + rank, max_obst=args.max_obst)
+    dlp_slot = np.array([levels[k % len(levels)] == 'dlp' for k in range(n_uniq)])
+    reps = (N + n_uniq - 1) // n_uniq
     tile = lambda a: np.concatenate([a] * reps, axis=0)[:N]  # noqa: E731
     stages = {'all': L.STAGE_ALL, 'norss': L.STAGE_MOTION | L.STAGE_OBS | L.STAGE_REWARD,
               'motion': L.STAGE_MOTION | L.STAGE_REWARD}[args.stages]
@@ -141,6 +144,8 @@ def main():
         sl = slice(a, b)
         env.set_scene_arrays(np.arange(a, b), tile(start)[sl], tile(dest)[sl], tile(bbox)[sl], tile(verts)[sl],
                              tile(nob)[sl])
+    if dlp_slot.any():                                       # Dragon-Lake slots stay Dragon-Lake slots whatever their first map's size
+        env.set_draw_class(np.nonzero(tile(dlp_slot))[0], 1)
     n_obst_all = tile(nob)
     edges = 4.0 * n_obst_all
     # algorithmic bytes per scene-step = 808 + 16*E (reads 64 + 16E, writes 744)
@@ -158,12 +163,20 @@ def main():
         env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
 
     fresh = not args.same_map
-    pool_packed = None
+    gen_rate = None
+    gl = []
     if fresh:
-        pool_scenes = make_scenes(args.pool, args.mix, rng)
-        pool_packed = pack_scenes(pool_scenes, args.max_obst)
-        env.set_pool(pool_packed)
-
+        # New maps at episode turnover, drawn inside the step kernel (HOPE_AUTO_REDRAW): generated lots from a device-resident pool
+        # (native generator, refilled by the host whenever it likes) and the 248 Dragon-Lake cases drawn on the device with a
+        # fresh start candidate / jitter / flips / obstacle cull per episode (ParkingMapDLP.reset).
+        gl = [lv for lv in levels if lv != 'dlp']
+        if gl:
+            tg = time.perf_counter()
+            parts = [generate_arrays(lv, args.pool // len(gl), seed=(args.seed + rank) * 7919 + 17 + j, max_obst=args.max_obst) for j, lv in enumerate(gl)]
+            gen_rate = sum(len(p_[4]) for p_ in parts) / (time.perf_counter() - tg)
+            env.set_pool(tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(6)))
+        if 'dlp' in levels:
+            env.set_dlp_cases()
         env.set_redraw_seed(args.seed * 7919 + 1)
 
         def one_step(i):  # noqa: F811
@@ -177,13 +190,17 @@ def main():
         from hope_amd import agents as A
         from hope_amd.rollout import PPOTrainer, SACTrainer
         torch.manual_seed(args.seed)                                  # identical initial weights on every rank
+        refresher = None
+        if fresh and gl:                                              # the pool of generated lots is replaced in the background
+            from hope_amd.scene_gen import PoolRefresher
+            refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5)
         if args.algo == 'ppo':
             agent = A.BatchedPPO(device=dev, use_img=args.image, mini_batch=args.mini_batch, mini_epoch=args.mini_epoch)
-            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=fresh)
+            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=fresh, pool_refresher=refresher)
         else:
             agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
             trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac',
-                                 fresh_scenes=fresh)
+                                 fresh_scenes=fresh, pool_refresher=refresher)
         one_step = lambda i: trainer.step()  # noqa: E731
 
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY
@@ -255,8 +272,7 @@ def main():
     # ---- in-run correctness witness of exactly this configuration (after all timing)
     parity = None
     if args.witness > 0 and trainer is None and rank == 0:
-        parity = parity_witness(env, stages, fresh, (start, dest, bbox, verts, nob, nvert), len(uniq), pool_packed,
-                                act_bank[3], args.witness, args.seed + 1234)
+        parity = parity_witness(env, stages, fresh, act_bank[3], args.witness, args.seed + 1234)
     if dist is not None:
         tt = torch.tensor([elapsed], device='cpu' if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -339,8 +355,10 @@ def main():
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
-                       'episode_turnover': (f'new map from a device-resident pool of {args.pool} scenes (drawn inside the step kernel: HOPE_AUTO_REDRAW)'
+                       'episode_turnover': (f'new map per episode, drawn inside the step kernel (HOPE_AUTO_REDRAW): generated lots from a device-resident pool of '
+                                            f'{args.pool} scenes, Dragon-Lake cases drawn on the device (start candidate, jitter, flips, cull per episode)'
                                             if fresh else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),
+                       'host_generator_scenes_per_s': gen_rate,
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': dom,
@@ -377,9 +395,10 @@ def main():
                                      'horizon': args.horizon, 'mini_batch': args.mini_batch,
                                      'mini_epoch': args.mini_epoch if args.algo == 'ppo' else None,
                                      'updates_in_run': trainer.updates, 'allreduce_bytes_total': trainer.agent.allreduce_bytes,
+                                     'pool_refreshes_in_run': (trainer.refresher.commits if trainer.refresher is not None else 0),
                                      'rollout': trainer.stats()})
         if not args.no_cpu_baseline and world == 1 and trainer is None:
-            result['cpu_baseline'] = cpu_baseline(args, uniq, stages)
+            result['cpu_baseline'] = cpu_baseline(args, (start, dest, bbox, verts, nob, nvert), stages)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -387,14 +406,15 @@ def main():
         print(json.dumps(result))
 
 
-def parity_witness(env, stages, fresh, init_packed, n_uniq, pool_packed, act, k, seed):
+def parity_witness(env, stages, fresh, act, k, seed):
     """In-run correctness witness of the TIMED configuration (float32 observations and actions, the launch form the library
     picked for this batch size, HOPE_AUTO_RESET [| HOPE_AUTO_REDRAW]): `k` random scene slots are rebuilt in the CPU oracle
     from what is on the device after the timed region -- pose / t / accumulator (hope_env_download_state) and the map each
-    slot holds now (hope_env_download_pool_index) -- then ONE more fused step runs on the GPU over the whole batch and in the
-    oracle on those slots, with the same actions.  Scenes whose episode ends in that step are followed through the turnover:
-    the oracle resets them on the map the kernel drew.  The oracle is the checker here, nothing else (it runs after the
-    timed region).  The GPU computes in float64 and stores float32, so every float32 output must equal float32(oracle)."""
+    slot holds now (hope_env_download_scenes: after device-side draws the maps exist there only) -- then ONE more fused step
+    runs on the GPU over the whole batch and in the oracle on those slots, with the same actions.  Scenes whose episode ends
+    in that step are followed through the turnover: the oracle resets them on the map the kernel drew.  The oracle is the
+    checker here, nothing else (it runs after the timed region).  The GPU computes in float64 and stores float32, so every
+    float32 output must equal float32(oracle)."""
     import torch
     from hope_amd import _lib as L
     from hope_amd import tables as T
@@ -409,21 +429,14 @@ def parity_witness(env, stages, fresh, init_packed, n_uniq, pool_packed, act, k,
     O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
     torch.cuda.synchronize(env.device)
 
-    def maps(slots, pidx):
-        """(start, dest, bbox, verts, n_obst, nvert) of the map each slot holds: pool entry pidx, or (pidx < 0) the scene it got
-        from set_scenes"""
-        out = []
-        for j, a_init in enumerate(init_packed):
-            v = a_init[slots % n_uniq]
-            if pool_packed is not None:
-                sel = (pidx >= 0).reshape((-1,) + (1,) * (v.ndim - 1))
-                v = np.where(sel, pool_packed[j][np.maximum(pidx, 0)], v)
-            out.append(v)
-        return out
+    def maps(slots):
+        """(start, dest, bbox, verts, n_obst, nvert) of the map each slot holds; a triangle repeats its last vertex"""
+        start, dest, bbox, verts, nob = env.download_scenes(slots)
+        nvert = np.where((verts[:, :, 3] == verts[:, :, 2]).all(axis=2), 3, 4).astype(np.int32)
+        return start, dest, bbox, verts, nob, nvert
 
     pose, tt, acc = env.download_state()
-    pidx = env.pool_index()[ids] if pool_packed is not None else np.full(k, -1)
-    start, dest, bbox, verts, nob, nvert = maps(ids, pidx)
+    start, dest, bbox, verts, nob, nvert = maps(ids)
     orc = O.BatchOracle(k, env.max_obst, omp=True)
     orc.set_scenes(np.arange(k), start, dest, bbox, verts, nvert, nob)
     orc.pose[:], orc.t[:], orc.accum[:] = pose[ids], tt[ids], acc[ids]
@@ -461,8 +474,7 @@ def parity_witness(env, stages, fresh, init_packed, n_uniq, pool_packed, act, k,
         mask_bad += int((g['action_mask'][go] != o['mask'][go].astype(g['action_mask'].dtype)).any(axis=1).sum())
     if done.any():
         dl = np.nonzero(done)[0]
-        pidx2 = env.pool_index()[ids][dl] if (pool_packed is not None and fresh) else pidx[dl]
-        s2, d2, b2, v2, n2, nv2 = maps(ids[dl], pidx2)
+        s2, d2, b2, v2, n2, nv2 = maps(ids[dl])                      # the maps the kernel drew (or kept) for the new episodes
         orc2 = O.BatchOracle(len(dl), env.max_obst, omp=True)
         orc2.set_scenes(np.arange(len(dl)), s2, d2, b2, v2, nv2, n2)
         o2 = orc2.reset_obs(with_rs=False)
@@ -477,7 +489,7 @@ def parity_witness(env, stages, fresh, init_packed, n_uniq, pool_packed, act, k,
     return res
 
 
-def cpu_baseline(args, uniq, stages):
+def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's unique scenes
     """The CPU oracle (a C port of the reference algorithm) timed on this box's host cores on a bounded
     sample of the SAME workload: first --cpu-scenes scenes, --cpu-steps steps, single thread (and all
     cores via OpenMP as an extra figure).  Reported, non-target."""
@@ -485,9 +497,8 @@ def cpu_baseline(args, uniq, stages):
     from hope_amd import tables as T
     from hope_amd.scenes import pack_scenes
     from oracle import oracle as O
-    n = min(args.cpu_scenes, len(uniq))
-    sample = uniq[:n]
-    start, dest, bbox, verts, nob, nvert = pack_scenes(sample, args.max_obst)
+    n = min(args.cpu_scenes, len(uniq[4]))
+    start, dest, bbox, verts, nob, nvert = (a[:n] for a in uniq)
     t = T.all_tables()
     O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
     with_rs = bool(stages & L.STAGE_RS)

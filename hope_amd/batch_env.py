@@ -78,6 +78,15 @@ class ParkingBatch:
         start, dest, bbox, verts, nob, _nv = pack_scenes(scenes, self.max_obst)
         self.set_scene_arrays(ids, start, dest, bbox, verts, nob)
 
+    def set_draw_class(self, ids, cls):
+        """size class of scene slots (0: lots of <= 32 obstacles, 1: larger lots / Dragon-Lake cases): which launch chain steps a
+        slot and which pool entries it draws at turnover; set_scenes derives it from the obstacle count of the uploaded map"""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(cls, dtype=np.uint8), ids.shape))
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.hope_env_set_draw_class(self.h, ids.ctypes.data, len(ids), c.ctypes.data), 'hope_env_set_draw_class')
+        return self
+
     def set_scene_arrays(self, ids, start, dest, bbox, verts, n_obst):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (start, dest, bbox, verts)]
@@ -97,6 +106,77 @@ class ParkingBatch:
         L.check(self.lib.hope_env_set_pool(self.h, len(nob), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
                                            a[3].ctypes.data, nob.ctypes.data), 'hope_env_set_pool')
         self.pool_size = len(nob)
+
+    def pool_staging(self, n_pool):
+        """pinned host arrays (start[n,3], dest[n,3], bbox[n,4], verts[n,max_obst,4,2], n_obst[n]) of the handle that the next
+        commit_pool(n_pool) uploads; any host thread may fill them (e.g. the native generator, GIL released)"""
+        ptr = [C.c_void_p() for _ in range(5)]
+        L.check(self.lib.hope_env_pool_staging(self.h, int(n_pool), *[C.byref(q) for q in ptr]), 'hope_env_pool_staging')
+        shapes = [(n_pool, 3), (n_pool, 3), (n_pool, 4), (n_pool, self.max_obst, 4, 2), (n_pool,)]
+        out = []
+        for q, shp, ct in zip(ptr, shapes, (C.c_double,) * 4 + (C.c_int32,)):
+            out.append(np.ctypeslib.as_array(C.cast(q, C.POINTER(ct)), shape=(int(np.prod(shp)),)).reshape(shp))
+        return tuple(out)
+
+    def commit_pool(self, n_pool):
+        """asynchronous upload of the staged pool + swap: steps enqueued afterwards draw from it (no synchronisation)"""
+        L.check(self.lib.hope_env_commit_pool(self.h, int(n_pool), self._stream()), 'hope_env_commit_pool')
+        self.pool_size = int(n_pool)
+        return self
+
+    def set_dlp_cases(self, pool=None):
+        """make the Dragon-Lake-Parking cases (a `DlpScenePool`, default data/dlp_scenes.npz) drawable on the device: at episode
+        turnover a large-tile scene then gets a case with a freshly drawn start candidate, jitter, flips and obstacle cull
+        (ParkingMapDLP.reset) instead of a frozen host-side sample.  pool=False removes them."""
+        if pool is False:
+            L.check(self.lib.hope_env_set_dlp_cases(self.h, 0, None, None, None, None, 0, None, None), 'hope_env_set_dlp_cases')
+            return self
+        from .scenes import DlpScenePool
+        pool = pool or DlpScenePool()
+        dest = np.ascontiguousarray(pool.dest, dtype=np.float64)
+        cand_off = np.ascontiguousarray(pool.start_off, dtype=np.int32)
+        cand = np.ascontiguousarray(pool.starts, dtype=np.float64)
+        case_set = np.ascontiguousarray(pool.case_set, dtype=np.int32)
+        set_off = np.ascontiguousarray(pool.set_off, dtype=np.int32)
+        sv = np.array(pool.set_verts, dtype=np.float64)          # [total][4][2]; triangles repeat their last vertex
+        tri = np.asarray(pool.set_nvert) == 3
+        sv[tri, 3] = sv[tri, 2]
+        sv = np.ascontiguousarray(sv)
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.hope_env_set_dlp_cases(self.h, len(dest), dest.ctypes.data, cand_off.ctypes.data, cand.ctypes.data,
+                                                case_set.ctypes.data, len(set_off) - 1, set_off.ctypes.data, sv.ctypes.data),
+                'hope_env_set_dlp_cases')
+        self.n_dlp_cases = len(dest)
+        return self
+
+    def pool_overflow(self):
+        out = np.zeros(1, np.int32)
+        L.check(self.lib.hope_env_pool_overflow(self.h, out.ctypes.data), 'hope_env_pool_overflow')
+        return int(out[0])
+
+    def download_scenes(self, ids):
+        """the maps the listed scene slots hold now -> (start, dest, bbox, verts, n_obst) (host arrays)"""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        n = len(ids)
+        start, dest, bbox = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 4))
+        verts, nob = np.zeros((n, self.max_obst, 4, 2)), np.zeros(n, np.int32)
+        L.check(self.lib.hope_env_download_scenes(self.h, ids.ctypes.data, n, start.ctypes.data, dest.ctypes.data, bbox.ctypes.data,
+                                                  verts.ctypes.data, nob.ctypes.data), 'hope_env_download_scenes')
+        return start, dest, bbox, verts, nob
+
+    def pool_state(self):
+        """(pool index, episode counter) of every scene: with download_state() the whole snapshot of a run that draws maps"""
+        idx, ep = np.zeros(self.n, np.int32), np.zeros(self.n, np.uint32)
+        L.check(self.lib.hope_env_download_pool_state(self.h, idx.ctypes.data, ep.ctypes.data), 'hope_env_download_pool_state')
+        return idx, ep
+
+    def restore_maps(self, pool_index, episode, seed):
+        """repeat the draws of a snapshot (same pool / cases resident, the seed in use then); follow with upload_state()"""
+        drawn = np.ascontiguousarray(np.asarray(pool_index) != -1, dtype=np.uint8)
+        ep = np.ascontiguousarray(episode, dtype=np.uint32)
+        L.check(self.lib.hope_env_restore_maps(self.h, drawn.ctypes.data, ep.ctypes.data, C.c_uint64(int(seed) & (2 ** 64 - 1))),
+                'hope_env_restore_maps')
+        return self
 
     def redraw(self, mask, seed=0):
         """map.reset for the flagged scenes: each takes a pool scene of its tile class and restarts (asynchronous)"""

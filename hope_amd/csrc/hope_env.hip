@@ -58,6 +58,8 @@ struct hope_env {
     int32_t* cls_list[2] = {nullptr, nullptr};
     int cls_count[2] = {0, 0};
     std::vector<int32_t> n_obst_host;
+    std::vector<uint8_t> slot_cls_host;          // draw / launch class of every scene slot (0: <= 32 obstacles, 1: larger lots)
+    uint8_t* slot_cls = nullptr;                 // the same on the device
     double* rs_rec = nullptr;
     uint64_t redraw_seed = 0;       // HOPE_AUTO_REDRAW
     float4* obb = nullptr;          // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
@@ -78,11 +80,27 @@ struct hope_env {
     double* pool_verts = nullptr;   // [pool_n][max_obst][8]
     double* pool_c = nullptr;       // [pool_n][SC_WORDS]
     int32_t* pool_nobst = nullptr;  // [pool_n]
-    double* pool_state = nullptr;   // scratch for k_set_scene_consts
-    int32_t* pool_t = nullptr;
+    // double-buffered storage behind the pointers above: a new pool is uploaded (asynchronously, from pinned staging) into the
+    // set the step kernels are NOT reading and swapped in by stream order (hope_env_pool_staging / hope_env_commit_pool)
+    struct PoolSet { double* verts = nullptr; double* c = nullptr; int32_t* nobst = nullptr; int32_t* list[2] = {nullptr, nullptr}; int cap = 0, list_cap = 0; };
+    PoolSet pset[2];
+    int pactive = -1;
+    struct PoolStage { double* start = nullptr; double* dest = nullptr; double* bbox = nullptr; double* verts = nullptr; int32_t* nobst = nullptr;
+                       int32_t* list = nullptr; int cap = 0; bool busy = false; };
+    PoolStage pstage;                            // pinned host memory
+    double* pstage_dev = nullptr;                // device staging of start | dest | bbox
+    int pstage_dev_cap = 0;
+    hipStream_t pool_stream = nullptr;
+    hipEvent_t ev_pool_ready = nullptr, ev_pool_copied = nullptr, ev_last_step = nullptr;
+    bool pool_wait_pending = false;
     int32_t* pool_cls[2] = {nullptr, nullptr};   // pool entries of each tile class
     int pool_cls_n[2] = {0, 0};
-    int32_t* cur_pool = nullptr;    // [n] pool entry a scene currently holds (-1: uploaded by set_scenes)
+    std::vector<int32_t> pool_nobst_host;        // n_obst of the pool's complete scenes (class lists are rebuilt from it)
+    // Dragon-Lake-Parking cases drawn on the device (hope_env_set_dlp_cases)
+    DlpCases dlp = {};
+    void* dlp_mem[6] = {};
+    int32_t* pool_overflow = nullptr;            // [1] device counter: draws truncated to max_obst obstacles
+    int32_t* cur_pool = nullptr;    // [n] pool entry a scene currently holds (-1: uploaded by set_scenes; -1 - c... see hope_env.h)
     uint32_t* episode = nullptr;    // [n] redraw counter (part of the draw's hash)
     // HOPE_F_OVERLAP: the two tile classes' launches go to two streams (fork / join with events)
     static constexpr int MAX_CHAINS = 8;                    // launch chains in flight: tile classes x HOPE_CHAINS sub-lists
@@ -203,24 +221,10 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
                                    int32_t* tstep, int32_t* n_obst, double* traj, int32_t* traj_len, int32_t* traj_valid) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    int s = ids[k];
+    int s = ids ? ids[k] : k;
     double* c = scene_c + (size_t)s * SC_WORDS;
-    for (int i = 0; i < 3; i++) { c[SC_START + i] = start[3 * k + i]; c[SC_DEST + i] = dest[3 * k + i]; }
-    for (int i = 0; i < 4; i++) c[SC_BBOX + i] = bbox[4 * k + i];
-    double sn, ct;
-    hm_sincos(dest[3 * k + 2], &sn, &ct);
-    Box b = make_box(dest[3 * k], dest[3 * k + 1], ct, sn);       // dest.create_box()
-    for (int v = 0; v < 4; v++) { c[SC_DBOX + 2 * v] = b.x[v]; c[SC_DBOX + 2 * v + 1] = b.y[v]; }
-    // Polygon(dest_box).area: GEOS Area::ofRingSigned
-    double sum = 0.0, x0 = b.x[0];
-    for (int i = 1; i < 4; i++) sum += (b.x[i] - x0) * (b.y[i - 1] - b.y[(i + 1) & 3]);
-    c[SC_DAREA] = fabs(sum / 2.0);
-    double dx = dest[3 * k] - start[3 * k], dy = dest[3 * k + 1] - start[3 * k + 1];
-    c[SC_DNORM] = fmax(sqrt(dx * dx + dy * dy), 10.0);            // car_parking_base.py:211
-    c[SC_DCEN] = 0.5 * (b.x[0] + b.x[2]);
-    c[SC_DCEN + 1] = 0.5 * (b.y[0] + b.y[2]);
-    c[SC_DCEN + 2] = ct;
-    c[SC_DCEN + 3] = sn;
+    fill_scene_consts(c, start + 3 * k, dest + 3 * k, bbox + 4 * k);
+    if (!state) return;                                           // (pool entries: constants only)
     double* st = state + (size_t)s * ST_WORDS;
     st[0] = start[3 * k]; st[1] = start[3 * k + 1]; st[2] = start[3 * k + 2]; st[3] = 0.0;
     tstep[s] = 0;
@@ -278,30 +282,40 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
                                                const int32_t* pl1, int n1, const double* pverts, const double* pc,
                                                const int32_t* pnob, double* verts, double* scene_c, int32_t* n_obst,
                                                double* state, int32_t* tstep, double* traj, int32_t* traj_len,
-                                               int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode, float4* obb) {
+                                               int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode, float4* obb, DlpCases dlp,
+                                               int32_t* overflow, const uint8_t* slot_cls) {
+    __shared__ double c24[SC_WORDS];
     const int s = blockIdx.x, lane = threadIdx.x;
     if (!mask[s]) return;
-    const int cls = (max_obst > SMALL_TILE && n_obst[s] > SMALL_TILE) ? 1 : 0;
+    const int cls = slot_cls[s] ? 1 : 0;
     const int32_t* pl = cls ? pl1 : pl0;
     const int cnt = cls ? n1 : n0;
     const uint32_t ep = episode[s];
     __syncthreads();
     double* c = scene_c + (size_t)s * SC_WORDS;
     if (cnt > 0) {
-        const int j = pl[(int)(mix64(seed ^ mix64(((uint64_t)s << 32) | ep)) % (uint64_t)cnt)];
-        const int nob = pnob[j];
-        const double2* src = (const double2*)(pverts + (size_t)j * max_obst * 8);
-        double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
-        for (int v = lane; v < 4 * nob; v += WAVE) dst[v] = src[v];
-        for (int o = lane; o < nob; o += WAVE) obb[(size_t)s * max_obst + o] = obstacle_box(pverts + ((size_t)j * max_obst + o) * 8);
-        if (lane < SC_WORDS) c[lane] = pc[(size_t)j * SC_WORDS + lane];
+        const uint64_t key = mix64(seed ^ mix64(((uint64_t)s << 32) | ep));
+        const int j = pl[(int)(key % (uint64_t)cnt)];
+        int nob;
+        if (j >= 0) {
+            nob = pnob[j];
+            const double2* src = (const double2*)(pverts + (size_t)j * max_obst * 8);
+            double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
+            for (int v = lane; v < 4 * nob; v += WAVE) dst[v] = src[v];
+            for (int o = lane; o < nob; o += WAVE) obb[(size_t)s * max_obst + o] = obstacle_box(pverts + ((size_t)j * max_obst + o) * 8);
+            if (lane < SC_WORDS) c24[lane] = pc[(size_t)j * SC_WORDS + lane];
+        } else                                                // a Dragon-Lake-Parking case, drawn exactly as the fused turnover draws it
+            nob = draw_dlp_case(dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), max_obst, verts + (size_t)s * max_obst * 8,
+                                obb + (size_t)s * max_obst, c24, nullptr, overflow, lane);
+        __syncthreads();
+        if (lane < SC_WORDS) c[lane] = c24[lane];
         if (lane == 0) { n_obst[s] = nob; cur_pool[s] = j; }
-    }
+    } else if (lane < SC_WORDS) c24[lane] = c[lane];
     __syncthreads();
     if (lane == 0) {
         episode[s] = ep + 1;
         double* st = state + (size_t)s * ST_WORDS;
-        st[0] = c[SC_START]; st[1] = c[SC_START + 1]; st[2] = c[SC_START + 2]; st[3] = 0.0;
+        st[0] = c24[SC_START]; st[1] = c24[SC_START + 1]; st[2] = c24[SC_START + 2]; st[3] = 0.0;
         tstep[s] = 0;
         if (traj) {
             double* tr = traj + (size_t)s * BEV_TRAJ_LEN * 3;
@@ -416,6 +430,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     if (!h) return fail(HOPE_ENOMEM, "hope_env_create: host allocation failed");
     h->n = n_scenes; h->max_obst = max_obstacles; h->device = device_id; h->flags = flags;
     h->n_obst_host.assign(n_scenes, 0);
+    h->slot_cls_host.assign(n_scenes, 0);
     snprintf(h->arch, sizeof(h->arch), "%s", prop.gcnArchName);
     size_t N = (size_t)n_scenes;
 #define ALLOC(ptr, bytes)                                                                          \
@@ -446,6 +461,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->rs_rec, N * rs_rec_bytes_per_scene());
     ALLOC(h->cur_pool, N * sizeof(int32_t));
     ALLOC(h->episode, N * sizeof(uint32_t));
+    ALLOC(h->pool_overflow, sizeof(int32_t));
+    ALLOC(h->slot_cls, N);
     if (flags & HOPE_F_IMAGE) {
         ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
         ALLOC(h->traj_len, N * sizeof(int32_t));
@@ -467,6 +484,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->rs_flag, 0, N));
     HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
+    HIPCHK(hipMemset(h->pool_overflow, 0, sizeof(int32_t)));
+    HIPCHK(hipMemset(h->slot_cls, 0, N));
     if (lds > 48 * 1024) {
         for (const void* f : {(const void*)k_env_step<float, float>, (const void*)k_env_step<float, float, true>,
                               (const void*)k_env_step<float, double>, (const void*)k_env_step<double, float>,
@@ -516,9 +535,12 @@ int hope_env_destroy(hope_env_t* h) {
         if (h->side[i]) hipStreamDestroy(h->side[i]);
     }
     if (h->gstream) hipStreamDestroy(h->gstream);
+    if (h->pool_stream) hipStreamDestroy(h->pool_stream);
+    for (hipEvent_t e : {h->ev_pool_ready, h->ev_pool_copied, h->ev_last_step}) if (e) hipEventDestroy(e);
+    for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->obb, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pool_verts, h->pool_c, h->pool_nobst, h->pool_state, h->pool_t, h->pool_cls[0], h->pool_cls[1], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -596,6 +618,38 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
                          const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
                          int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid);
 
+// The dense per-class scene lists of the launch chains and the per-slot class byte (host mirror; reset-time only).  A slot's class
+// decides which launch chain steps it (LDS tile of 32 or max_obstacles obstacles) AND which pool entries it draws at episode
+// turnover: by default the size class of the map hope_env_set_scenes gave it, or what hope_env_set_draw_class says.
+static int rebuild_class_lists(hope_env_t* h) {
+    std::vector<int32_t> l0, l1;
+    l0.reserve(h->n); l1.reserve(h->n);
+    const bool two = h->max_obst > SMALL_TILE;
+    for (int i = 0; i < h->n; i++) (two && h->slot_cls_host[i] ? l1 : l0).push_back(i);
+    // Two launch chains run concurrently (HOPE_F_OVERLAP): the step ends with the longer one running alone.  A scene with
+    // few obstacles may run in the large-tile launches too (it only gets more LDS than it needs), so the small-tile class
+    // hands scenes over until the large-tile chain holds `frac` of all scenes (HOPE_CLS1_FRAC, default below).  (The handed-over
+    // slots keep their class byte: they go on drawing small lots.)
+    if (two && (h->flags & HOPE_F_OVERLAP)) {
+        const char* fr = getenv("HOPE_CLS1_FRAC");
+        // measured (mixed scene set, 25 % large-tile scenes by themselves): 0.42 gives +1 / +4 / +4 % at 4 096 / 8 192 / 16 384
+        // scenes, 0 at 32 768, -3 % at 65 536 (the moved scenes lose occupancy there and nothing is left to hide)
+        const double frac = fr ? atof(fr) : (h->n < 32768 ? 0.42 : 0.0);
+        const size_t want1 = (size_t)(frac * h->n);
+        if (l1.size() < want1) {
+            const size_t move = std::min(l0.size(), want1 - l1.size());
+            l1.insert(l1.end(), l0.end() - move, l0.end());
+            l0.resize(l0.size() - move);
+            std::sort(l1.begin(), l1.end());
+        }
+    }
+    h->cls_count[0] = (int)l0.size(); h->cls_count[1] = (int)l1.size();
+    if (!l0.empty()) HIPCHK(hipMemcpy(h->cls_list[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!l1.empty()) HIPCHK(hipMemcpy(h->cls_list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->slot_cls, h->slot_cls_host.data(), (size_t)h->n, hipMemcpyHostToDevice));
+    return HOPE_OK;
+}
+
 int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const double* start, const double* dest,
                         const double* bbox, const double* verts, const int32_t* n_obst) {
     if (!h || n < 0 || (n > 0 && (!scene_ids || !start || !dest || !bbox || !n_obst)))
@@ -613,33 +667,11 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
                                h->verts, h->obb, h->traj, h->traj_len, h->traj_valid);
         if (rc != HOPE_OK) return rc;
     }
-    // rebuild the dense per-class scene lists (host mirror of n_obst; N ints, reset-time only)
-    for (int k = 0; k < n; k++) h->n_obst_host[scene_ids[k]] = n_obst[k];
-    {
-        std::vector<int32_t> l0, l1;
-        l0.reserve(h->n); l1.reserve(h->n);
-        const bool two = h->max_obst > SMALL_TILE;
-        for (int i = 0; i < h->n; i++) (two && h->n_obst_host[i] > SMALL_TILE ? l1 : l0).push_back(i);
-        // Two launch chains run concurrently (HOPE_F_OVERLAP): the step ends with the longer one running alone.  A scene with
-        // few obstacles may run in the large-tile launches too (it only gets more LDS than it needs), so the small-tile class
-        // hands scenes over until the large-tile chain holds `frac` of all scenes (HOPE_CLS1_FRAC, default below).
-        if (two && (h->flags & HOPE_F_OVERLAP)) {
-            const char* fr = getenv("HOPE_CLS1_FRAC");
-            // measured (mixed scene set, 25 % large-tile scenes by themselves): 0.42 gives +1 / +4 / +4 % at 4 096 / 8 192 / 16 384
-            // scenes, 0 at 32 768, -3 % at 65 536 (the moved scenes lose occupancy there and nothing is left to hide)
-            const double frac = fr ? atof(fr) : (h->n < 32768 ? 0.42 : 0.0);
-            const size_t want1 = (size_t)(frac * h->n);
-            if (l1.size() < want1) {
-                const size_t move = std::min(l0.size(), want1 - l1.size());
-                l1.insert(l1.end(), l0.end() - move, l0.end());
-                l0.resize(l0.size() - move);
-                std::sort(l1.begin(), l1.end());
-            }
-        }
-        h->cls_count[0] = (int)l0.size(); h->cls_count[1] = (int)l1.size();
-        if (!l0.empty()) HIPCHK(hipMemcpy(h->cls_list[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        if (!l1.empty()) HIPCHK(hipMemcpy(h->cls_list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    for (int k = 0; k < n; k++) {
+        h->n_obst_host[scene_ids[k]] = n_obst[k];
+        h->slot_cls_host[scene_ids[k]] = (h->max_obst > SMALL_TILE && n_obst[k] > SMALL_TILE) ? 1 : 0;
     }
+    { int rc = rebuild_class_lists(h); if (rc != HOPE_OK) return rc; }
     HIPCHK(hipDeviceSynchronize());
     drop_graphs(h);                                         // grids depend on the class sizes
     h->have_scenes = true;
@@ -661,8 +693,10 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     p.pool_verts = h->pool_verts; p.pool_c = h->pool_c; p.pool_nobst = h->pool_nobst;
     p.pool_cls[0] = h->pool_cls[0]; p.pool_cls[1] = h->pool_cls[1]; p.pool_cls_n[0] = h->pool_cls_n[0]; p.pool_cls_n[1] = h->pool_cls_n[1];
     p.cur_pool = h->cur_pool; p.episode = h->episode; p.redraw_seed = h->redraw_seed;
+    p.dlp = h->dlp; p.pool_overflow = h->pool_overflow; p.slot_cls = h->slot_cls;
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 block(WAVE);
+
     // One chain of launches per tile class (scenes with few obstacles get a small LDS tile and therefore more resident
     // waves): k_env_step -> k_rs_compact -> k_rs_words -> k_rs_validate.  The chains share nothing but read-only data
     // (own scene list, own queue counter, record slots filled from opposite ends), so with a side stream they run
@@ -806,6 +840,19 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     return HOPE_OK;
 }
 
+// A scene draws its next map from the pool entries of ITS tile class (the dense per-class launch lists are fixed between
+// hope_env_set_scenes calls).  A resident class without entries would silently keep its maps: refuse instead.
+static int check_pool_classes(hope_env_t* h, const char* who) {
+    bool resident[2] = {false, false};
+    for (int i = 0; i < h->n; i++) resident[h->slot_cls_host[i] ? 1 : 0] = true;
+    for (int c = 0; c < 2; c++)
+        if (resident[c] && h->pool_cls_n[c] == 0)
+            return fail(HOPE_ESTATE, std::string(who) + ": scene slots of the " + (c ? "large" : "small (<= 32 obstacles)") +
+                                     " size class are resident but the pool holds no map of that size class (a slot draws from its own class: "
+                                     "hope_env_set_pool / hope_env_set_dlp_cases / hope_env_set_draw_class)");
+    return HOPE_OK;
+}
+
 static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages,
                        const hope_step_out* out, void* stream, int has_action) {
     if (!h || !out) return fail(HOPE_EINVAL, "hope_env_step: null argument");
@@ -815,7 +862,9 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (stages & HOPE_STAGE_RS) stages |= HOPE_STAGE_REWARD;       // the RS gate needs the status
     if (stages & HOPE_AUTO_REDRAW) {
         if (!(stages & HOPE_AUTO_RESET)) return fail(HOPE_EINVAL, "hope_env_step: HOPE_AUTO_REDRAW needs HOPE_AUTO_RESET");
-        if (h->pool_n <= 0) return fail(HOPE_ESTATE, "hope_env_step: HOPE_AUTO_REDRAW without a scene pool (hope_env_set_pool)");
+        if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_step: HOPE_AUTO_REDRAW without a scene pool (hope_env_set_pool / hope_env_set_dlp_cases)");
+        int rc0 = check_pool_classes(h, "hope_env_step");
+        if (rc0 != HOPE_OK) return rc0;
     }
     if (stages & HOPE_STAGE_IMG) {
         if (!h->traj) return fail(HOPE_ESTATE, "hope_env_step: HOPE_STAGE_IMG needs a handle created with HOPE_F_IMAGE");
@@ -826,6 +875,14 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     hipStream_t s = (hipStream_t)stream;
     const bool prof = h->flags & HOPE_F_PROFILE;
     h->step_seq++;
+    if (h->pool_wait_pending) {                             // a pool committed since the last launch: its upload orders before this step
+        HIPCHK(hipStreamWaitEvent(s, h->ev_pool_ready, 0));
+        h->pool_wait_pending = false;
+    }
+    struct LastStep {                                       // (the next pool upload must not overwrite a set this step still reads)
+        hope_env_t* h; hipStream_t s;
+        ~LastStep() { if (h->pactive >= 0 && h->ev_last_step) hipEventRecord(h->ev_last_step, s); }
+    } last_step{h, s};
     if (h->flags & HOPE_F_GRAPH) {
         // The caller's stream may be the null stream, which cannot be captured: the graph lives on a library stream that
         // is ordered after / before the caller's stream with two events.
@@ -903,51 +960,241 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
     return HOPE_OK;
 }
 
+// ---- scene pool: pinned staging -> asynchronous upload into the set the kernels are not reading -> swap by stream order ----
+static int pool_init_streams(hope_env_t* h) {
+    if (h->pool_stream) return HOPE_OK;
+    HIPCHK(hipStreamCreateWithFlags(&h->pool_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_pool_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_pool_copied, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_last_step, hipEventDisableTiming));
+    return HOPE_OK;
+}
+
+// draw lists of the two size classes into pinned staging: complete pool scenes by their obstacle count, and -- in the large class
+// -- the device-drawn Dragon-Lake cases as -2 - case (-1 is "the map hope_env_set_scenes uploaded")
+static void build_pool_lists(hope_env_t* h, const int32_t* n_obst, int n_pool, std::vector<int32_t>& l0, std::vector<int32_t>& l1) {
+    const bool two = h->max_obst > SMALL_TILE;
+    for (int k = 0; k < n_pool; k++) (two && n_obst[k] > SMALL_TILE ? l1 : l0).push_back(k);
+    for (int c = 0; c < h->dlp.n_cases; c++) (two ? l1 : l0).push_back(-2 - c);
+}
+
+static int pool_set_reserve(hope_env_t* h, hope_env::PoolSet& ps, int n_pool, int n_list) {
+    if (n_pool > ps.cap) {
+        for (void* q : {(void*)ps.verts, (void*)ps.c, (void*)ps.nobst}) if (q) hipFree(q);
+        ps.verts = ps.c = nullptr; ps.nobst = nullptr; ps.cap = 0;
+        const size_t P = (size_t)n_pool;
+        hipError_t e_ = hipMalloc((void**)&ps.verts, P * h->max_obst * 8 * sizeof(double));
+        if (e_ == hipSuccess) e_ = hipMalloc((void**)&ps.c, P * SC_WORDS * sizeof(double));
+        if (e_ == hipSuccess) e_ = hipMalloc((void**)&ps.nobst, P * sizeof(int32_t));
+        if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc pool: ") + hipGetErrorString(e_));
+        ps.cap = n_pool;
+    }
+    if (n_list > ps.list_cap) {
+        for (int c = 0; c < 2; c++) { if (ps.list[c]) hipFree(ps.list[c]); ps.list[c] = nullptr; }
+        for (int c = 0; c < 2; c++) {
+            hipError_t e_ = hipMalloc((void**)&ps.list[c], (size_t)n_list * sizeof(int32_t));
+            if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc pool lists: ") + hipGetErrorString(e_));
+        }
+        ps.list_cap = n_list;
+    }
+    return HOPE_OK;
+}
+
+int hope_env_pool_staging(hope_env_t* h, int n_pool, double** start, double** dest, double** bbox, double** verts, int32_t** n_obst) {
+    if (!h || n_pool <= 0 || !start || !dest || !bbox || !verts || !n_obst) return fail(HOPE_EINVAL, "hope_env_pool_staging: bad argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    int rc = pool_init_streams(h);
+    if (rc != HOPE_OK) return rc;
+    if (h->pstage.busy) { HIPCHK(hipEventSynchronize(h->ev_pool_copied)); h->pstage.busy = false; }   // the previous upload still reads it
+    if (n_pool > h->pstage.cap) {
+        for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list})
+            if (q) hipHostFree(q);
+        h->pstage = hope_env::PoolStage{};
+        const size_t P = (size_t)n_pool;
+        hipError_t e_ = hipHostMalloc((void**)&h->pstage.start, P * 24);
+        if (e_ == hipSuccess) e_ = hipHostMalloc((void**)&h->pstage.dest, P * 24);
+        if (e_ == hipSuccess) e_ = hipHostMalloc((void**)&h->pstage.bbox, P * 32);
+        if (e_ == hipSuccess) e_ = hipHostMalloc((void**)&h->pstage.verts, P * h->max_obst * 8 * sizeof(double));
+        if (e_ == hipSuccess) e_ = hipHostMalloc((void**)&h->pstage.nobst, P * sizeof(int32_t));
+        if (e_ == hipSuccess) e_ = hipHostMalloc((void**)&h->pstage.list, (P + 4096) * sizeof(int32_t));
+        if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipHostMalloc pool staging: ") + hipGetErrorString(e_));
+        h->pstage.cap = n_pool;
+    }
+    *start = h->pstage.start; *dest = h->pstage.dest; *bbox = h->pstage.bbox; *verts = h->pstage.verts; *n_obst = h->pstage.nobst;
+    return HOPE_OK;
+}
+
+int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
+    if (!h || n_pool <= 0) return fail(HOPE_EINVAL, "hope_env_commit_pool: bad argument");
+    if (n_pool > h->pstage.cap) return fail(HOPE_ESTATE, "hope_env_commit_pool: more entries than hope_env_pool_staging provided");
+    for (int k = 0; k < n_pool; k++)
+        if (h->pstage.nobst[k] < 0 || h->pstage.nobst[k] > h->max_obst) return fail(HOPE_EINVAL, "hope_env_commit_pool: n_obst exceeds max_obstacles");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    std::vector<int32_t> l0, l1;
+    build_pool_lists(h, h->pstage.nobst, n_pool, l0, l1);
+    if ((int)(l0.size() + l1.size()) > h->pstage.cap + 4096) return fail(HOPE_EINVAL, "hope_env_commit_pool: too many Dragon-Lake cases for the list staging");
+    const int t = h->pactive < 0 ? 0 : 1 - h->pactive;
+    hope_env::PoolSet& ps = h->pset[t];
+    int rc = pool_set_reserve(h, ps, n_pool, (int)std::max(l0.size(), l1.size()) + 1);
+    if (rc != HOPE_OK) return rc;
+    if (3 * 32 * n_pool / 8 > h->pstage_dev_cap) {           // start | dest | bbox: 24 + 24 + 32 bytes per entry
+        if (h->pstage_dev) hipFree(h->pstage_dev);
+        h->pstage_dev = nullptr; h->pstage_dev_cap = 0;
+        hipError_t e_ = hipMalloc((void**)&h->pstage_dev, (size_t)n_pool * 80);
+        if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc pool staging: ") + hipGetErrorString(e_));
+        h->pstage_dev_cap = 12 * n_pool;
+    }
+    hipStream_t us = h->pool_stream;
+    // the target set was the active one until the previous swap: steps enqueued before that swap may still be reading it
+    if (h->pactive >= 0) HIPCHK(hipStreamWaitEvent(us, h->ev_last_step, 0));
+    const size_t P = (size_t)n_pool;
+    char* dv = (char*)h->pstage_dev;
+    HIPCHK(hipMemcpyAsync(ps.verts, h->pstage.verts, P * h->max_obst * 8 * sizeof(double), hipMemcpyHostToDevice, us));
+    HIPCHK(hipMemcpyAsync(ps.nobst, h->pstage.nobst, P * sizeof(int32_t), hipMemcpyHostToDevice, us));
+    HIPCHK(hipMemcpyAsync(dv, h->pstage.start, P * 24, hipMemcpyHostToDevice, us));
+    HIPCHK(hipMemcpyAsync(dv + P * 24, h->pstage.dest, P * 24, hipMemcpyHostToDevice, us));
+    HIPCHK(hipMemcpyAsync(dv + P * 48, h->pstage.bbox, P * 32, hipMemcpyHostToDevice, us));
+    memcpy(h->pstage.list, l0.data(), l0.size() * sizeof(int32_t));
+    memcpy(h->pstage.list + l0.size(), l1.data(), l1.size() * sizeof(int32_t));
+    if (!l0.empty()) HIPCHK(hipMemcpyAsync(ps.list[0], h->pstage.list, l0.size() * sizeof(int32_t), hipMemcpyHostToDevice, us));
+    if (!l1.empty()) HIPCHK(hipMemcpyAsync(ps.list[1], h->pstage.list + l0.size(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice, us));
+    HIPCHK(hipEventRecord(h->ev_pool_copied, us));          // the pinned staging may be refilled once this has passed
+    h->pstage.busy = true;
+    hipLaunchKernelGGL(k_set_scene_consts, dim3((n_pool + 127) / 128), dim3(128), 0, us, n_pool, (const int32_t*)nullptr,
+                       (const double*)dv, (const double*)(dv + P * 24), (const double*)(dv + P * 48), (const int32_t*)nullptr, ps.c,
+                       (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev_pool_ready, us));
+    // swap: every launch enqueued from now on reads the new set, after waiting (on its own stream) for the upload
+    h->pool_verts = ps.verts; h->pool_c = ps.c; h->pool_nobst = ps.nobst;
+    h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
+    h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
+    h->pool_n = n_pool;
+    h->pool_nobst_host.assign(h->pstage.nobst, h->pstage.nobst + n_pool);
+    h->pactive = t;
+    h->pool_wait_pending = true;
+    (void)stream;
+    drop_graphs(h);                                         // the pool pointers are kernel arguments of the captured launches
+    return HOPE_OK;
+}
+
 int hope_env_set_pool(hope_env_t* h, int n_pool, const double* start, const double* dest, const double* bbox,
                       const double* verts, const int32_t* n_obst) {
     if (!h || n_pool <= 0 || !start || !dest || !bbox || !verts || !n_obst) return fail(HOPE_EINVAL, "hope_env_set_pool: bad argument");
     for (int k = 0; k < n_pool; k++)
         if (n_obst[k] < 0 || n_obst[k] > h->max_obst) return fail(HOPE_EINVAL, "hope_env_set_pool: n_obst exceeds max_obstacles");
+    double *ps, *pd, *pb, *pv;
+    int32_t* pn;
+    int rc = hope_env_pool_staging(h, n_pool, &ps, &pd, &pb, &pv, &pn);
+    if (rc != HOPE_OK) return rc;
+    const size_t P = (size_t)n_pool;
+    memcpy(ps, start, P * 24); memcpy(pd, dest, P * 24); memcpy(pb, bbox, P * 32);
+    memcpy(pv, verts, P * h->max_obst * 8 * sizeof(double)); memcpy(pn, n_obst, P * sizeof(int32_t));
+    rc = hope_env_commit_pool(h, n_pool, nullptr);
+    if (rc != HOPE_OK) return rc;
+    DeviceGuard guard(h->device);
+    HIPCHK(hipStreamSynchronize(h->pool_stream));           // the synchronous form: the caller's arrays are free on return anyway
+    return HOPE_OK;
+}
+
+// the class lists of the ACTIVE set after the Dragon-Lake cases changed (rare; host-synchronous)
+static int refresh_pool_lists_sync(hope_env_t* h) {
+    int rc = pool_init_streams(h);
+    if (rc != HOPE_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int32_t> l0, l1;
+    build_pool_lists(h, h->pool_nobst_host.data(), h->pool_n, l0, l1);
+    if (h->pactive < 0) h->pactive = 0;
+    hope_env::PoolSet& ps = h->pset[h->pactive];
+    rc = pool_set_reserve(h, ps, std::max(h->pool_n, ps.cap), (int)std::max(l0.size(), l1.size()) + 1);
+    if (rc != HOPE_OK) return rc;
+    if (!l0.empty()) HIPCHK(hipMemcpy(ps.list[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!l1.empty()) HIPCHK(hipMemcpy(ps.list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
+    h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
+    drop_graphs(h);
+    return HOPE_OK;
+}
+
+int hope_env_set_dlp_cases(hope_env_t* h, int n_cases, const double* dest, const int32_t* cand_off, const double* cand,
+                           const int32_t* case_set, int n_sets, const int32_t* set_off, const double* set_verts) {
+    if (!h || n_cases < 0 || (n_cases > 0 && (!dest || !cand_off || !cand || !case_set || n_sets <= 0 || !set_off || !set_verts)))
+        return fail(HOPE_EINVAL, "hope_env_set_dlp_cases: bad argument");
+    for (int c = 0; c < n_cases; c++) {
+        if (cand_off[c + 1] <= cand_off[c]) return fail(HOPE_EINVAL, "hope_env_set_dlp_cases: a case without start candidates");
+        if (case_set[c] < 0 || case_set[c] >= n_sets) return fail(HOPE_EINVAL, "hope_env_set_dlp_cases: case_set out of range");
+    }
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     HIPCHK(hipDeviceSynchronize());
-    for (void* q : {(void*)h->pool_verts, (void*)h->pool_c, (void*)h->pool_nobst, (void*)h->pool_state, (void*)h->pool_t,
-                    (void*)h->pool_cls[0], (void*)h->pool_cls[1]})
-        if (q) hipFree(q);
-    h->pool_verts = h->pool_c = h->pool_state = nullptr; h->pool_nobst = h->pool_t = h->pool_cls[0] = h->pool_cls[1] = nullptr;
-    h->pool_n = 0;
-#define PALLOC(ptr, bytes)                                                                       \
-    do {                                                                                         \
-        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                      \
-        if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc pool: ") + hipGetErrorString(e_)); \
-    } while (0)
-    const size_t P = (size_t)n_pool;
-    PALLOC(h->pool_verts, P * h->max_obst * 8 * sizeof(double));
-    PALLOC(h->pool_c, P * SC_WORDS * sizeof(double));
-    PALLOC(h->pool_nobst, P * sizeof(int32_t));
-    PALLOC(h->pool_state, P * ST_WORDS * sizeof(double));
-    PALLOC(h->pool_t, P * sizeof(int32_t));
-    PALLOC(h->pool_cls[0], P * sizeof(int32_t));
-    PALLOC(h->pool_cls[1], P * sizeof(int32_t));
-#undef PALLOC
-    const int chunk = 4096;
-    std::vector<int32_t> ids(chunk);
-    for (int a = 0; a < n_pool; a += chunk) {
-        const int m = std::min(chunk, n_pool - a);
-        for (int k = 0; k < m; k++) ids[k] = a + k;
-        int rc = upload_scenes(h, ids.data(), m, start + 3 * (size_t)a, dest + 3 * (size_t)a, bbox + 4 * (size_t)a,
-                               verts + (size_t)a * h->max_obst * 8, n_obst + a, h->pool_c, h->pool_state, h->pool_t,
-                               h->pool_nobst, h->pool_verts, nullptr, nullptr, nullptr, nullptr);
-        if (rc != HOPE_OK) return rc;
+    for (void*& q : h->dlp_mem) { if (q) hipFree(q); q = nullptr; }
+    h->dlp = DlpCases{};
+    if (n_cases > 0) {
+        const size_t nc = (size_t)cand_off[n_cases], nv = (size_t)set_off[n_sets];
+        const void* src[6] = {dest, cand_off, cand, case_set, set_off, set_verts};
+        const size_t bytes[6] = {sizeof(double) * 3 * n_cases, sizeof(int32_t) * (n_cases + 1), sizeof(double) * 3 * nc,
+                                 sizeof(int32_t) * n_cases, sizeof(int32_t) * (n_sets + 1), sizeof(double) * 8 * nv};
+        for (int i = 0; i < 6; i++) {
+            hipError_t e_ = hipMalloc(&h->dlp_mem[i], bytes[i]);
+            if (e_ != hipSuccess) return fail(HOPE_ENOMEM, std::string("hipMalloc dlp cases: ") + hipGetErrorString(e_));
+            HIPCHK(hipMemcpy(h->dlp_mem[i], src[i], bytes[i], hipMemcpyHostToDevice));
+        }
+        h->dlp.n_cases = n_cases;
+        h->dlp.dest = (const double*)h->dlp_mem[0]; h->dlp.cand_off = (const int32_t*)h->dlp_mem[1];
+        h->dlp.cand = (const double*)h->dlp_mem[2]; h->dlp.case_set = (const int32_t*)h->dlp_mem[3];
+        h->dlp.set_off = (const int32_t*)h->dlp_mem[4]; h->dlp.set_verts = (const double*)h->dlp_mem[5];
     }
-    std::vector<int32_t> l0, l1;
-    const bool two = h->max_obst > SMALL_TILE;
-    for (int k = 0; k < n_pool; k++) (two && n_obst[k] > SMALL_TILE ? l1 : l0).push_back(k);
-    h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
-    if (!l0.empty()) HIPCHK(hipMemcpy(h->pool_cls[0], l0.data(), l0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (!l1.empty()) HIPCHK(hipMemcpy(h->pool_cls[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->pool_n = n_pool;
-    drop_graphs(h);                                         // the pool pointers are kernel arguments of the captured launches
+    return refresh_pool_lists_sync(h);
+}
+
+int hope_env_set_draw_class(hope_env_t* h, const int32_t* scene_ids, int n, const uint8_t* cls) {
+    if (!h || n < 0 || (n > 0 && (!scene_ids || !cls))) return fail(HOPE_EINVAL, "hope_env_set_draw_class: null argument");
+    if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_set_draw_class: hope_env_set_scenes has not been called");
+    for (int k = 0; k < n; k++) {
+        if (scene_ids[k] < 0 || scene_ids[k] >= h->n) return fail(HOPE_EINVAL, "hope_env_set_draw_class: scene id out of range");
+        if (!cls[k] && h->n_obst_host[scene_ids[k]] > SMALL_TILE)
+            return fail(HOPE_EINVAL, "hope_env_set_draw_class: a scene with more than 32 obstacles cannot join the small class");
+    }
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < n; k++) h->slot_cls_host[scene_ids[k]] = (cls[k] && h->max_obst > SMALL_TILE) ? 1 : 0;
+    int rc = rebuild_class_lists(h);
+    if (rc != HOPE_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    drop_graphs(h);
+    return HOPE_OK;
+}
+
+int hope_env_pool_overflow(hope_env_t* h, int32_t* count) {
+    if (!h || !count) return fail(HOPE_EINVAL, "hope_env_pool_overflow: null argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(count, h->pool_overflow, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HOPE_OK;
+}
+
+// the maps the scenes hold NOW (after device-side draws they exist on the device only): host-synchronous
+int hope_env_download_scenes(hope_env_t* h, const int32_t* scene_ids, int n, double* start, double* dest, double* bbox, double* verts,
+                             int32_t* n_obst) {
+    if (!h || n < 0 || (n > 0 && !scene_ids)) return fail(HOPE_EINVAL, "hope_env_download_scenes: bad argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t tile = (size_t)h->max_obst * 8;
+    std::vector<double> c(SC_WORDS);
+    for (int k = 0; k < n; k++) {
+        const int s_ = scene_ids[k];
+        if (s_ < 0 || s_ >= h->n) return fail(HOPE_EINVAL, "hope_env_download_scenes: scene id out of range");
+        HIPCHK(hipMemcpy(c.data(), h->scene_c + (size_t)s_ * SC_WORDS, SC_WORDS * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; i++) { if (start) start[3 * (size_t)k + i] = c[SC_START + i]; if (dest) dest[3 * (size_t)k + i] = c[SC_DEST + i]; }
+        for (int i = 0; i < 4; i++) if (bbox) bbox[4 * (size_t)k + i] = c[SC_BBOX + i];
+        if (verts) HIPCHK(hipMemcpy(verts + (size_t)k * tile, h->verts + (size_t)s_ * tile, tile * sizeof(double), hipMemcpyDeviceToHost));
+        if (n_obst) HIPCHK(hipMemcpy(n_obst + k, h->n_obst + s_, sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return HOPE_OK;
 }
 
@@ -961,14 +1208,50 @@ int hope_env_set_redraw_seed(hope_env_t* h, uint64_t seed) {
 int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* stream) {
     if (!h || !mask) return fail(HOPE_EINVAL, "hope_env_redraw: null argument");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_redraw: hope_env_set_scenes has not been called");
-    if (h->pool_n <= 0) return fail(HOPE_ESTATE, "hope_env_redraw: hope_env_set_pool has not been called");
+    if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_redraw: no scene pool (hope_env_set_pool / hope_env_set_dlp_cases)");
+    int rc0 = check_pool_classes(h, "hope_env_redraw");
+    if (rc0 != HOPE_OK) return rc0;
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    if (h->pool_wait_pending) { HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_pool_ready, 0)); h->pool_wait_pending = false; }
     hipLaunchKernelGGL(k_redraw, dim3(h->n), dim3(WAVE), 0, (hipStream_t)stream, h->max_obst, mask, seed, h->pool_cls[0],
                        h->pool_cls_n[0], h->pool_cls[1], h->pool_cls_n[1], h->pool_verts, h->pool_c, h->pool_nobst, h->verts,
-                       h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode, h->obb);
+                       h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode, h->obb,
+                       h->dlp, h->pool_overflow, h->slot_cls);
     HIPCHK(hipGetLastError());
+    if (h->pactive >= 0 && h->ev_last_step) HIPCHK(hipEventRecord(h->ev_last_step, (hipStream_t)stream));
     return HOPE_OK;
+}
+
+// Snapshot / restore of the map each scene holds after device-side draws.  A draw is a pure function of (seed, scene, episode
+// counter) and of the pool / case lists, so a map is restored by repeating its draw: the counters go back by one and k_redraw runs
+// for the scenes that held a drawn map.  Pose / t / accumulator are restored separately (hope_env_upload_state, afterwards).
+int hope_env_download_pool_state(hope_env_t* h, int32_t* pool_index, uint32_t* episode) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_download_pool_state: null handle");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    if (pool_index) HIPCHK(hipMemcpy(pool_index, h->cur_pool, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (episode) HIPCHK(hipMemcpy(episode, h->episode, (size_t)h->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HOPE_OK;
+}
+
+int hope_env_restore_maps(hope_env_t* h, const uint8_t* drawn /* host [N]: the scene held a drawn map */, const uint32_t* episode, uint64_t seed) {
+    if (!h || !drawn || !episode) return fail(HOPE_EINVAL, "hope_env_restore_maps: null argument");
+    if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_restore_maps: no scene pool");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<uint32_t> ep(episode, episode + h->n);
+    for (int i = 0; i < h->n; i++) if (drawn[i]) { if (ep[i] == 0) return fail(HOPE_EINVAL, "hope_env_restore_maps: a drawn scene with episode counter 0"); ep[i] -= 1; }
+    HIPCHK(hipMemcpy(h->episode, ep.data(), (size_t)h->n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    uint8_t* dmask = nullptr;
+    HIPCHK(hipMalloc((void**)&dmask, (size_t)h->n));
+    hipError_t e = hipMemcpy(dmask, drawn, (size_t)h->n, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? hope_env_redraw(h, dmask, seed, nullptr) : fail(HOPE_EHIP, "hipMemcpy mask");
+    hipDeviceSynchronize();
+    hipFree(dmask);
+    return rc;
 }
 
 int hope_env_download_pool_index(hope_env_t* h, int32_t* out) {

@@ -19,6 +19,106 @@
 
 namespace hope {
 
+// Dragon-Lake-Parking cases resident on the device (hope_env_set_dlp_cases): what ParkingMapDLP.reset draws from
+// (src/env/parking_map_dlp.py:38-86).  A pool list entry j <= -2 names case -2 - j.
+struct DlpCases {
+    int n_cases;
+    const double* dest;       // [n_cases][3]
+    const int32_t* cand_off;  // [n_cases + 1] start candidates of case c: cand[cand_off[c] .. cand_off[c + 1])
+    const double* cand;       // [][3]
+    const int32_t* case_set;  // [n_cases] obstacle set of the case
+    const int32_t* set_off;   // [n_sets + 1]
+    const double* set_verts;  // [][4][2] obstacle rings of all sets (a triangle repeats its last vertex)
+};
+
+// the per-scene constant record from (start, dest, map box): what hope_env_set_scenes computes per scene
+__device__ __forceinline__ void fill_scene_consts(double* c, const double* start, const double* dest, const double* bbox) {
+    for (int i = 0; i < 3; i++) { c[SC_START + i] = start[i]; c[SC_DEST + i] = dest[i]; }
+    for (int i = 0; i < 4; i++) c[SC_BBOX + i] = bbox[i];
+    double sn, ct;
+    hm_sincos(dest[2], &sn, &ct);
+    Box b = make_box(dest[0], dest[1], ct, sn);                   // dest.create_box()
+    for (int v = 0; v < 4; v++) { c[SC_DBOX + 2 * v] = b.x[v]; c[SC_DBOX + 2 * v + 1] = b.y[v]; }
+    double sum = 0.0, x0 = b.x[0];                                // Polygon(dest_box).area: GEOS Area::ofRingSigned
+    for (int i = 1; i < 4; i++) sum += (b.x[i] - x0) * (b.y[i - 1] - b.y[(i + 1) & 3]);
+    c[SC_DAREA] = fabs(sum / 2.0);
+    double dx = dest[0] - start[0], dy = dest[1] - start[1];
+    c[SC_DNORM] = fmax(sqrt(dx * dx + dy * dy), 10.0);            // car_parking_base.py:211
+    c[SC_DCEN] = 0.5 * (b.x[0] + b.x[2]);
+    c[SC_DCEN + 1] = 0.5 * (b.y[0] + b.y[2]);
+    c[SC_DCEN + 2] = ct;
+    c[SC_DCEN + 3] = sn;
+}
+
+// uniform in [0, 1) number i of the counter-based stream `key`
+__device__ __forceinline__ double draw_uniform(uint64_t key, int i) {
+    return (double)(mix64(key + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ParkingMapDLP.reset (parking_map_dlp.py:38-86) for case `cs`, by one wave: a start candidate drawn uniformly + N(0, 0.05^2) m /
+// N(0, 0.02^2) rad jitter (:60-65), the map box floor / ceil(min / max(start, dest) -/+ 20) (:70-73), the case's obstacles
+// culled by that box in their order (filter_obstacles :88-101), then independent 50 % flips of dest and start about their box
+// centres (:80-83, _flip_box_orientation :117-123).  Writes the scene's tile (and its LDS copy when ltile != null), obstacle
+// boxes and the constant record `c24` (24 doubles, LDS or global, written by lane 0); returns the obstacle count.
+__device__ __forceinline__ int draw_dlp_case(const DlpCases& D, int cs, uint64_t key, int max_obst, double* gverts, float4* gobb,
+                                             double* c24, double* ltile, int32_t* overflow, int lane) {
+    const int c0 = D.cand_off[cs], n_c = D.cand_off[cs + 1] - c0;
+    int ci = (int)(draw_uniform(key, 0) * n_c);
+    ci = ci < n_c ? ci : n_c - 1;
+    double st[3], de[3];
+    for (int i = 0; i < 3; i++) { st[i] = D.cand[3 * (size_t)(c0 + ci) + i]; de[i] = D.dest[3 * (size_t)cs + i]; }
+    {   // three standard normals (Box-Muller on two pairs of uniforms)
+        const double u1 = fmax(draw_uniform(key, 1), 1e-300), u2 = draw_uniform(key, 2);
+        const double u3 = fmax(draw_uniform(key, 3), 1e-300), u4 = draw_uniform(key, 4);
+        double s2, c2, s4, c4;
+        hm_sincos(2.0 * PI * u2, &s2, &c2);
+        hm_sincos(2.0 * PI * u4, &s4, &c4);
+        const double r1 = sqrt(-2.0 * log(u1)), r3 = sqrt(-2.0 * log(u3));
+        st[0] += 0.05 * (r1 * c2); st[1] += 0.05 * (r1 * s2); st[2] += 0.02 * (r3 * c4);
+        (void)s4;
+    }
+    double bb[4] = {floor(fmin(st[0], de[0]) - 20.0), ceil(fmax(st[0], de[0]) + 20.0),
+                    floor(fmin(st[1], de[1]) - 20.0), ceil(fmax(st[1], de[1]) + 20.0)};
+    // cull, keeping the order of the set
+    const int so = D.case_set[cs], a = D.set_off[so], n_set = D.set_off[so + 1] - a;
+    int cnt = 0;
+    for (int base = 0; base < n_set; base += WAVE) {
+        const int o = base + lane;
+        bool keep = false;
+        double v[8];
+        if (o < n_set) {
+            const double2* src = (const double2*)(D.set_verts + 8 * (size_t)(a + o));
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const double2 q = src[k]; v[2 * k] = q.x; v[2 * k + 1] = q.y; }
+            const double mnx = fmin(fmin(v[0], v[2]), fmin(v[4], v[6])), mxx = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+            const double mny = fmin(fmin(v[1], v[3]), fmin(v[5], v[7])), mxy = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+            keep = !(mxx <= bb[0] || mnx >= bb[1] || mxy <= bb[2] || mny >= bb[3]);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1));
+        if (keep && pos < max_obst) {
+            double2* dst = (double2*)(gverts + 8 * (size_t)pos);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[k] = make_double2(v[2 * k], v[2 * k + 1]);
+            if (ltile) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) ltile[8 * pos + k] = v[k];
+            }
+            gobb[pos] = obstacle_box(v);
+        }
+        cnt += __popcll(m);
+    }
+    if (cnt > max_obst) { if (lane == 0 && overflow) atomicAdd(overflow, 1); cnt = max_obst; }
+    if (lane == 0) {
+        // flips about the box centre: the centre is pose + R(yaw) (mid, 0), the flipped pose its mirror image, heading + pi
+        const double mid = 0.5 * (CAR_XF + CAR_XR);
+        if (draw_uniform(key, 5) > 0.5) { double s_, c_; hm_sincos(de[2], &s_, &c_); de[0] += 2.0 * mid * c_; de[1] += 2.0 * mid * s_; de[2] += PI; }
+        if (draw_uniform(key, 6) > 0.5) { double s_, c_; hm_sincos(st[2], &s_, &c_); st[0] += 2.0 * mid * c_; st[1] += 2.0 * mid * s_; st[2] += PI; }
+        fill_scene_consts(c24, st, de, bb);
+    }
+    return cnt;
+}
+
 struct StepParams {
     int n, max_obst;          // max_obst = HBM tile stride (obstacle slots per scene)
     int tile_cap;             // LDS tile capacity of THIS launch (obstacles)
@@ -52,6 +152,9 @@ struct StepParams {
     int32_t* cur_pool;        // [n]
     uint32_t* episode;        // [n]
     unsigned long long redraw_seed;
+    DlpCases dlp;             // HOPE_AUTO_REDRAW: Dragon-Lake-Parking cases drawn on the device (hope_env_set_dlp_cases), or n_cases = 0
+    int32_t* pool_overflow;   // [1] draws whose culled obstacle set exceeded max_obst (truncated): must stay 0
+    const uint8_t* slot_cls;  // [n] draw class of every scene slot (0: lots of <= 32 obstacles, 1: larger)
     double* post;             // [n][POST_WORDS] per-scene hand-over to k_post (reward / target arithmetic, lane = scene)
     uint8_t* rs_flag;         // [n] 1: the scene passes the Reeds-Shepp gate this step (k_rs_compact builds the queues)
     int32_t* rs_count_zero;   // this tile class's RS queue counter, cleared here for the k_rs_compact that follows; or null
@@ -676,24 +779,36 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         // picked exactly as hope_env_redraw picks it, copied into the scene's slots by this wave; the rest of the turnover
         // (and of this kernel, in the one-launch form) then works on the new scene, whose whole tile is staged in LDS
         bool redrawn = false;
-        if ((p.stages & HOPE_AUTO_REDRAW) && p.pool_verts) {
-            const int cls = (p.max_obst > SMALL_TILE && n_obst > SMALL_TILE) ? 1 : 0;
+        if ((p.stages & HOPE_AUTO_REDRAW) && (p.pool_verts || p.dlp.n_cases > 0)) {
+            const int cls = p.slot_cls[scene] ? 1 : 0;                 // the slot's class, not the current map's size
             const int cnt = p.pool_cls_n[cls];
             if (cnt > 0) {
                 const uint32_t ep = p.episode[scene];
-                const int j = p.pool_cls[cls][(int)(mix64(p.redraw_seed ^ mix64(((uint64_t)scene << 32) | ep)) % (uint64_t)cnt)];
-                const int nob = p.pool_nobst[j];
-                const double2* psrc = (const double2*)(p.pool_verts + (size_t)j * p.max_obst * 8);
+                const uint64_t key = mix64(p.redraw_seed ^ mix64(((uint64_t)scene << 32) | ep));
+                const int j = p.pool_cls[cls][(int)(key % (uint64_t)cnt)];
                 double2* gdst = (double2*)(const_cast<double*>(p.verts) + (size_t)scene * p.max_obst * 8);
-                double2* ldst = (double2*)tile;
-                wsync();
-                for (int v = lane; v < 4 * nob; v += WAVE) { const double2 q2 = psrc[v]; gdst[v] = q2; ldst[v] = q2; }
                 float4* gobb = const_cast<float4*>(p.obb) + (size_t)scene * p.max_obst;
-                for (int o = lane; o < nob; o += WAVE) gobb[o] = obstacle_box(p.pool_verts + ((size_t)j * p.max_obst + o) * 8);
-                const double* pc = p.pool_c + (size_t)j * SC_WORDS;
-                if (lane < SC_WORDS) const_cast<double*>(p.scene_c)[(size_t)scene * SC_WORDS + lane] = pc[lane];
+                double* gsc = const_cast<double*>(p.scene_c) + (size_t)scene * SC_WORDS;
+                int nob;
+                wsync();
+                if (j >= 0) {                                           // a complete scene of the pool
+                    nob = p.pool_nobst[j];
+                    const double2* psrc = (const double2*)(p.pool_verts + (size_t)j * p.max_obst * 8);
+                    double2* ldst = (double2*)tile;
+                    for (int v = lane; v < 4 * nob; v += WAVE) { const double2 q2 = psrc[v]; gdst[v] = q2; ldst[v] = q2; }
+                    for (int o = lane; o < nob; o += WAVE) gobb[o] = obstacle_box(p.pool_verts + ((size_t)j * p.max_obst + o) * 8);
+                    const double* pc = p.pool_c + (size_t)j * SC_WORDS;
+                    if (lane < SC_WORDS) gsc[lane] = pc[lane];
+                    sc = pc;                                            // the new scene's constants, straight from the pool
+                } else {                                                // a Dragon-Lake-Parking case: drawn here (ParkingMapDLP.reset)
+                    double* c24 = scr + LDS_SH + 64;                    // (region A is free between the sub-step loop and the lidar)
+                    nob = draw_dlp_case(p.dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), p.max_obst, (double*)gdst, gobb, c24, tile,
+                                        p.pool_overflow, lane);
+                    wsync();
+                    if (lane < SC_WORDS) gsc[lane] = c24[lane];
+                    sc = c24;
+                }
                 if (lane == 0) { const_cast<int32_t*>(p.n_obst)[scene] = nob; p.cur_pool[scene] = j; p.episode[scene] = ep + 1; }
-                sc = pc;                                                // the new scene's constants, straight from the pool
                 if (lane < 8) dbox[lane] = sc[SC_DBOX + lane];
                 dest_area = sc[SC_DAREA];
                 n_obst = nob;

@@ -134,10 +134,13 @@ class TransitionRing:
 
 
 class HopeRollout:
-    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True, fresh_scenes=False):
+    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True, fresh_scenes=False, pool_refresher=None):
         """fresh_scenes: finished episodes continue on a NEW map drawn from the env's device-resident scene pool
-        (ParkingBatch.set_pool), as the reference's loop does with `env.reset(...)`; otherwise on the same map."""
+        (ParkingBatch.set_pool / set_dlp_cases), as the reference's loop does with `env.reset(...)`; otherwise on the same map.
+        pool_refresher: a `scene_gen.PoolRefresher`; the trainers poll it after every update, so the pool of generated lots is
+        replaced by new ones in the background (asynchronous upload, no synchronisation with the step loop)."""
         self.env, self.agent, self.use_mask, self.fresh = env, agent, use_mask, fresh_scenes
+        self.refresher = pool_refresher
         self.seed = seed
         dev = env.device
         self.ring = TransitionRing(env.n, horizon, agent.keys, dev)
@@ -201,8 +204,9 @@ class PPOTrainer(HopeRollout):
     """train_HOPE_ppo.py:177-213: act -> step -> push; when the buffer is full (`horizon` steps of all scenes,
     the batched `len(memory) % batch_size == 0`) run PPO.update and clear."""
 
-    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True, fresh_scenes=False):
-        super().__init__(env, agent, horizon, use_mask=True, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes)
+    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True, fresh_scenes=False, pool_refresher=None):
+        super().__init__(env, agent, horizon, use_mask=True, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes,
+                         pool_refresher=pool_refresher)
         self.updates = 0
 
     def step(self):
@@ -212,6 +216,8 @@ class PPOTrainer(HopeRollout):
             losses = self.agent.update(obs, action, reward, done, log_prob, self.last_obs(), generator=self.gen)
             self.ring.clear()
             self.updates += 1
+            if self.refresher is not None:
+                self.refresher.poll()
             return losses
         return None
 
@@ -220,8 +226,10 @@ class SACTrainer(HopeRollout):
     """train_HOPE_sac.py:177-221: uniform random actions until the memory is full, then the policy (plain Gaussian
     sample, no action mask), one SAC update every `update_every` env steps on a uniform batch from the ring."""
 
-    def __init__(self, env, agent, horizon=8, update_every=10, seed=0, use_planner=True, learn=True, fresh_scenes=False):
-        super().__init__(env, agent, horizon, use_mask=False, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes)
+    def __init__(self, env, agent, horizon=8, update_every=10, seed=0, use_planner=True, learn=True, fresh_scenes=False,
+                 pool_refresher=None):
+        super().__init__(env, agent, horizon, use_mask=False, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes,
+                         pool_refresher=pool_refresher)
         self.update_every, self.learn, self.updates = update_every, learn, 0
 
     def step(self):
@@ -229,5 +237,7 @@ class SACTrainer(HopeRollout):
         if self.learn and self.ring.size == self.ring.T and self.steps % self.update_every == 0:
             batch = self.ring.sample(self.agent.batch_size, self.last_obs(), self.gen)
             self.updates += 1
+            if self.refresher is not None and self.updates % 16 == 0:
+                self.refresher.poll()
             return self.agent.update(batch)
         return None

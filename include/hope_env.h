@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 4
+#define HOPE_ABI_VERSION 5
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -186,14 +186,53 @@ int hope_env_restart(hope_env_t *h, const uint8_t *mask, void *stream);
  * hope_env_redraw (asynchronous on `stream`) gives every scene with mask[i] != 0 a pool entry of ITS obstacle-tile class
  * (n_obst <= 32 or larger: the dense per-class launch lists stay valid), chosen by a counter-based hash of
  * (seed, scene, episodes drawn so far), and restarts it (pose = start, t = 0, accum_arrive_reward = 0).  Follow with
- * hope_env_reset_obs(active = mask) for the first observation.  The host refills / replaces the pool whenever it likes. */
+ * hope_env_reset_obs(active = mask) for the first observation.  The host refills / replaces the pool whenever it likes.
+ * The size-class mix of the resident scenes therefore stays what hope_env_set_scenes made it (a slot that holds a <= 32-obstacle
+ * lot keeps drawing such lots); a resident class without pool entries is an error (HOPE_ESTATE), not a silent restart. */
 int hope_env_set_pool(hope_env_t *h, int n_pool, const double *start, const double *dest, const double *bbox,
                       const double *verts, const int32_t *n_obst);
+/* The same without blocking the step loop: hope_env_pool_staging hands out PINNED host arrays of the handle (layout as above, for
+ * n_pool entries; valid until the next hope_env_pool_staging call) that any host thread may fill -- e.g. hope_scenegen_generate
+ * writing into them directly -- and hope_env_commit_pool uploads them asynchronously into the pool set the kernels are not reading
+ * and swaps the sets: launches enqueued afterwards wait (on the device, in stream order) for the upload and draw from the new pool;
+ * launches already enqueued keep the old one.  Neither call synchronises with the step kernels (hope_env_pool_staging waits at most
+ * for the previous upload's copy to leave the staging).  Both must be called from the thread that owns the handle. */
+int hope_env_pool_staging(hope_env_t *h, int n_pool, double **start, double **dest, double **bbox, double **verts, int32_t **n_obst);
+int hope_env_commit_pool(hope_env_t *h, int n_pool, void *stream);
 /* seed of HOPE_AUTO_REDRAW's draws (default 0) */
 int hope_env_set_redraw_seed(hope_env_t *h, uint64_t seed);
 int hope_env_redraw(hope_env_t *h, const uint8_t *mask, uint64_t seed, void *stream);
-/* pool entry each scene currently holds (-1: as uploaded by hope_env_set_scenes); host-synchronous */
+/* pool entry each scene currently holds: >= 0 a complete pool scene, -1 the map hope_env_set_scenes uploaded;
+ * values <= -2 name Dragon-Lake-Parking case c = -2 - value drawn on the device (hope_env_set_dlp_cases); host-synchronous */
 int hope_env_download_pool_index(hope_env_t *h, int32_t *out /*[N]*/);
+
+/* Dragon-Lake-Parking cases drawn ON THE DEVICE at episode turnover (ParkingMapDLP.reset, src/env/parking_map_dlp.py:38-86): per
+ * episode a start candidate of the case chosen uniformly (:58-59) with N(0, 0.05^2) m / N(0, 0.02^2) rad jitter (:60-65), the map
+ * box floor / ceil(min / max(start, dest) -/+ 20 m) (:70-73), the case's obstacles culled by that box (:88-101), independent 50 %
+ * flips of dest and start about their box centres (:80-83).  The data of data/dlp.data (host pointers, host-synchronous):
+ * dest [n_cases][3]; cand_off [n_cases + 1] + cand [][3]: the start candidates of each case; case_set [n_cases]: the obstacle set
+ * a case uses; set_off [n_sets + 1] + set_verts [][4][2]: the rings of each set (a triangle repeats its last vertex).  The cases
+ * join the draw list of the large-tile class (every culled lot has 37 .. 125 obstacles): hope_env_redraw / HOPE_AUTO_REDRAW pick
+ * uniformly among that class's complete pool scenes and the cases.  n_cases = 0 removes them. */
+int hope_env_set_dlp_cases(hope_env_t *h, int n_cases, const double *dest, const int32_t *cand_off, const double *cand,
+                           const int32_t *case_set, int n_sets, const int32_t *set_off, const double *set_verts);
+/* The size class of scene slots: 0 = lots of at most 32 obstacles (small LDS tile, draws from the pool's small maps), 1 = larger
+ * lots (draws from the large maps and the Dragon-Lake cases).  hope_env_set_scenes sets it from the uploaded map's obstacle count;
+ * this call overrides it, e.g. to keep a slot among the Dragon-Lake lots although its first map kept only 30 obstacles (class 1 is
+ * always allowed, class 0 only for maps of <= 32 obstacles).  cls: host u8 [n].  Host-synchronous. */
+int hope_env_set_draw_class(hope_env_t *h, const int32_t *scene_ids, int n, const uint8_t *cls);
+/* draws whose culled obstacle set did not fit max_obstacles and was truncated (must stay 0); host-synchronous */
+int hope_env_pool_overflow(hope_env_t *h, int32_t *count);
+/* the maps the listed scenes hold NOW (after device-side draws they exist on the device only); any output may be NULL; layout as
+ * hope_env_set_scenes; host-synchronous */
+int hope_env_download_scenes(hope_env_t *h, const int32_t *scene_ids, int n, double *start, double *dest, double *bbox, double *verts,
+                             int32_t *n_obst);
+/* Snapshot / restore of drawn maps.  A draw is a pure function of (seed, scene, episode counter) and of the pool / case lists:
+ * hope_env_download_pool_state returns the pool index and the episode counter of every scene; hope_env_restore_maps (host arrays:
+ * drawn[i] != 0 where the scene held a drawn map, the saved counters, the seed in use when the maps were drawn) repeats those draws
+ * with the SAME pool / cases resident.  Restore pose / t / accumulator afterwards with hope_env_upload_state.  Host-synchronous. */
+int hope_env_download_pool_state(hope_env_t *h, int32_t *pool_index /*[N]*/, uint32_t *episode /*[N]*/);
+int hope_env_restore_maps(hope_env_t *h, const uint8_t *drawn /*[N]*/, const uint32_t *episode /*[N]*/, uint64_t seed);
 
 /* With HOPE_F_PROFILE every kernel launch is bracketed by its own HIP event pair on the launch stream.
  * Returns the accumulated time (ms) and launch count per kernel since the last call with reset != 0:
@@ -248,6 +287,17 @@ int hope_debug_rs_filter_dump(double *out /*[64][16]*/);
 int hope_debug_rs_log(int32_t *out /*[cap][4]*/, int cap, int32_t *n, int reset);
 /* the same for k_env_step (environment variable HOPE_STEP_TIMING; float32 observation / action handles); tools/step_timing.py */
 int hope_debug_step_prof(uint64_t *out /*[16]*/, int reset);
+
+/* ---- host-side scene generator (no device involved; any thread) ------------------------------------------------------ */
+/* n scenes of `level` (0 Normal, 1 Complex, 2 Extrem) drawn as ParkingMapNormal.reset does (src/env/parking_map_normal.py:474-494
+ * over generate_bay_parking_case :40-246 / generate_parallel_parking_case :248-457): bay lot with probability 1/2 for Normal /
+ * Complex, parallel otherwise; map box = floor / ceil of min / max(start, dest) -/+ 10 m.  bay_mode: -1 as the reference, 0
+ * parallel only, 1 bay only.  Outputs are HOST arrays in the layout of hope_env_set_scenes / hope_env_set_pool: start [n][3],
+ * dest [n][3], bbox [n][4], verts [n][max_obstacles][4][2] (slots beyond n_obst[i] untouched), n_obst [n], case_id [n] (0 bay,
+ * 1 parallel; may be NULL).  Scene i depends only on (seed, first_index + i), not on n_threads (<= 0: all hardware threads).
+ * Returns 0, HOPE_EINVAL, or -100 - i when scene i has more than max_obstacles obstacles (impossible for max_obstacles >= 18). */
+int hope_scenegen_generate(int level, int bay_mode, int n, uint64_t seed, int64_t first_index, int max_obstacles, double *start,
+                           double *dest, double *bbox, double *verts, int32_t *n_obst, int32_t *case_id, int n_threads);
 
 /* ---- introspection ---------------------------------------------------------------------------- */
 int hope_env_num_scenes(const hope_env_t *h);

@@ -95,7 +95,7 @@ def rollout(env, orc, rng, steps, tol, with_rs=False, stages=None):
 def test_library_is_native():
     from hope_amd import load_library
     L = load_library()
-    assert L.hope_abi_version() == 4
+    assert L.hope_abi_version() == 5
 
 
 def test_step_parity_f64_dlp():
@@ -754,20 +754,18 @@ def test_headline_configuration_has_an_oracle_witness_65536_scenes():
     oracle from the device state, one fused step, turnovers followed onto the drawn map), over 32 steps so that episodes end."""
     import bench
     from hope_amd import ParkingBatch, _lib as L
-    from hope_amd.scenes import SceneSource, pack_scenes
-    n, mo, P, U = 65536, 128, 2048, 1024
-    src = SceneSource(seed=61)
-    uniq = [src.draw() for _ in range(U)]
-    pool = [src.draw() for _ in range(P)]
-    init = pack_scenes(uniq, mo)
-    pool_packed = pack_scenes(pool, mo)
+    from hope_amd.scene_gen import generate_arrays, mixed_arrays
+    n, mo, P, U = 65536, 128, 2046, 1024
+    init = mixed_arrays(U, seed=61, max_obst=mo)
     env = ParkingBatch(n, mo, obs_dtype=torch.float32, action_dtype=torch.float32)
     assert env.overlap                                            # the default launch form: two chains, split step kernel
-    reps = n // U
     for a in range(0, n, 8192):
         sl = np.arange(a, a + 8192) % U
         env.set_scene_arrays(np.arange(a, a + 8192), init[0][sl], init[1][sl], init[2][sl], init[3][sl], init[4][sl])
-    env.set_pool(pool_packed)
+    env.set_draw_class(np.arange(3, n, 4), 1)                    # every fourth slot: Dragon-Lake lots, drawn on the device
+    parts = [generate_arrays(lv, P // 3, seed=62 + j, max_obst=mo) for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
+    env.set_pool(tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(6)))
+    env.set_dlp_cases()
     env.set_redraw_seed(99)
     env.reset_obs()
     rng = np.random.default_rng(62)
@@ -781,7 +779,7 @@ def test_headline_configuration_has_an_oracle_witness_65536_scenes():
         if it % 4 == 3:                                           # plain steps in between, so that states drift apart
             env.step(act, auto_reset=True, fresh=True)
             continue
-        r = bench.parity_witness(env, L.STAGE_ALL, True, init, U, pool_packed, act, 1024, seed=1000 + it)
+        r = bench.parity_witness(env, L.STAGE_ALL, True, act, 1024, seed=1000 + it)
         for k in tot:
             tot[k] += r[k]
         worst = max(worst, r['max_abs_err'])
@@ -861,3 +859,249 @@ def test_rs_float32_filter_equals_the_float64_kernel_and_never_contradicts_it():
     assert st['samples'] > 1_000_000 and st['bad_hit'] == 0 and st['bad_clear'] == 0
     assert st['passes'] > 100_000 and st['exact_passes'] < 0.35 * st['passes']
     env.close()
+
+
+def _ks2(a, b):
+    a, b = np.sort(a), np.sort(b)
+    allv = np.concatenate([a, b])
+    return float(np.abs(np.searchsorted(a, allv, side='right') / len(a) - np.searchsorted(b, allv, side='right') / len(b)).max())
+
+
+def test_device_side_dlp_draw_distribution_and_oracle_parity():
+    """f-2 (VERDICT r2 #3a): ParkingMapDLP.reset on the device.  (a) > 10^5 turnovers of large-tile scenes draw cases of
+    data/dlp.data with a fresh start candidate, jitter, flips, map box and obstacle cull; every marginal of the drawn scenes is
+    within KS 0.02 of the host sampler's (`DlpScenePool.sample`, pinned to parking_map_dlp.py:38-101); (b) with a one-candidate
+    case the jitter is N(0, 0.05^2) m / N(0, 0.02^2) rad and each flip has probability 1/2; (c) the env steps exactly like the
+    oracle on the drawn scenes; (d) the fused turnover (HOPE_AUTO_REDRAW) draws the same scenes as hope_env_redraw; (e) a
+    snapshot's maps are restored by repeating the draws."""
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import DlpScenePool, pack_scenes
+    from oracle import oracle as O
+    n, mo = 16384, 128
+    pool = DlpScenePool()
+    rng = np.random.default_rng(81)
+    uniq = [pool.sample(rng=rng) for _ in range(256)]
+    packed = pack_scenes(uniq, mo)
+    env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
+    for a in range(0, n, 8192):
+        sl = np.arange(a, a + 8192) % len(uniq)
+        env.set_scene_arrays(np.arange(a, a + 8192), *(x[sl] for x in packed[:5]))
+    env.set_draw_class(np.arange(n), 1)                       # Dragon-Lake slots, whatever the first map's obstacle count
+    with pytest.raises(Exception, match='pool'):
+        env.redraw(torch.ones(n, dtype=torch.uint8, device=env.device), seed=1)          # no pool, no cases yet
+    env.set_dlp_cases(pool)
+    ones = torch.ones(n, dtype=torch.uint8, device=env.device)
+    feats, cases = [], []
+    ids = np.arange(n)
+    for it in range(7):
+        env.redraw(ones, seed=500 + it)
+        start, dest, bbox, verts, nob = env.download_scenes(ids)
+        idx = env.pool_index()
+        assert (idx <= -2).all() and (nob > 0).all() and (nob <= mo).all()
+        cases.append(-2 - idx)
+        feats.append(np.column_stack([start, dest, bbox[:, 1] - bbox[:, 0], bbox[:, 3] - bbox[:, 2], nob,
+                                      np.hypot(start[:, 0] - dest[:, 0], start[:, 1] - dest[:, 1])]))
+    assert env.pool_overflow() == 0
+    dev = np.concatenate(feats)
+    cs = np.concatenate(cases)
+    assert len(dev) > 100_000
+    hist = np.bincount(cs, minlength=len(pool))
+    assert hist.min() > 0.6 * len(cs) / len(pool) and hist.max() < 1.4 * len(cs) / len(pool)     # cases uniform (:50)
+    hrng = np.random.default_rng(82)
+    host = []
+    for _ in range(len(dev) // 4):
+        s = pool.sample(rng=hrng)
+        host.append(np.concatenate([s.start, s.dest, [s.bbox[1] - s.bbox[0], s.bbox[3] - s.bbox[2], s.n_obst,
+                                                      np.hypot(s.start[0] - s.dest[0], s.start[1] - s.dest[1])]]))
+    host = np.array(host)
+    names = ['start_x', 'start_y', 'start_yaw', 'dest_x', 'dest_y', 'dest_yaw', 'box_w', 'box_h', 'n_obst', 'dist']
+    worst = {nm: _ks2(np.cos(dev[:, j]) if 'yaw' in nm else dev[:, j], np.cos(host[:, j]) if 'yaw' in nm else host[:, j]) for j, nm in enumerate(names)}
+    print('device DLP draws vs host sampler, KS:', {k: round(v, 4) for k, v in worst.items()})
+    assert max(worst.values()) < 0.02, worst
+    # (c) the env on the drawn scenes == the oracle on the downloaded scenes
+    sub = np.sort(rng.choice(n, 768, replace=False))
+    start, dest, bbox, verts, nob = env.download_scenes(sub)
+    env.reset_obs()
+    t = env.tables
+    O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'])
+    orc = O.BatchOracle(len(sub), mo, omp=True)
+    orc.set_scenes(np.arange(len(sub)), start, dest, bbox, verts, np.full((len(sub), mo), 4, np.int32), nob)
+    o = orc.reset_obs()
+    st = torch.from_numpy(sub).to(env.device)
+    assert np.array_equal(env.lidar[st].cpu().numpy(), o['lidar']) and np.array_equal(env.action_mask[st].cpu().numpy(), o['mask'])
+    for it in range(5):
+        act = rng.uniform(-1, 1, (n, 2))
+        env.step(torch.from_numpy(act).to(env.device))
+        o = orc.step(act[sub])
+        torch.cuda.synchronize()
+        assert np.array_equal(env.status[st].cpu().numpy(), o['status'])
+        assert np.array_equal(env.lidar[st].cpu().numpy(), o['lidar']) and np.array_equal(env.reward[st].cpu().numpy(), o['reward'])
+        assert np.array_equal(env.rs_word[st][:, 6].cpu().numpy(), o['rs_found'])
+    # (e) snapshot: maps + state, then move on, then restore
+    pose, tt, acc = env.download_state()
+    pidx, ep = env.pool_state()
+    snap = env.download_scenes(sub)
+    env.redraw(ones, seed=900)
+    assert not np.array_equal(env.download_scenes(sub)[0], snap[0])
+    env.restore_maps(pidx, ep, seed=500 + 6)
+    env.upload_state(pose=pose, t=tt, accum=acc)
+    back = env.download_scenes(sub)
+    assert all(np.array_equal(snap[j], back[j]) for j in (0, 1, 2, 4))
+    assert all(np.array_equal(snap[3][k, :snap[4][k]], back[3][k, :back[4][k]]) for k in range(len(sub)))     # (slots beyond n_obst are stale)
+    assert np.array_equal(env.pool_state()[0], pidx) and np.array_equal(env.pool_state()[1], ep)
+    env.close()
+
+    # (b) one case, one candidate: the residual IS the jitter
+    class One:
+        dest = np.array([[3.0, 40.0, 1.2]]); starts = np.array([[10.0, 30.0, 0.4]]); start_off = np.array([0, 1]); case_set = np.array([0])
+        set_off = np.array([0, 40]); set_nvert = np.full(40, 4)
+        set_verts = np.array([[[x, 20.0], [x + 1, 20.0], [x + 1, 21.0], [x, 21.0]] for x in np.linspace(-5, 60, 40)])
+    m = 32768
+    e2 = ParkingBatch(m, mo, obs_dtype=torch.float64)
+    sc = pool.sample(rng=rng)
+    for a in range(0, m, 8192):
+        e2.set_scenes(np.arange(a, a + 8192), [sc] * 8192)
+    e2.set_draw_class(np.arange(m), 1)
+    e2.set_dlp_cases(One)
+    e2.redraw(torch.ones(m, dtype=torch.uint8, device=e2.device), seed=7)
+    start, dest, bbox, verts, nob = e2.download_scenes(np.arange(m))
+    flipped_s = np.abs(np.cos(start[:, 2] - 0.4) + 1) < 0.1
+    flipped_d = np.abs(np.cos(dest[:, 2] - 1.2) + 1) < 0.1
+    assert abs(flipped_s.mean() - 0.5) < 0.02 and abs(flipped_d.mean() - 0.5) < 0.02
+    assert abs((flipped_s & flipped_d).mean() - 0.25) < 0.02                         # independent
+    r = (start[~flipped_s] - One.starts[0]) / np.array([0.05, 0.05, 0.02])
+    from scipy import stats
+    for j in range(3):
+        d = stats.kstest(r[:, j], 'norm').statistic
+        assert d < 0.015, (j, d)
+    assert abs(np.corrcoef(r[:, 0], r[:, 1])[0, 1]) < 0.03 and abs(np.corrcoef(r[:, 0], r[:, 2])[0, 1]) < 0.03
+    # the unflipped dest is the case's; the flipped one is its mirror about the box centre (heading + pi)
+    assert np.allclose(dest[~flipped_d], One.dest[0]) and np.allclose(dest[flipped_d][:, 2], 1.2 + np.pi)
+    mid = 0.5 * (3.76 - 0.93)
+    assert np.allclose(dest[flipped_d][:, :2], One.dest[0, :2] + 2 * mid * np.array([np.cos(1.2), np.sin(1.2)]))
+    # map box and cull rules on the drawn values (parking_map_dlp.py:70-73, :88-101)
+    s0 = np.where(flipped_s[:, None], start - np.column_stack([2 * mid * np.cos(start[:, 2] - np.pi), 2 * mid * np.sin(start[:, 2] - np.pi), np.full(m, np.pi)]), start)
+    assert np.array_equal(bbox[:, 0], np.floor(np.minimum(s0[:, 0], 3.0) - 20)) and np.array_equal(bbox[:, 3], np.ceil(np.maximum(s0[:, 1], 40.0) + 20))
+    keep = ~((One.set_verts[:, :, 0].max(1)[None] <= bbox[:, :1]) | (One.set_verts[:, :, 0].min(1)[None] >= bbox[:, 1:2]))
+    assert np.array_equal(nob, keep.sum(1))
+    e2.close()
+
+
+def test_fused_turnover_draws_dlp_cases_like_redraw():
+    """(d) of the above: HOPE_AUTO_REDRAW with device-drawn Dragon-Lake cases and generated lots == step + hope_env_redraw(done)
+    + reset_obs(done), in both launch forms; a resident size class without pool entries is refused."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scene_gen import mixed_arrays, generate_arrays
+    n, mo = 4096, 128
+    init = mixed_arrays(n, seed=91, max_obst=mo)
+    small = generate_arrays('Complex', 300, seed=92, max_obst=mo)[:6]
+    names = ('lidar', 'action_mask', 'target', 'reward', 'reward_info', 'status', 'done', 'pose', 'rs_word', 'rs_lengths')
+    for split in (False, True):
+        if split:
+            os.environ['HOPE_SPLIT_MIN'] = '1'
+        try:
+            a = ParkingBatch(n, mo, obs_dtype=torch.float64)
+            b = ParkingBatch(n, mo, obs_dtype=torch.float64)
+            rng = np.random.default_rng(93)
+            t0 = rng.integers(185, 200, n)
+            for e in (a, b):
+                e.set_scene_arrays(np.arange(n), *init[:5])
+                e.set_draw_class(np.arange(3, n, 4), 1)                      # every fourth slot is a Dragon-Lake lot
+                e.set_dlp_cases()
+                e.reset_obs()
+                e.upload_state(t=t0)
+            g = torch.Generator(device='cuda').manual_seed(9)
+            act = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+            with pytest.raises(Exception, match='size class'):
+                a.step(act, auto_reset=True, fresh=True)                   # the <= 32-obstacle lots have nothing to draw from
+            for e in (a, b):
+                e.set_pool(small)
+            a.set_redraw_seed(31)
+            turned = cases = 0
+            for it in range(20):
+                act = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+                a.step(act, auto_reset=True, fresh=True)
+                b.step(act)
+                turned += int(b.done.sum().item())
+                b.turnover(seed=31)
+                torch.cuda.synchronize()
+                for k in names:
+                    assert torch.equal(getattr(a, k), getattr(b, k)), (split, it, k)
+                assert np.array_equal(a.pool_index(), b.pool_index())
+                assert all(np.array_equal(x, y) for x, y in zip(a.download_state(), b.download_state()))
+            ia = a.pool_index()
+            cases = int((ia <= -2).sum())
+            sub = np.nonzero(ia <= -2)[0][:64]
+            da, db = a.download_scenes(sub), b.download_scenes(sub)
+            assert all(np.array_equal(da[j], db[j]) for j in (0, 1, 2, 4)) and all(np.array_equal(da[3][k, :da[4][k]], db[3][k, :db[4][k]]) for k in range(len(sub)))
+            assert turned > 300 and cases > 50 and a.pool_overflow() == 0
+            a.close(); b.close()
+        finally:
+            os.environ.pop('HOPE_SPLIT_MIN', None)
+
+
+def test_pool_refresh_in_the_background_keeps_up_and_matches_the_synchronous_upload():
+    """f-2 (VERDICT r2 #3b): the pool of generated lots is replaced while the step loop runs -- native generator in a background
+    thread into pinned staging, asynchronous upload into the idle pool set, swap by stream order (hope_env_pool_staging /
+    hope_env_commit_pool; no hipDeviceSynchronize).  An env refreshed that way behaves exactly like one given the same pools with
+    the synchronous hope_env_set_pool at the same steps; committing does not wait for the GPU; scenes turned over after a commit
+    hold maps of the NEW pool."""
+    import time
+    from hope_amd import ParkingBatch
+    from hope_amd.scene_gen import PoolRefresher, generate_arrays
+    n, mo, P = 8192, 32, 1200
+    init = generate_arrays('Complex', n, seed=5, max_obst=mo)[:5]
+    a = ParkingBatch(n, mo, obs_dtype=torch.float64)
+    b = ParkingBatch(n, mo, obs_dtype=torch.float64)
+    for e in (a, b):
+        e.set_scene_arrays(np.arange(n), *init)
+        e.reset_obs()
+        e.upload_state(t=np.random.default_rng(6).integers(150, 200, n))
+        e.set_redraw_seed(77)
+    ref = PoolRefresher(a, P, levels=('Normal', 'Complex', 'Extrem'), seed=9, threads=2)
+    assert ref.poll(wait=True)                                        # the first pool
+    pools = []
+
+    def snapshot():
+        arrs = [x.copy() for x in a.pool_staging(P)]                 # (the staging is being refilled; copies of what was committed are kept below)
+        return arrs
+    names = ('lidar', 'action_mask', 'reward', 'status', 'done', 'pose', 'rs_word')
+    g = torch.Generator(device='cuda').manual_seed(3)
+    commit_ms = []
+    committed = 1
+    cur = None
+    for it in range(60):
+        if it % 10 == 0:
+            # hand b the pool a is about to commit: generate it synchronously with the same (seed, batch) recipe
+            batch = ref.batch - 1 if it else 0
+            per = P // 3
+            parts = [generate_arrays(lv, per if j < 2 else P - 2 * per, seed=9 * 1000003 + j, max_obst=mo, first_index=batch * P)
+                     for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
+            cur = tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(5))
+            pools.append(cur)
+            if it:
+                t0 = time.perf_counter()
+                assert ref.poll(wait=True)
+                commit_ms.append((time.perf_counter() - t0) * 1e3)
+                committed += 1
+            b.set_pool(cur + (None,))
+        act = torch.rand((n, 2), device='cuda', generator=g, dtype=torch.float32) * 2 - 1
+        a.step(act, auto_reset=True, fresh=True)
+        b.step(act, auto_reset=True, fresh=True)
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(getattr(a, k), getattr(b, k)), (it, k)
+        assert np.array_equal(a.pool_index(), b.pool_index())
+    # maps of turned-over scenes come from the pool committed last
+    idx = a.pool_index()
+    turned = np.nonzero(idx >= 0)[0]
+    assert len(turned) > 500
+    s_, d_, bb_, v_, nob_ = a.download_scenes(turned[:200])
+    which = np.array([[np.array_equal(s_[k], pl[0][idx[turned[k]]]) and nob_[k] == pl[4][idx[turned[k]]] for pl in pools] for k in range(200)])
+    assert which.any(axis=1).all()                                    # every drawn map is an entry of a pool that was committed
+    assert which[:, -1].any() and which[:, 0].sum() < 200             # ... of the newest one too: the swaps took effect
+    print('pool commits:', committed, 'ms per commit incl. waiting for the generator thread:', [round(x, 2) for x in commit_ms],
+          'generator s total:', round(ref.gen_seconds, 3))
+    ref.close()
+    a.close(); b.close()
