@@ -39,11 +39,20 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s = ro.stats()
-    rec = D.gather_eval_stats(env.status, torch.zeros_like(env.status), env.reward, torch.zeros_like(env.reward))
     if rank == 0:
         print(f'{world} rank(s) x {args.scenes} scenes: {args.scenes * world * args.steps / dt / 1e6:.2f} M env+agent steps/s, '
-              f'{s["episodes"]} episodes on rank 0, success rate {s["success_rate"]:.3f}, RS replay active {s["executing_rs"]:.3f}, '
-              f'gathered {len(rec)} eval records')
+              f'{s["episodes"]} episodes on rank 0, success rate {s["success_rate"]:.3f}, RS replay active {s["executing_rs"]:.3f}')
+    # evaluation as eval_utils.py does it (one episode per slot, per-level table), records gathered over the ranks
+    from hope_amd import agents as A
+    from hope_amd import evaluate as E
+    ag = A.BatchedPPO(device=dev, use_img=False)
+    env.set_scenes(np.arange(args.scenes), [uniq[i % len(uniq)] for i in range(args.scenes)])
+    rec = E.BatchedEvaluator(env, ag, seed=rank).run()
+    if rank == 0:
+        levels = [uniq[i % len(uniq)].level for i in range(args.scenes)] * world
+        for k, v in E.summarize(rec, levels).items():
+            print(f'  eval {k:8s}: {v["episodes"]} episodes, success {v["success_rate"]:.3f}, steps {v["step_num_mean"]:.1f} +- {v["step_num_std"]:.1f}, '
+                  f'path {v["path_length_mean"]:.2f} m')
 
 
 if __name__ == '__main__':

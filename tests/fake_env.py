@@ -28,6 +28,7 @@ class OracleEnv:
         self.rs_word = torch.full((n, 8), -1, dtype=torch.int8)
         self.rs_lengths = torch.zeros(n, 5)
         self.img = None
+        self.pose = torch.from_numpy(self.orc.pose.copy())
 
     def _publish(self, o, obs_only=None):
         sel = slice(None) if obs_only is None else obs_only
@@ -38,18 +39,27 @@ class OracleEnv:
     def reset_obs(self):
         o = self.orc.reset_obs(with_rs=self.with_rs)
         self._publish(o)
+        self.pose.copy_(torch.from_numpy(self.orc.pose))
         return self
 
-    def step(self, actions, auto_reset=False):
+    def step(self, actions, auto_reset=False, active=None):
+        keep = None
+        if active is not None:                      # frozen scenes: state and outputs untouched (hope_env_step's `active`)
+            keep = ~active.bool().numpy()
+            saved = (self.orc.pose[keep].copy(), self.orc.t[keep].copy(), self.orc.accum[keep].copy())
         o = self.orc.step(actions.double().numpy(), with_rs=self.with_rs)
-        self._publish(o)
-        self.reward.copy_(torch.from_numpy(o['reward']).float())
-        self.status.copy_(torch.from_numpy(o['status']))
-        self.done.copy_(torch.from_numpy((o['status'] != 1).astype(np.uint8)))
-        self.rs_word[:, :5] = torch.from_numpy(o['rs_ctypes'].astype(np.int8))
-        self.rs_word[:, 5] = torch.from_numpy((o['rs_ctypes'] >= 0).sum(1).astype(np.int8))
-        self.rs_word[:, 6] = torch.from_numpy(o['rs_found'].astype(np.int8))
-        self.rs_lengths.copy_(torch.from_numpy(o['rs_lengths']).float())
+        if keep is not None:
+            self.orc.pose[keep], self.orc.t[keep], self.orc.accum[keep] = saved
+        sel = slice(None) if keep is None else np.nonzero(~keep)[0]
+        self._publish(o, sel)
+        self.pose[sel] = torch.from_numpy(self.orc.pose[sel])
+        self.reward[sel] = torch.from_numpy(o['reward'][sel]).float()
+        self.status[sel] = torch.from_numpy(o['status'][sel])
+        self.done[sel] = torch.from_numpy((o['status'][sel] != 1).astype(np.uint8))
+        self.rs_word[sel, :5] = torch.from_numpy(o['rs_ctypes'][sel].astype(np.int8))
+        self.rs_word[sel, 5] = torch.from_numpy((o['rs_ctypes'][sel] >= 0).sum(1).astype(np.int8))
+        self.rs_word[sel, 6] = torch.from_numpy(o['rs_found'][sel].astype(np.int8))
+        self.rs_lengths[sel] = torch.from_numpy(o['rs_lengths'][sel]).float()
         ids = np.nonzero(o['status'] != 1)[0]
         if auto_reset and len(ids):                 # HOPE_AUTO_RESET: restart on the same map + the action-less step
             start, dest, bbox, verts, nob, nvert = self.packed

@@ -35,7 +35,7 @@ def test_agent_glue_reference_vectors_on_gpu(gold):
     TG.check_state_norm(g, 'cuda')
 
 
-def make_env(n, seed=5, image=False, levels=('Normal', 'Complex', 'Extrem', 'dlp'), near=True, unique=512):
+def make_env(n, seed=5, image=False, levels=('Normal', 'Complex', 'Extrem', 'dlp'), near=True, unique=512, device='cuda:0'):
     from hope_amd import ParkingBatch
     from hope_amd.scenes import SceneSource
     rng = np.random.default_rng(seed)
@@ -46,7 +46,7 @@ def make_env(n, seed=5, image=False, levels=('Normal', 'Complex', 'Extrem', 'dlp
             r, a = rng.uniform(3.0, 9.0), rng.uniform(0, 2 * np.pi)
             s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.4])
     scenes = [uniq[i % len(uniq)] for i in range(n)]
-    env = ParkingBatch(n, 128, image=image)
+    env = ParkingBatch(n, 128, image=image, device=device)
     for a in range(0, n, 4096):
         env.set_scenes(np.arange(a, min(n, a + 4096)), scenes[a:a + 4096])
     return env, scenes
@@ -154,3 +154,79 @@ def test_ppo_loop_two_ranks_share_gpu():
     [p.join(120) for p in ps]
     assert res[0][3] == res[1][3] == 1 and res[0][4] > 0
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_batched_evaluator_on_the_gpu():
+    """eval() for 2 048 episodes at once (hope_amd/evaluate.py): one episode per slot, finished slots frozen, per-level table;
+    with RS replay a random-init policy parks most cars, as in the rollout loops."""
+    from hope_amd import agents as A
+    from hope_amd import evaluate as E
+    from hope_amd.scene_gen import mixed_arrays
+    n = 2048
+    from hope_amd import ParkingBatch
+    arr = mixed_arrays(n, seed=17, max_obst=128)
+    env = ParkingBatch(n, 128)
+    env.set_scene_arrays(np.arange(n), *arr[:5])
+    torch.manual_seed(0)
+    ag = A.BatchedPPO(device='cuda', use_img=False)
+    ev = E.BatchedEvaluator(env, ag, post_proc_action=True, seed=3)
+    rec = ev.run()
+    torch.cuda.synchronize()
+    assert rec.shape == (n, 4)
+    r = rec.cpu().numpy()
+    assert set(np.unique(r[:, 0]).astype(int)) <= {2, 3, 4, 5} and (r[:, 1] >= 1).all() and (r[:, 1] <= 202).all()
+    assert (r[r[:, 0] == 5, 1] == 200).all()                                  # OUTTIME fires at t > 200: reset's step + 200 actions
+    levels = [('Normal', 'Complex', 'Extrem', 'dlp')[k % 4] for k in range(n)]
+    s = E.summarize(rec, levels)
+    print('evaluator:', {k: (round(v['success_rate'], 3), round(v['step_num_mean'], 1), round(v['path_length_mean'], 2)) for k, v in s.items()})
+    assert s['all']['episodes'] == n and all(s[k]['episodes'] == n // 4 for k in ('Normal', 'Complex', 'Extrem', 'dlp'))
+    assert s['all']['success_rate'] > 0.3 and s['all']['path_length_mean'] > 1.0
+    # frozen slots: stepping on with everything inactive changes nothing
+    pose = env.pose.clone()
+    env.step(torch.zeros((n, 2), device='cuda'), active=torch.zeros(n, dtype=torch.uint8, device='cuda'))
+    torch.cuda.synchronize()
+    assert torch.equal(env.pose, pose)
+    env.close()
+
+
+def _nccl_rank(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{rank}'))
+    from hope_amd import agents as A
+    from hope_amd import dist as D
+    from hope_amd import evaluate as E
+    from hope_amd.rollout import PPOTrainer
+    from test_agents import probe
+    torch.manual_seed(0)
+    ag = A.BatchedPPO(device=f'cuda:{rank}', use_img=False, mini_batch=2048, mini_epoch=1)
+    lo, hi = D.shard_range(4096, rank, world)
+    env, _ = make_env(hi - lo, seed=20 + rank, device=f'cuda:{rank}')
+    tr = PPOTrainer(env, ag, horizon=4, seed=30 + rank)
+    for _ in range(4):
+        tr.step()
+    rec = E.BatchedEvaluator(env, ag, seed=rank).run(max_steps=30)           # one all-gather of the eval records over RCCL
+    torch.cuda.synchronize()
+    q.put((rank, probe(ag.actor.cpu()).numpy(), tr.updates, ag.allreduce_bytes, tuple(rec.shape), float(rec[:, 1].sum())))
+    env.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 GPUs: the RCCL path (backend "nccl" over xGMI)')
+def test_rccl_gradient_allreduce_and_eval_gather_two_gpus():
+    """The two exchange points of a data-parallel run on REAL RCCL: the fused gradient all-reduce keeps two ranks on
+    two GPUs bit-identical, the evaluator's all-gather gives both the same table.  Skipped on 1-GPU boxes (the same code runs
+    over gloo in tests/test_agents.py / tests/test_evaluate.py and as 2 ranks sharing one GPU above)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_nccl_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda r: r[0])
+    [p.join(120) for p in ps]
+    assert res[0][2] == res[1][2] == 1 and res[0][3] > 0
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][4] == res[1][4] == (4096, 4) and res[0][5] == res[1][5]
