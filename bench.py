@@ -305,30 +305,46 @@ def main():
         # labelled as such.  They describe the default workload only.
         default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and fresh)
         traffic = traffic_source = None
-        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_image.json' if args.image else 'r02_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_image.json' if args.image else 'r03_pmc_traffic.json')
         if os.path.exists(pmc) and default_workload and not args.graph:
             try:
                 traffic = json.load(open(pmc))['kernels'][dom]['hbm_bytes']
                 traffic_source = 'static: ' + os.path.relpath(pmc, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)'
             except Exception:
                 traffic = None
-        # instruction-issue roofline (every kernel here is VALU-issue / latency bound, none is HBM bound): a gfx950 SIMD
-        # issues one wave64 VALU instruction per 4 cycles -- measured: float64 add / mul / fma run at that full rate
-        # (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.04 quad-cycles) -- so the chip retires at most
-        # 1024 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s.
+        # Instruction-issue roofline (every kernel here is VALU-issue / latency bound, none is HBM bound), MIX-WEIGHTED: the issue
+        # rate of a wave64 VALU instruction depends on its class -- measured on this GPU type by tools/valu_rate.py
+        # (profiles/r03_valu_rates.json): float64 add / mul / fma ~4.4e11 wave-instructions/s chip-wide, float64 rcp / sqrt
+        # ~1.5e11, plain 32-bit ALU ops ~7.7e11 -- and the per-kernel instruction counts by class come from the committed
+        # rocprofv3 --pmc pass of this command (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64).  floor = sum over classes
+        # of count / rate; frac = floor / measured time.  Counts are static (labelled), the step time is this run's.
         valu = None
-        sq = os.path.join(ROOT, 'profiles', 'r02_sq_counters.json')
-        if os.path.exists(sq) and default_workload and not args.image:
+        sq = os.path.join(ROOT, 'profiles', 'r03_sq_counters.json')
+        vr = os.path.join(ROOT, 'profiles', 'r03_valu_rates.json')
+        if os.path.exists(sq) and os.path.exists(vr) and default_workload and not args.image:
             try:
                 sqd = json.load(open(sq))
-                peak_issue = 1024 * 2.4e9 / 4
-                insts = sqd['valu_insts_per_bench_step']
-                valu = {'valu_insts_per_bench_step': insts, 'peak_wave_insts_per_s': peak_issue,
-                        'min_ms_per_step_at_peak_issue': insts / peak_issue * 1e3,
-                        'frac': insts / peak_issue / (elapsed / args.steps),
-                        'per_kernel_valu_insts_per_launch': {k: v.get('SQ_INSTS_VALU') for k, v in sqd['kernels'].items()},
-                        'source': 'static instruction counts: profiles/r02_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU pass '
-                                  'of this command); step time: this run'}
+                ceil = json.load(open(vr))['ceilings']
+                r64, rtr, r32 = ceil['f64_arith_wave_insts_per_s'], ceil['f64_trans_wave_insts_per_s'], ceil['other_valu_wave_insts_per_s']
+                per_kernel, floor_s, insts = {}, 0.0, 0.0
+                for kname, c in sqd['kernels'].items():
+                    v = c.get('SQ_INSTS_VALU', 0.0)
+                    f64 = c.get('SQ_INSTS_VALU_ADD_F64', 0.0) + c.get('SQ_INSTS_VALU_MUL_F64', 0.0) + c.get('SQ_INSTS_VALU_FMA_F64', 0.0)
+                    tr = c.get('SQ_INSTS_VALU_TRANS_F64', 0.0)
+                    fl = f64 / r64 + tr / rtr + max(v - f64 - tr, 0.0) / r32
+                    nl = c.get('launches_per_bench_step', 1)
+                    t_meas = per_step.get(kname, 0.0) * 1e-3
+                    per_kernel[kname] = {'valu_insts_per_launch': v, 'f64_share': (f64 + tr) / v if v else None, 'launches_per_bench_step': nl,
+                                         'floor_ms_per_bench_step': fl * nl * 1e3,
+                                         'frac_of_its_own_event_time': fl * nl / t_meas if t_meas > 0 else None}
+                    floor_s += fl * nl
+                    insts += v * nl
+                valu = {'valu_insts_per_bench_step': insts, 'mix_weighted_floor_ms_per_step': floor_s * 1e3,
+                        'frac': floor_s / (elapsed / args.steps), 'rates_wave_insts_per_s': {'f64_arith': r64, 'f64_trans': rtr, 'other': r32},
+                        'per_kernel': per_kernel,
+                        'source': 'static instruction counts by class: profiles/r03_sq_counters.json (rocprofv3 --pmc passes of this command); '
+                                  'issue rates: profiles/r03_valu_rates.json (tools/valu_rate.py on the same GPU type); step and kernel times: this run. '
+                                  'A single wave issues at most one instruction per ~8-10 cycles, so a kernel needs >= 4 waves per SIMD to reach these rates.'}
             except Exception:
                 valu = None
         # the box's own streaming ceiling next to the 8 TB/s vendor peak: device-to-device copy of 1 GiB

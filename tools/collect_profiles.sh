@@ -14,12 +14,12 @@ py() { python "$@" 2>$O/stderr.log; }
 py $R/bench.py | tail -1 > $O/${TAG}_bench_default.json
 py $R/bench.py --image --no-cpu-baseline | tail -1 > $O/${TAG}_bench_image.json
 
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_img -- python $R/bench.py --image --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_image_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_img -- python $R/bench.py --image --steps 10 --warmup 3 --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1 > $O/${TAG}_bench_image_under_rocprof.json
 for V in "" "_image"; do
   FLAG=""; [ -n "$V" ] && FLAG="--image"
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
   done
 done
 # derived busy / utilisation metrics (list VALU-busy and LDS-bank-conflict next to the HBM fraction)
@@ -28,7 +28,7 @@ for V in "" "_image"; do
   I=0
   for C in "VALUBusy SALUBusy" "LDSBankConflict MemUnitBusy" "OccupancyPercent VALUUtilization"; do
     I=$((I+1))
-    rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --no-cpu-baseline > /dev/null 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
   done
 done
 python $R/tools/reduce_profiles.py $O $TAG
@@ -39,7 +39,7 @@ py $R/tools/stage_times.py --scenes 32768 > $O/${TAG}_stage_times.txt
 py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
 # batch-size sweep, launch modes, new-map turnover, BASELINE configs 4 / 5 on one GPU, 2 ranks sharing the GPU
 {
-  for NS in 4096 8192 16384 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --steps 40 --warmup 10 | tail -1; done
+  for NS in 4096 8192 16384 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 0 --steps 40 --warmup 10 | tail -1; done
   echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 | tail -1
   echo "== --scenes 8192 --graph"; py $R/bench.py --scenes 8192 --graph --no-cpu-baseline --steps 40 --warmup 10 | tail -1
   echo "== --same-map"; py $R/bench.py --same-map --no-cpu-baseline --steps 40 --warmup 10 | tail -1
