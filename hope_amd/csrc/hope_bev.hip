@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
+#include <algorithm>
+
 #include "hope_dev.h"
 #include "hope_internal.h"
 
@@ -42,6 +44,12 @@ constexpr int TILES = BEV_IMG / TILE_OUT;      // 4 x 4 tiles per scene
 constexpr int FB_DIM = 90;                     // window side: 61 crop px * sqrt(2) + rounding
 constexpr int FB_STRIDE = 92;                  // bytes per window row: 23 dwords (odd -> lane-per-row is conflict-free)
 constexpr int FB_BYTES = FB_DIM * FB_STRIDE;
+// static layer (obstacles, start outline, dest: everything _render draws that does not move within an episode): built once per
+// map by k_bev_static in bands of SL_ROWS rows, one byte per pixel in LDS, stored 2 bits per pixel
+constexpr int SL_ROWS = 16, SL_STRIDE = 516;   // 500 pixels + pad: 129 dwords (odd)
+constexpr int SL_BYTES = SL_ROWS * SL_STRIDE;
+constexpr int SL_SLOT = (SL_BYTES + 72 + 15) / 16 * 16;
+constexpr int SL_PARTS = 4;                    // workgroups per rebuilt scene
 constexpr int FB_SLOT = (FB_BYTES + 72 + 15) / 16 * 16;   // window + 64 dummy bytes, 16-byte aligned
 constexpr int BEV_WAVES = 4;                   // waves per workgroup = per scene (they share the span tables)
 constexpr double RENDER_K = 12.0;              // K  configs.py:103
@@ -60,6 +68,13 @@ constexpr int F_SIMPLE = 1;                    // every row has exactly one span
 constexpr uint32_t SPAN_EMPTY = 2u | (1u << 16);   // a0 = 1 > a1 = 0 (stored + 1)
 
 struct Window { int x0, y0, x1, y1; };         // inclusive world-pixel bounds, inside [0, 499]^2
+
+// Byte of the packed static layer that holds world pixel (x, y) (4 pixels per byte).  The layer is TILED: blocks of 32 x 16 pixels
+// are one 128-byte cache line each (16 x 32 blocks per scene), so the ~90 x 90 pixel window a tile samples touches ~28 lines
+// instead of 90 (row-major rows are 128 bytes apart and a window uses 23 bytes of each).
+__device__ __forceinline__ int layer_byte(int x, int y) {
+    return (((y >> 4) << 4) + (x >> 5)) * 128 + ((y & 15) << 3) + ((x & 31) >> 2);
+}
 
 // The crop -> world-surface map of _get_img_observation, wave-uniform.  blit offsets, Rect placement and rotate()'s
 // 16.16 stepping (or rotate90's index swap) are all integer-affine in the crop pixel (x, y), so k_bev_prep folds them:
@@ -112,11 +127,14 @@ __device__ __forceinline__ Spans row_spans(const int (&px)[5], const int (&py)[5
     return r;
 }
 
-__device__ __forceinline__ void hline(uint8_t* fb, const Window& w, int id, int xa, int y, int xb, int lane) {
+// (the raster helpers take the buffer's row stride and size as template parameters: window of the image kernel / band of the
+// static-layer kernel; `wx0` is the world x of the buffer's column 0)
+template <int STRIDE>
+__device__ __forceinline__ void hline(uint8_t* fb, const Window& w, int wx0, int id, int xa, int y, int xb, int lane) {
     if (y < w.y0 || y > w.y1) return;          // the window lies inside the surface: this is also drawhorzlineclip's test
     if (xb < xa) { const int t = xa; xa = xb; xb = t; }
     xa = max(xa, w.x0); xb = min(xb, w.x1);
-    uint8_t* row = fb + __mul24(y - w.y0, FB_STRIDE) - w.x0;
+    uint8_t* row = fb + __mul24(y - w.y0, STRIDE) - wx0;
     for (int x = xa + lane; x <= xb; x += WAVE) row[x] = (uint8_t)id;
 }
 
@@ -133,19 +151,20 @@ __device__ __forceinline__ void fill_span(uint8_t* row, uint8_t* dummy, int id, 
     }
 }
 // draw_fillpoly on the LDS window: n points (closing point included), wave-uniform; lane = row
-__device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, const int (&px)[5], const int (&py)[5], int n,
+template <int STRIDE, int BYTES>
+__device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, int wx0, const int (&px)[5], const int (&py)[5], int n,
                                           int id, int lane) {
     int miny = py[0], maxy = py[0], minx = px[0], maxx = px[0];
 #pragma unroll
     for (int i = 1; i < 5; i++)
         if (i < n) { miny = min(miny, py[i]); maxy = max(maxy, py[i]); minx = min(minx, px[i]); maxx = max(maxx, px[i]); }
-    if (miny == maxy) { hline(fb, w, id, minx, miny, maxx, lane); return; }
+    if (miny == maxy) { hline<STRIDE>(fb, w, wx0, id, minx, miny, maxx, lane); return; }
     const int ylo = max(miny, w.y0), yhi = min(maxy, w.y1);
     for (int yb = ylo; yb <= yhi; yb += WAVE) {
         const int y = yb + lane;
         const Spans c = row_spans(px, py, n, maxy, y, y <= yhi);
-        uint8_t* row = fb + __mul24(y - w.y0, FB_STRIDE) - w.x0;
-        uint8_t* dummy = fb + FB_BYTES + lane;
+        uint8_t* row = fb + __mul24(y - w.y0, STRIDE) - wx0;
+        uint8_t* dummy = fb + BYTES + lane;
         fill_span(row, dummy, id, c.cnt >= 2 ? max(c.a0, w.x0) : 1, c.cnt >= 2 ? min(c.a1, w.x1) : 0);
         if (__any(c.cnt >= 4)) fill_span(row, dummy, id, c.cnt >= 4 ? max(c.a2, w.x0) : 1, c.cnt >= 4 ? min(c.a3, w.x1) : 0);
     }
@@ -154,13 +173,14 @@ __device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, const in
         if (i >= n) continue;
         const int ip = i ? i - 1 : n - 1;
         const int y = py[i];
-        if (miny < y && py[ip] == y && y < maxy) hline(fb, w, id, px[i], y, px[ip], lane);
+        if (miny < y && py[ip] == y && y < maxy) hline<STRIDE>(fb, w, wx0, id, px[i], y, px[ip], lane);
     }
 }
 
 // draw_line (Bresenham, err = (dx > dy ? dx : -dy) / 2) in closed form: step k of the major axis lands on
 //   x-major: (x1 + k sx, y1 + sy ceil((k dy - dx/2) / dx))      y-major: (x1 + sx ceil((k dx - dy/2) / dy), y1 + k sy)
-__device__ __forceinline__ void line(uint8_t* fb, const Window& w, int id, int x1, int y1, int x2, int y2, int lane) {
+template <int STRIDE>
+__device__ __forceinline__ void line(uint8_t* fb, const Window& w, int wx0, int id, int x1, int y1, int x2, int y2, int lane) {
     const int dx = abs(x2 - x1), dy = abs(y2 - y1), sx = x1 < x2 ? 1 : -1, sy = y1 < y2 ? 1 : -1;
     const int steps = max(dx, dy);
     for (int k = lane; k <= steps; k += WAVE) {
@@ -168,7 +188,7 @@ __device__ __forceinline__ void line(uint8_t* fb, const Window& w, int id, int x
         if (steps == 0) { x = x1; y = y1; }
         else if (dx > dy) { x = x1 + k * sx; y = y1 + sy * (int)ceilf((float)(k * dy - dx / 2) / (float)dx); }
         else { y = y1 + k * sy; x = x1 + sx * (int)ceilf((float)(k * dx - dy / 2) / (float)dy); }
-        if (x >= w.x0 && x <= w.x1 && y >= w.y0 && y <= w.y1) fb[(y - w.y0) * FB_STRIDE + x - w.x0] = (uint8_t)id;
+        if (x >= w.x0 && x <= w.x1 && y >= w.y0 && y <= w.y1) fb[(y - w.y0) * STRIDE + x - wx0] = (uint8_t)id;
     }
 }
 
@@ -184,6 +204,14 @@ __device__ __forceinline__ uint32_t palette(int id) {
         default: r = 10; g = 10; b = 10 + 10 * (id - 5); break;   // TRAJ_COLORS[id - 5]  configs.py:84-89
     }
     return r | (g << 10) | (b << 20);
+}
+
+// Ordering of one wave's own LDS traffic: the LDS unit executes a wave's instructions in order, so only the compiler
+// has to be kept from moving accesses across the phase boundaries (the workgroup's waves work on different windows)
+__device__ __forceinline__ void wave_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ====================================================================================================================
@@ -331,7 +359,101 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
             out[OFF_TAB + (l - 1) * TAB_ROWS + lane] = (int)sp;
         }
     }
-    if (lane == 0) p.traj_valid[scene] = traj_len;
+    if (lane == 0) {
+        p.traj_valid[scene] = traj_len;
+        if (p.layer_valid[scene] == 0) {                      // a new map since the layer was built: queue the scene for k_bev_static
+            p.layer_valid[scene] = 1;
+            p.rebuild[1 + atomicAdd(&p.rebuild[0], 1)] = scene;
+        }
+    }
+}
+
+// ====================================================================================================================
+// k_bev_static: the part of _render that cannot change within an episode -- surface.fill(BG), the obstacles, the start
+// outline, the dest box (car_parking_base.py:302-311) -- rasterised ONCE per map into the scene's 500 x 500 layer (2 bits per
+// pixel: 0 background, 1 obstacle, 2 start, 3 dest) with the same pygame routines the image kernel used to run per tile and
+// step.  Four waves per scene, each taking every fourth band of SL_ROWS rows: band in LDS (one byte per pixel), then packed.
+// Scenes come from the list k_bev_prep made; the grid is fixed and strides over it.
+// ====================================================================================================================
+__global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_static(BevParams p) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    uint8_t* fb = lds_raw + wave * SL_SLOT;
+    const int count = p.rebuild[0];
+    // SL_PARTS workgroups per scene, each a quarter of the bands: a rebuilt scene is on the image's critical path
+    for (int it = blockIdx.x; it < SL_PARTS * count; it += gridDim.x) {
+        const int scene = p.rebuild[1 + it / SL_PARTS], part = it % SL_PARTS;
+        const int* scr = p.scratch + (size_t)scene * BEV_SCENE_INTS;
+        const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+        const double offx = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 1] + sc[SC_BBOX])), offy = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 3] + sc[SC_BBOX + 2]));
+        const int n_obst = p.n_obst[scene];
+        uint8_t* layer = p.layer + (size_t)scene * BEV_LAYER_ROWS * BEV_LAYER_STRIDE;
+        // start outline and dest box: the pixel corners k_bev_prep computed (box headers 0 and 1)
+        int sx[5], sy[5], dx[5], dy[5];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            sx[k] = scr[OFF_HDR + H_VX + k]; sy[k] = scr[OFF_HDR + H_VY + k];
+            dx[k] = scr[OFF_HDR + HDR_INTS + H_VX + k]; dy[k] = scr[OFF_HDR + HDR_INTS + H_VY + k];
+        }
+        sx[4] = sx[0]; sy[4] = sy[0]; dx[4] = dx[0]; dy[4] = dy[0];
+        const int n_chunks = (n_obst + WAVE - 1) / WAVE;
+        for (int band = part * BEV_WAVES + wave; band * SL_ROWS < WIN; band += SL_PARTS * BEV_WAVES) {
+            const Window cw = {0, band * SL_ROWS, WIN - 1, min(band * SL_ROWS + SL_ROWS, WIN) - 1};
+            wave_phase();
+            {   // surface.fill(BG_COLOR)
+                uint4* f4 = (uint4*)fb;
+                for (int i = lane; i < (SL_BYTES + 15) / 16; i += WAVE) f4[i] = make_uint4(0, 0, 0, 0);
+            }
+            wave_phase();
+            for (int c = 0; c < n_chunks; c++) {                     // obstacles (:303-305), lane = obstacle
+                const int o = WAVE * c + lane;
+                int vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0}, nv = 0;
+                if (o < n_obst) {
+                    const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { vx[k] = to_px(v[2 * k], v[2 * k + 1], RENDER_K, 0.0, offx); vy[k] = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); }
+                    nv = (v[6] == v[4] && v[7] == v[5]) ? 3 : 4;     // triangles repeat their last vertex (include/hope_env.h)
+                }
+                const int bx0 = min(min(vx[0], vx[1]), min(vx[2], vx[3])), bx1 = max(max(vx[0], vx[1]), max(vx[2], vx[3]));
+                const int by0 = min(min(vy[0], vy[1]), min(vy[2], vy[3])), by1 = max(max(vy[0], vy[1]), max(vy[2], vy[3]));
+                unsigned long long omask = __ballot(nv != 0 && !(bx1 < cw.x0 || bx0 > cw.x1 || by1 < cw.y0 || by0 > cw.y1));
+                while (omask) {
+                    const int l = __builtin_ctzll(omask);
+                    omask &= omask - 1;
+                    int qx[5], qy[5];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
+                    const int qn = __builtin_amdgcn_readlane(nv, l);
+                    if (qn == 3) { qx[3] = qx[0]; qy[3] = qy[0]; qx[4] = qx[0]; qy[4] = qy[0]; }
+                    else { qx[4] = qx[0]; qy[4] = qy[0]; }
+                    fill_poly<SL_STRIDE, SL_BYTES>(fb, cw, 0, qx, qy, qn + 1, 1, lane);
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 5; k++) line<SL_STRIDE>(fb, cw, 0, 2, sx[k - 1], sy[k - 1], sx[k], sy[k], lane);      // start: lines(closed=True), width 1
+            line<SL_STRIDE>(fb, cw, 0, 2, sx[4], sy[4], sx[0], sy[0], lane);
+            fill_poly<SL_STRIDE, SL_BYTES>(fb, cw, 0, dx, dy, 5, 3, lane);                                              // dest
+            wave_phase();
+            // pack: 16 pixels (bytes 0..3) -> one dword of the layer; lane = dword of a row (32 per row), rows two at a time
+            const int rows = cw.y1 - cw.y0 + 1;
+            for (int r0 = 0; r0 < rows; r0 += 2) {
+                const int r = r0 + (lane >> 5), d = lane & 31;
+                if (r < rows) {
+                    uint32_t outw = 0;
+                    if (d < 32) {
+                        const uint8_t* src = fb + r * SL_STRIDE + 16 * d;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const uint32_t q = (16 * d + 4 * t < WIN) ? *(const uint32_t*)(src + 4 * t) : 0u;      // (SL_STRIDE and 16 d are multiples of 4)
+                            const uint32_t b = (q & 3u) | ((q >> 6) & 12u) | ((q >> 12) & 48u) | ((q >> 18) & 192u);
+                            outw |= b << (8 * t);
+                        }
+                    }
+                    *(uint32_t*)(layer + layer_byte(16 * d, cw.y0 + r)) = outw;
+                }
+            }
+        }
+    }
 }
 
 // ====================================================================================================================
@@ -343,14 +465,6 @@ __device__ __forceinline__ void table_span(const uint32_t* tab, int miny, int nr
     const uint32_t sp = (r >= 0 && r < nrows) ? tab[r] : SPAN_EMPTY;
     a = max((int)(sp & 0xffff) - 1, x_lo);
     b = min((int)(sp >> 16) - 1, x_hi);
-}
-
-// Ordering of one wave's own LDS traffic: the LDS unit executes a wave's instructions in order, so only the compiler
-// has to be kept from moving accesses across the phase boundaries (the workgroup's waves work on different windows)
-__device__ __forceinline__ void wave_phase() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // wave 0: 5 1 4 0, wave 1: 6 2 7 3, wave 2: 9 8 13 12, wave 3: 10 11 14 15 -- every wave gets one of the 4 centre tiles
@@ -380,7 +494,6 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
     m.dyx = scr[OFF_MAP + M_DYX]; m.dyy = scr[OFF_MAP + M_DYY]; m.dy0 = scr[OFF_MAP + M_DY0];
     m.rox = scr[OFF_MAP + M_ROX]; m.roy = scr[OFF_MAP + M_ROY];
     const bool veh_hidden = scr[OFF_MAP + M_VEH_HIDDEN] != 0;
-    const int n_obst = (p.debug & 2) ? 0 : p.n_obst[scene];
     const int traj_len = p.traj_len[scene];
     const int m_traj = min(traj_len, BEV_TRAJ_LEN);
     const int n_box = (p.debug & 4) ? 0 : 3 + (traj_len > 1 ? m_traj : 0);
@@ -403,22 +516,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         const int* hdr = scr + OFF_HDR + bslot * HDR_INTS;
         h_miny = hdr[H_MINY]; h_nrows = hdr[H_NROWS]; h_flags = hdr[H_FLAGS]; h_minx = hdr[H_MINX]; h_maxx = hdr[H_MAXX]; h_maxy = hdr[H_MAXY];
     }
-    // obstacles (car_parking_base.py:303-305) as integer pixels, lane = obstacle; the first 128 stay in registers
-    int ovx[2][4], ovy[2][4], onv[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int o = WAVE * c + lane;
-        onv[c] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { ovx[c][k] = 0; ovy[c][k] = 0; }
-        if (o < n_obst) {
-            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { ovx[c][k] = to_px(v[2 * k], v[2 * k + 1], RENDER_K, 0.0, offx); ovy[c][k] = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); }
-            onv[c] = (v[6] == v[4] && v[7] == v[5]) ? 3 : 4;                 // triangles repeat their last vertex (include/hope_env.h)
-        }
-    }
-    const int n_chunks = (n_obst + WAVE - 1) / WAVE;
+    const uint8_t* layer = p.layer + (size_t)scene * BEV_LAYER_ROWS * BEV_LAYER_STRIDE;      // the static layer (k_bev_static)
 
     for (int it = 0; it < TILES * TILES / BEV_WAVES; it++) {
         const int tile = tile_of(wave, it);
@@ -440,73 +538,41 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             w.x0 = max(lo_x, 0); w.x1 = min(hi_x, WIN - 1); w.y0 = max(lo_y, 0); w.y1 = min(hi_y, WIN - 1);
         }
         int bg_id = 0;
+        bool has_dyn = false;                                                // this tile's window holds moving boxes
         // pass 0 (rare): the rotate() background colour is the surface's top-left pixel -- rasterise a 1 x 1 window there
         for (int pass = need_bg ? 0 : 1; pass < 2; pass++) {
             const Window cw = pass == 0 ? Window{0, 0, 0, 0} : w;
-            wave_phase();                                                    // the previous tile's gather is done
-            {   // surface.fill(BG_COLOR)
-                uint4* f4 = (uint4*)fb;
-                for (int i = lane; i < (FB_BYTES + 15) / 16; i += WAVE) f4[i] = make_uint4(0, 0, 0, 0);
-            }
-            wave_phase();
+            const int wx0 = cw.x0;                                           // world x of the window's LDS column 0
             const bool live = cw.x0 <= cw.x1 && cw.y0 <= cw.y1 && !(p.debug & 1);
-            if (live) {
-                for (int c = 0; c < n_chunks; c++) {
-                    int vx[4], vy[4], nv;
-                    if (c < 2) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { vx[k] = c == 0 ? ovx[0][k] : ovx[1][k]; vy[k] = c == 0 ? ovy[0][k] : ovy[1][k]; }
-                        nv = c == 0 ? onv[0] : onv[1];
-                    } else {                                                 // more than 128 obstacles: convert again
-                        const int o = WAVE * c + lane;
-                        nv = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { vx[k] = 0; vy[k] = 0; }
-                        if (o < n_obst) {
-                            const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
-#pragma unroll
-                            for (int k = 0; k < 4; k++) { vx[k] = to_px(v[2 * k], v[2 * k + 1], RENDER_K, 0.0, offx); vy[k] = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); }
-                            nv = (v[6] == v[4] && v[7] == v[5]) ? 3 : 4;
-                        }
-                    }
-                    const int bx0 = min(min(vx[0], vx[1]), min(vx[2], vx[3])), bx1 = max(max(vx[0], vx[1]), max(vx[2], vx[3]));
-                    const int by0 = min(min(vy[0], vy[1]), min(vy[2], vy[3])), by1 = max(max(vy[0], vy[1]), max(vy[2], vy[3]));
-                    unsigned long long omask = __ballot(nv != 0 && !(bx1 < cw.x0 || bx0 > cw.x1 || by1 < cw.y0 || by0 > cw.y1));
-                    while (omask) {
-                        const int l = __builtin_ctzll(omask);
-                        omask &= omask - 1;
-                        int qx[5], qy[5];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
-                        const int qn = __builtin_amdgcn_readlane(nv, l);
-                        if (qn == 3) { qx[3] = qx[0]; qy[3] = qy[0]; qx[4] = qx[0]; qy[4] = qy[0]; }
-                        else { qx[4] = qx[0]; qy[4] = qy[0]; }
-                        fill_poly(fb, cw, qx, qy, qn + 1, 1, lane);
-                    }
+            // The LDS window only holds what MOVES -- the vehicle and the trajectory boxes (0 = nothing drawn) -- and only for
+            // tiles such a box reaches (the centre of the crop and the trail behind the car); the static part of the surface
+            // (background, obstacles, start outline, dest) is sampled straight from the scene's packed layer by the gather.
+            bool hit = live && lane >= 2 && lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
+            if (lane == 2 && veh_hidden) hit = false;
+            unsigned long long mask = __ballot(hit);
+            const bool dyn = mask != 0;
+            if (pass == 1) has_dyn = dyn;
+            if (dyn) {
+                wave_phase();                                                // the previous tile's gather is done
+                {
+                    uint4* f4 = (uint4*)fb;
+                    for (int i = lane; i < (FB_BYTES + 15) / 16; i += WAVE) f4[i] = make_uint4(0, 0, 0, 0);
                 }
+                wave_phase();
                 // boxes in draw order
-                bool hit = lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
-                if (lane == 2 && veh_hidden) hit = false;
-                unsigned long long mask = __ballot(hit);
                 while (mask) {
                     const int l = __builtin_ctzll(mask);
                     mask &= mask - 1;
                     const int qid = __builtin_amdgcn_readlane(bid, l);
                     const int qslot = __builtin_amdgcn_readlane(bslot, l);
                     const int qflags = __builtin_amdgcn_readlane(h_flags, l);
-                    if (qid == 2 || !(qflags & F_SIMPLE)) {
+                    if (!(qflags & F_SIMPLE)) {
                         const int* hdr = scr + OFF_HDR + qslot * HDR_INTS;
                         int qx[5], qy[5];
 #pragma unroll
                         for (int k = 0; k < 4; k++) { qx[k] = hdr[H_VX + k]; qy[k] = hdr[H_VY + k]; }
                         qx[4] = qx[0]; qy[4] = qy[0];
-                        if (qid == 2) {                                      // width=1: lines(closed=True)
-#pragma unroll
-                            for (int k = 1; k < 5; k++) line(fb, cw, 2, qx[k - 1], qy[k - 1], qx[k], qy[k], lane);
-                            line(fb, cw, 2, qx[4], qy[4], qx[0], qy[0], lane);
-                        } else {
-                            fill_poly(fb, cw, qx, qy, 5, qid, lane);         // never for a car-shaped box; kept for exactness
-                        }
+                        fill_poly<FB_STRIDE, FB_BYTES>(fb, cw, wx0, qx, qy, 5, qid, lane);      // never for a car-shaped box; kept for exactness
                         continue;
                     }
                     const int qminy = __builtin_amdgcn_readlane(h_miny, l), qnrows = __builtin_amdgcn_readlane(h_nrows, l);
@@ -529,7 +595,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                                 if (sa > sb) { sa = INT_MAX; sb = INT_MIN; }
                             }
                         }
-                        uint8_t* row = fb + __mul24(y - cw.y0, FB_STRIDE) - cw.x0;
+                        uint8_t* row = fb + __mul24(y - cw.y0, FB_STRIDE) - wx0;
                         uint8_t* dummy = fb + FB_BYTES + lane;
                         if (has_next) {                                      // left and right of the successor's span
                             fill_span(row, dummy, qid, xa, min(xb, sa - 1));
@@ -541,7 +607,10 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                 }
             }
             wave_phase();
-            if (pass == 0) bg_id = fb[0];
+            if (pass == 0) {                                                 // rotate()'s background: the surface's pixel (0, 0)
+                const int did = dyn ? fb[0] : 0;
+                bg_id = did ? did : ((p.debug & 2) ? 0 : (layer[0] & 3));
+            }
         }
 
         // ---- gather: lane = 4 consecutive outputs of one tile row; cv2.resize reads crop pixels (4u+1|2, 4v+1|2) -----
@@ -565,7 +634,10 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int dx = dxb + ((s & 1) ? m.dxx : 0) + ((s >> 1) ? m.dxy : 0), dy = dyb + ((s & 1) ? m.dyx : 0) + ((s >> 1) ? m.dyy : 0);
-                    const int id = fb[__mul24((dy >> 16) - w.y0, FB_STRIDE) + (dx >> 16) - w.x0];
+                    const int wx = dx >> 16, wy = dy >> 16;
+                    int id = (layer[layer_byte(wx, wy)] >> ((wx & 3) * 2)) & 3;
+                    if (p.debug & 2) id = 0;
+                    if (has_dyn) { const int did = fb[__mul24(wy - w.y0, FB_STRIDE) + wx - w.x0]; id = did ? did : id; }
                     ids[jj] |= (uint32_t)id << (8 * s);
                 }
                 dxb += dxx4; dyb += dyx4;                                     // next output: 4 crop pixels to the right
@@ -580,7 +652,10 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                     const bool white = (unsigned)(4 * u0 + 1 + ax_ + m.rox) >= (unsigned)WIN || (ay_ ? row_out1 : row_out0);
                     const bool outside = (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
                     const int sx = min(max(dx >> 16, w.x0), wx1), sy = min(max(dy >> 16, w.y0), wy1);
-                    int id = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0];
+                    const int lx = min(sx, WIN - 1), ly = min(sy, WIN - 1);  // (an empty window lies beyond the surface: the read is discarded, keep it in bounds)
+                    int id = (layer[layer_byte(lx, ly)] >> ((lx & 3) * 2)) & 3;
+                    if (p.debug & 2) id = 0;
+                    if (has_dyn) { const int did = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0]; id = did ? did : id; }
                     id = outside ? bg_id : id;                                // rotate()'s bgcolor
                     id = white ? 0 : id;                                      // observation.fill(BG_COLOR) -> black later
                     ids[jj] |= (uint32_t)id << (8 * s);
@@ -607,8 +682,20 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
 size_t bev_lds_bytes() { return 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * FB_SLOT; }
 
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer) {
+    hipError_t e = hipMemsetAsync(p.rebuild, 0, sizeof(int32_t), stream);          // the list of stale layers starts empty
+    if (e != hipSuccess) return e;
     if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
     hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
+    // the layers of the scenes that got a new map since the last image (a fixed grid strides over k_bev_prep's list; the usual
+    // step has a fraction of a per cent of the scenes in it, the first one all of them)
+    const size_t lds_static = (size_t)BEV_WAVES * SL_SLOT;
+    static bool attr_done = false;
+    if (!attr_done && lds_static > 48 * 1024) {
+        e = hipFuncSetAttribute((const void*)k_bev_static, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_static);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_bev_static, dim3(std::min(SL_PARTS * p.n, 4096)), dim3(BEV_WAVES * WAVE), lds_static, stream, p);
     if (timer) timer->end(stream);
     const dim3 grid(p.n), block(BEV_WAVES * WAVE);
     if (timer) timer->begin(HOPE_K_IMAGE, stream);

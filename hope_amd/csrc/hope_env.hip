@@ -53,6 +53,9 @@ struct hope_env {
     double* traj = nullptr;        // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory
     int32_t* traj_len = nullptr;   // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
     int32_t* traj_valid = nullptr; // HOPE_F_IMAGE: [n] entries below this index have span tables in bev_scratch
+    int32_t* layer_valid = nullptr; // HOPE_F_IMAGE: [n] the static image layer (obstacles, start outline, dest) matches the scene's map
+    uint8_t* bev_layer = nullptr;   // HOPE_F_IMAGE: [n][64 KiB] the static layer, 2 bits per pixel, tiled
+    int32_t* bev_list = nullptr;    // HOPE_F_IMAGE: [1 + n] count + scenes whose layer must be rebuilt this step
     int* bev_scratch = nullptr;    // HOPE_F_IMAGE: [n][BEV_SCENE_INTS]
     // per tile class (0: n_obst <= SMALL_TILE, 1: larger) dense scene lists; classes are static between set_scenes calls
     int32_t* cls_list[2] = {nullptr, nullptr};
@@ -218,7 +221,8 @@ namespace {
 // one thread per uploaded scene: constants, derived dest box, episode state reset
 __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* start, const double* dest,
                                    const double* bbox, const int32_t* nob, double* scene_c, double* state,
-                                   int32_t* tstep, int32_t* n_obst, double* traj, int32_t* traj_len, int32_t* traj_valid) {
+                                   int32_t* tstep, int32_t* n_obst, double* traj, int32_t* traj_len, int32_t* traj_valid,
+                                   int32_t* layer_valid) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int s = ids ? ids[k] : k;
@@ -234,6 +238,7 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
         tr[0] = st[0]; tr[1] = st[1]; tr[2] = st[2];
         traj_len[s] = 1;
         traj_valid[s] = 0;
+        layer_valid[s] = 0;                                           // a new map: the static image layer is rebuilt
     }
 }
 
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
                                                const int32_t* pnob, double* verts, double* scene_c, int32_t* n_obst,
                                                double* state, int32_t* tstep, double* traj, int32_t* traj_len,
                                                int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode, float4* obb, DlpCases dlp,
-                                               int32_t* overflow, const uint8_t* slot_cls) {
+                                               int32_t* overflow, const uint8_t* slot_cls, int32_t* layer_valid) {
     __shared__ double c24[SC_WORDS];
     const int s = blockIdx.x, lane = threadIdx.x;
     if (!mask[s]) return;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
                                 obb + (size_t)s * max_obst, c24, nullptr, overflow, lane);
         __syncthreads();
         if (lane < SC_WORDS) c[lane] = c24[lane];
-        if (lane == 0) { n_obst[s] = nob; cur_pool[s] = j; }
+        if (lane == 0) { n_obst[s] = nob; cur_pool[s] = j; if (layer_valid) layer_valid[s] = 0; }
     } else if (lane < SC_WORDS) c24[lane] = c[lane];
     __syncthreads();
     if (lane == 0) {
@@ -467,6 +472,9 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
         ALLOC(h->traj_len, N * sizeof(int32_t));
         ALLOC(h->traj_valid, N * sizeof(int32_t));
+        ALLOC(h->layer_valid, N * sizeof(int32_t));
+        ALLOC(h->bev_layer, N * (size_t)BEV_LAYER_ROWS * BEV_LAYER_STRIDE);
+        ALLOC(h->bev_list, (N + 1) * sizeof(int32_t));
         ALLOC(h->bev_scratch, N * BEV_SCENE_INTS * sizeof(int));
     }
 #undef ALLOC
@@ -474,6 +482,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         HIPCHK(hipMemset(h->traj, 0, N * BEV_TRAJ_LEN * 3 * sizeof(double)));
         HIPCHK(hipMemset(h->traj_len, 0, N * sizeof(int32_t)));
         HIPCHK(hipMemset(h->traj_valid, 0, N * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->layer_valid, 0, N * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->bev_list, 0, (N + 1) * sizeof(int32_t)));
         HIPCHK(hipMemset(h->bev_scratch, 0, N * BEV_SCENE_INTS * sizeof(int)));
     }
     HIPCHK(hipMemset(h->n_obst, 0, N * sizeof(int32_t)));
@@ -540,7 +550,7 @@ int hope_env_destroy(hope_env_t* h) {
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->obb, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_list, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -616,7 +626,8 @@ int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double*
 
 static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double* start, const double* dest, const double* bbox,
                          const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
-                         int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid);
+                         int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid,
+                         int32_t* d_layer_valid);
 
 // The dense per-class scene lists of the launch chains and the per-slot class byte (host mirror; reset-time only).  A slot's class
 // decides which launch chain steps it (LDS tile of 32 or max_obstacles obstacles) AND which pool entries it draws at episode
@@ -664,7 +675,7 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     {
         int rc = upload_scenes(h, scene_ids, n, start, dest, bbox, verts, n_obst, h->scene_c, h->state, h->tstep, h->n_obst,
-                               h->verts, h->obb, h->traj, h->traj_len, h->traj_valid);
+                               h->verts, h->obb, h->traj, h->traj_len, h->traj_valid, h->layer_valid);
         if (rc != HOPE_OK) return rc;
     }
     for (int k = 0; k < n; k++) {
@@ -687,7 +698,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
     p.verts = h->verts; p.obb = h->obb; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
     p.actions = actions; p.active = active; p.kin = h->kin; p.post = h->post;
-    p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid;
+    p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid; p.layer_valid = h->layer_valid;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.out = *out;
     p.pool_verts = h->pool_verts; p.pool_c = h->pool_c; p.pool_nobst = h->pool_nobst;
@@ -814,6 +825,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         BevParams b;
         b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
         b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.traj_valid = h->traj_valid; b.scratch = h->bev_scratch; b.img = out->img;
+        b.layer = h->bev_layer; b.layer_valid = h->layer_valid; b.rebuild = h->bev_list;
         // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
         b.active = active;
         b.debug = (stages >> 12) & 0xF;
@@ -930,7 +942,8 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
 // Shared by set_scenes and set_pool: stage the host arrays and write constants / tiles for entries ids[0..n)
 static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double* start, const double* dest, const double* bbox,
                          const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
-                         int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid) {
+                         int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid,
+                         int32_t* d_layer_valid) {
     size_t tile = (size_t)h->max_obst * 8 * sizeof(double);
     size_t o_ids = 0, o_nob = o_ids + sizeof(int32_t) * n, o_start = (o_nob + sizeof(int32_t) * n + 15) & ~(size_t)15;
     size_t o_dest = o_start + 24 * (size_t)n, o_bbox = o_dest + 24 * (size_t)n, o_verts = (o_bbox + 32 * (size_t)n + 15) & ~(size_t)15;
@@ -951,7 +964,7 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
     if (verts) HIPCHK(hipMemcpy(sp + o_verts, verts, tile * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_scene_consts, dim3((n + 127) / 128), dim3(128), 0, 0, n, (const int32_t*)(sp + o_ids),
                        (const double*)(sp + o_start), (const double*)(sp + o_dest), (const double*)(sp + o_bbox),
-                       (const int32_t*)(sp + o_nob), d_scene_c, d_state, d_t, d_nobst, d_traj, d_traj_len, d_traj_valid);
+                       (const int32_t*)(sp + o_nob), d_scene_c, d_state, d_t, d_nobst, d_traj, d_traj_len, d_traj_valid, d_layer_valid);
     if (verts)
         hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
                            (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), d_verts, d_obb, h->max_obst);
@@ -1064,7 +1077,7 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     h->pstage.busy = true;
     hipLaunchKernelGGL(k_set_scene_consts, dim3((n_pool + 127) / 128), dim3(128), 0, us, n_pool, (const int32_t*)nullptr,
                        (const double*)dv, (const double*)(dv + P * 24), (const double*)(dv + P * 48), (const int32_t*)nullptr, ps.c,
-                       (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+                       (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev_pool_ready, us));
     // swap: every launch enqueued from now on reads the new set, after waiting (on its own stream) for the upload
@@ -1217,7 +1230,7 @@ int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* str
     hipLaunchKernelGGL(k_redraw, dim3(h->n), dim3(WAVE), 0, (hipStream_t)stream, h->max_obst, mask, seed, h->pool_cls[0],
                        h->pool_cls_n[0], h->pool_cls[1], h->pool_cls_n[1], h->pool_verts, h->pool_c, h->pool_nobst, h->verts,
                        h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode, h->obb,
-                       h->dlp, h->pool_overflow, h->slot_cls);
+                       h->dlp, h->pool_overflow, h->slot_cls, h->layer_valid);
     HIPCHK(hipGetLastError());
     if (h->pactive >= 0 && h->ev_last_step) HIPCHK(hipEventRecord(h->ev_last_step, (hipStream_t)stream));
     return HOPE_OK;

@@ -55,6 +55,7 @@ struct RsParams {
 // bird's-eye image observation (hope_bev.hip)
 constexpr int BEV_IMG = HOPE_IMG_SIZE;
 constexpr int BEV_TRAJ_LEN = HOPE_TRAJ_RENDER_LEN;
+constexpr int BEV_LAYER_ROWS = 512, BEV_LAYER_STRIDE = 128;   // 500 x 500 world pixels, 4 per byte, tiled in 32 x 16 pixel blocks of 128 bytes: 16 x 32 blocks = 64 KiB per scene
 constexpr int BEV_SCENE_INTS = 16 + (3 + BEV_TRAJ_LEN) * 16 + (2 + BEV_TRAJ_LEN) * 64;   // k_bev_prep's per-scene scratch
 struct BevParams {
     int n, max_obst;
@@ -65,6 +66,9 @@ struct BevParams {
     const double* traj;       // [n][BEV_TRAJ_LEN][3] ring of vehicle.trajectory: entry e lives in slot e % BEV_TRAJ_LEN
     const int32_t* traj_len;  // [n] len(vehicle.trajectory)
     int32_t* traj_valid;      // [n] trajectory entries below this index already have their span table
+    uint8_t* layer;           // [n][BEV_LAYER_ROWS][BEV_LAYER_STRIDE] static layer (obstacles, start outline, dest): 2 bits per pixel
+    int32_t* layer_valid;     // [n] the layer matches the scene's map
+    int32_t* rebuild;         // [1 + n] count, then the scenes k_bev_prep found with a stale layer (k_bev_static rebuilds them)
     int* scratch;             // [n][BEV_SCENE_INTS] map + box headers + span tables (k_bev_prep -> k_bev_image)
     const uint8_t* active;    // [n] or null
     uint8_t* img;             // [n][3][64][64]

@@ -137,6 +137,7 @@ struct StepParams {
     double* traj;             // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory (entry e in slot e % 20), else null
     int32_t* traj_len;        // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
     int32_t* traj_valid;      // HOPE_F_IMAGE: [n] span-table watermark of the image kernels (0 after a reset)
+    int32_t* layer_valid;     // HOPE_F_IMAGE: [n] the static image layer matches the scene's map (0 after a new map)
     const uint8_t* active;    // [n] or null
     const double* tab;        // prefix-max mask table [NL][NITER][NACT]
     const double* pmax;       // [NL] max over (a,k) of tab
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                     if (lane < SC_WORDS) gsc[lane] = c24[lane];
                     sc = c24;
                 }
-                if (lane == 0) { const_cast<int32_t*>(p.n_obst)[scene] = nob; p.cur_pool[scene] = j; p.episode[scene] = ep + 1; }
+                if (lane == 0) { const_cast<int32_t*>(p.n_obst)[scene] = nob; p.cur_pool[scene] = j; p.episode[scene] = ep + 1; if (p.layer_valid) p.layer_valid[scene] = 0; }
                 if (lane < 8) dbox[lane] = sc[SC_DBOX + lane];
                 dest_area = sc[SC_DAREA];
                 n_obst = nob;
