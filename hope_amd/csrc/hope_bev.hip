@@ -482,6 +482,8 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     uint8_t* fb = lds_raw + 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + wave * FB_SLOT;   // + 64 dummy bytes (fill_span)
     const int scene = scene_of_block(blockIdx.x, p.n);
+    // k_bev_static (the launch before this one) has consumed the list of stale layers: it starts empty for the next image
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.rebuild[0] = 0;
     if (scene >= p.n) return;
     if (p.active && !p.active[scene]) return;
     const int* scr = p.scratch + (size_t)scene * BEV_SCENE_INTS;
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
 size_t bev_lds_bytes() { return 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * FB_SLOT; }
 
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer) {
-    hipError_t e = hipMemsetAsync(p.rebuild, 0, sizeof(int32_t), stream);          // the list of stale layers starts empty
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    // (p.rebuild[0], the length of the list of stale layers, is zero here: hope_env_create clears it and k_bev_image resets it)
     if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
     hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
     // the layers of the scenes that got a new map since the last image (a fixed grid strides over k_bev_prep's list; the usual

@@ -496,6 +496,14 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
     HIPCHK(hipMemset(h->pool_overflow, 0, sizeof(int32_t)));
     HIPCHK(hipMemset(h->slot_cls, 0, N));
+    if (getenv("HOPE_DEBUG_PTRS")) {
+        fprintf(stderr, "hope_env %p: verts %p obb %p scene_c %p state %p kin %p post %p rs_rec %p rs_list %p cls0 %p cls1 %p", (void*)h, (void*)h->verts, (void*)h->obb, (void*)h->scene_c,
+                (void*)h->state, (void*)h->kin, (void*)h->post, (void*)h->rs_rec, (void*)h->rs_list, (void*)h->cls_list[0], (void*)h->cls_list[1]);
+        if (h->traj) fprintf(stderr, " traj %p layer %p..%p bev_list %p scratch %p..%p", (void*)h->traj, (void*)h->bev_layer, (void*)(h->bev_layer + N * (size_t)BEV_LAYER_ROWS * BEV_LAYER_STRIDE),
+                             (void*)h->bev_list, (void*)h->bev_scratch, (void*)(h->bev_scratch + N * BEV_SCENE_INTS));
+        fprintf(stderr, "\n");
+    }
+    HIPCHK(rs_init_tables());        // (a synchronous symbol copy: here, never inside a captured step)
     if (lds > 48 * 1024) {
         for (const void* f : {(const void*)k_env_step<float, float>, (const void*)k_env_step<float, float, true>,
                               (const void*)k_env_step<float, double>, (const void*)k_env_step<double, float>,

@@ -1424,7 +1424,7 @@ hipError_t rs_fstat_read(unsigned long long* out /*[16]*/, int reset) {
 }
 
 // first-segment sample table of k_rs_validate_f: step added k + 1 times, sequentially, in float64 (the reference's `pd += d`)
-static hipError_t rs_init_tables() {
+hipError_t rs_init_tables() {
     static bool done[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
