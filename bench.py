@@ -63,6 +63,10 @@ def parse():
     ap.add_argument('--cpu-scenes', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=12)
     ap.add_argument('--seed', type=int, default=42)
+    ap.add_argument('--rs-join', default='deferred', choices=['deferred', 'joined'],
+                    help='deferred (HOPE_DEFER_RS): the caller\'s stream is ordered after the observation / reward outputs of a step; its '
+                         'Reeds-Shepp outputs are ordered by hope_env_wait_rs or the next step, so consecutive steps pipeline on the '
+                         'library\'s streams.  joined: every output ordered on the caller\'s stream before the next step is enqueued')
     ap.add_argument('--witness', type=int, default=1024,
                     help='after the timed region: this many random scene slots of the TIMED configuration are rebuilt in the CPU '
                          'oracle from the state on the device and one more fused step is compared (parity_check); 0 = off')
@@ -158,9 +162,11 @@ def main():
     g.manual_seed(args.seed + rank)
     act_bank = [torch.rand((N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
 
+    defer = args.rs_join == 'deferred'
+
     def one_step(i):
         # episode turnover is fused into the step (HOPE_AUTO_RESET = step + restart(done) + reset_obs(active=done))
-        env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True)
+        env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, defer_rs=defer)
 
     fresh = not args.same_map
     gen_rate = None
@@ -181,7 +187,7 @@ def main():
 
         def one_step(i):  # noqa: F811
             # the new map is drawn inside the step kernel (HOPE_AUTO_REDRAW = step + redraw(done) + reset_obs(active=done))
-            env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, fresh=True)
+            env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, fresh=True, defer_rs=defer)
 
     trainer = None
     if args.policy == 'hope':
@@ -371,6 +377,9 @@ def main():
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
+                       'rs_join': ('deferred: the caller\'s stream is ordered after each step\'s observation / reward / status outputs, its '
+                                   'Reeds-Shepp outputs by the next step on the library\'s streams (HOPE_DEFER_RS); all work of the K steps '
+                                   'is complete at the closing synchronize') if (defer and trainer is None) else 'joined',
                        'episode_turnover': (f'new map per episode, drawn inside the step kernel (HOPE_AUTO_REDRAW): generated lots from a device-resident pool of '
                                             f'{args.pool} scenes, Dragon-Lake cases drawn on the device (start candidate, jitter, flips, cull per episode)'
                                             if fresh else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),

@@ -219,10 +219,15 @@ class ParkingBatch:
         L.check(self.lib.hope_env_set_redraw_seed(self.h, C.c_uint64(int(seed) & (2 ** 64 - 1))), 'hope_env_set_redraw_seed')
         return self
 
-    def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False, fresh=False):
+    def step(self, actions, active=None, stages=L.STAGE_ALL, auto_reset=False, fresh=False, defer_rs=False):
         """actions: [N, 2] (steer, speed) in [-1, 1] on this device.  auto_reset=True: finished scenes restart inside
         the step (their lidar / action_mask / target are the new episode's first observation) -- on the same map, or with
-        fresh=True on a NEW map drawn from the device-resident scene pool (set_pool), like step() + turnover() in one call."""
+        fresh=True on a NEW map drawn from the device-resident scene pool (set_pool), like step() + turnover() in one call.
+        defer_rs=True (HOPE_DEFER_RS): the current stream is ordered after the observation / reward / status outputs only;
+        call wait_rs() before reading rs_word / rs_lengths (the planner override), the policy forward in between overlaps the
+        Reeds-Shepp kernels."""
+        if defer_rs:
+            stages |= L.DEFER_RS
         if self.image and (stages & L.STAGE_ALL) == L.STAGE_ALL:
             stages |= L.STAGE_IMG                    # USE_IMG (configs.py:100): the image is part of the observation
         if auto_reset:
@@ -236,6 +241,11 @@ class ParkingBatch:
         ap = C.c_void_p(active.data_ptr()) if active is not None else None
         L.check(self.lib.hope_env_step(self.h, C.c_void_p(actions.data_ptr()), ap, stages, C.byref(self._out),
                                        self._stream()), 'hope_env_step')
+        return self
+
+    def wait_rs(self):
+        """orders the current stream after the Reeds-Shepp outputs of the last step(defer_rs=True); no-op otherwise."""
+        L.check(self.lib.hope_env_wait_rs(self.h, self._stream()), 'hope_env_wait_rs')
         return self
 
     def restart(self, mask):

@@ -12,7 +12,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fn
 
 
 def lib_path():
-    return os.path.join(_HERE, 'libhope_env.so')
+    # HOPE_AMD_LIB: another build of the same ABI (A/B timing of two kernel versions in one gpurun call)
+    return os.environ.get('HOPE_AMD_LIB') or os.path.join(_HERE, 'libhope_env.so')
 
 
 def _stale(out):

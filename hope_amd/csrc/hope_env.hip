@@ -110,6 +110,9 @@ struct hope_env {
     int sub_chains = 1;
     hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {};
+    // HOPE_DEFER_RS: the chains of the last step have not been joined into the caller's stream (events ev_join[1], ev_join[RS_SIDE])
+    static constexpr int RS_SIDE = 5;                       // the stream of the first chain when it may not run on the caller's
+    bool rs_pending = false;
     // HOPE_F_GRAPH: the launches of one step, captured on a library stream and replayed while the arguments repeat
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -410,6 +413,23 @@ static void launch_env_step(bool of64, bool af64, dim3 grid, dim3 block, size_t 
 
 extern "C" {
 
+// HOPE_DEFER_RS bookkeeping: `s` waits for the chains the last step left unjoined / the host does
+static int join_rs(hope_env_t* h, hipStream_t s) {
+    if (!h->rs_pending) return HOPE_OK;
+    HIPCHK(hipStreamWaitEvent(s, h->ev_join[1], 0));
+    HIPCHK(hipStreamWaitEvent(s, h->ev_join[hope_env::RS_SIDE], 0));
+    h->rs_pending = false;
+    return HOPE_OK;
+}
+static int settle_rs(hope_env_t* h) {
+    if (!h || !h->rs_pending) return HOPE_OK;
+    DeviceGuard guard(h->device);
+    HIPCHK(hipEventSynchronize(h->ev_join[1]));
+    HIPCHK(hipEventSynchronize(h->ev_join[hope_env::RS_SIDE]));
+    h->rs_pending = false;
+    return HOPE_OK;
+}
+
 const char* hope_last_error(void) { return g_err.c_str(); }
 int hope_abi_version(void) { return HOPE_ABI_VERSION; }
 
@@ -542,6 +562,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
 }
 
 int hope_env_destroy(hope_env_t* h) {
+    settle_rs(h);
     if (!h) return HOPE_OK;
     DeviceGuard guard(h->device);
     drain_events(h);
@@ -671,6 +692,7 @@ static int rebuild_class_lists(hope_env_t* h) {
 
 int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const double* start, const double* dest,
                         const double* bbox, const double* verts, const int32_t* n_obst) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n < 0 || (n > 0 && (!scene_ids || !start || !dest || !bbox || !n_obst)))
         return fail(HOPE_EINVAL, "hope_env_set_scenes: null argument");
     if (n == 0) return HOPE_OK;
@@ -759,14 +781,18 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     const char* split_min = getenv("HOPE_SPLIT_MIN");      // (read per call: the tests force the split at small sizes)
     const bool split = fork && n_chain == 2 && want_rs && (stages & HOPE_STAGE_OBS) && !step_timing && !no_split &&
                        h->n >= (split_min ? atoi(split_min) : 16384);
+    // HOPE_DEFER_RS: both chains on library streams, the caller's stream joins the observation half only (hope_env.h)
+    const bool defer = split && (stages & HOPE_DEFER_RS) && !(h->flags & HOPE_F_GRAPH);
+    if (!defer) { int rcj = join_rs(h, s); if (rcj != HOPE_OK) return rcj; }    // (a deferred step's launches follow the unjoined ones on the same streams)
     if (fork) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         for (int i = 1; i < n_streams; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
+        if (defer) HIPCHK(hipStreamWaitEvent(h->side[hope_env::RS_SIDE], h->ev_fork, 0));
     }
     for (int i = 0; i < n_chain; i++) {
         const Chain& ch = chains[i];
         const int c = ch.c;
-        hipStream_t sc = (fork && ch.st > 0) ? h->side[ch.st] : s;
+        hipStream_t sc = (fork && ch.st > 0) ? h->side[ch.st] : defer ? h->side[hope_env::RS_SIDE] : s;
         int32_t* counter = h->rs_count + i;
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.scene_list = h->cls_list[c] + ch.a;
@@ -853,7 +879,12 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         }
     }
     if (fork) {
-        for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
+        if (defer) {                                            // the chains stay unjoined: hope_env_wait_rs / the next step
+            HIPCHK(hipEventRecord(h->ev_join[1], h->side[1]));
+            HIPCHK(hipEventRecord(h->ev_join[hope_env::RS_SIDE], h->side[hope_env::RS_SIDE]));
+            h->rs_pending = true;
+        } else
+            for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
         if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
         if (split) for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
     }
@@ -1047,6 +1078,7 @@ int hope_env_pool_staging(hope_env_t* h, int n_pool, double** start, double** de
 }
 
 int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n_pool <= 0) return fail(HOPE_EINVAL, "hope_env_commit_pool: bad argument");
     if (n_pool > h->pstage.cap) return fail(HOPE_ESTATE, "hope_env_commit_pool: more entries than hope_env_pool_staging provided");
     for (int k = 0; k < n_pool; k++)
@@ -1103,6 +1135,7 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
 
 int hope_env_set_pool(hope_env_t* h, int n_pool, const double* start, const double* dest, const double* bbox,
                       const double* verts, const int32_t* n_obst) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n_pool <= 0 || !start || !dest || !bbox || !verts || !n_obst) return fail(HOPE_EINVAL, "hope_env_set_pool: bad argument");
     for (int k = 0; k < n_pool; k++)
         if (n_obst[k] < 0 || n_obst[k] > h->max_obst) return fail(HOPE_EINVAL, "hope_env_set_pool: n_obst exceeds max_obstacles");
@@ -1141,6 +1174,7 @@ static int refresh_pool_lists_sync(hope_env_t* h) {
 
 int hope_env_set_dlp_cases(hope_env_t* h, int n_cases, const double* dest, const int32_t* cand_off, const double* cand,
                            const int32_t* case_set, int n_sets, const int32_t* set_off, const double* set_verts) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n_cases < 0 || (n_cases > 0 && (!dest || !cand_off || !cand || !case_set || n_sets <= 0 || !set_off || !set_verts)))
         return fail(HOPE_EINVAL, "hope_env_set_dlp_cases: bad argument");
     for (int c = 0; c < n_cases; c++) {
@@ -1171,6 +1205,7 @@ int hope_env_set_dlp_cases(hope_env_t* h, int n_cases, const double* dest, const
 }
 
 int hope_env_set_draw_class(hope_env_t* h, const int32_t* scene_ids, int n, const uint8_t* cls) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n < 0 || (n > 0 && (!scene_ids || !cls))) return fail(HOPE_EINVAL, "hope_env_set_draw_class: null argument");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_set_draw_class: hope_env_set_scenes has not been called");
     for (int k = 0; k < n; k++) {
@@ -1190,6 +1225,7 @@ int hope_env_set_draw_class(hope_env_t* h, const int32_t* scene_ids, int n, cons
 }
 
 int hope_env_pool_overflow(hope_env_t* h, int32_t* count) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || !count) return fail(HOPE_EINVAL, "hope_env_pool_overflow: null argument");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
@@ -1201,6 +1237,7 @@ int hope_env_pool_overflow(hope_env_t* h, int32_t* count) {
 // the maps the scenes hold NOW (after device-side draws they exist on the device only): host-synchronous
 int hope_env_download_scenes(hope_env_t* h, const int32_t* scene_ids, int n, double* start, double* dest, double* bbox, double* verts,
                              int32_t* n_obst) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n < 0 || (n > 0 && !scene_ids)) return fail(HOPE_EINVAL, "hope_env_download_scenes: bad argument");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
@@ -1227,6 +1264,7 @@ int hope_env_set_redraw_seed(hope_env_t* h, uint64_t seed) {
 }
 
 int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* stream) {
+    if (h) { DeviceGuard g0(h->device); int rcs = join_rs(h, (hipStream_t)stream); if (rcs != HOPE_OK) return rcs; }
     if (!h || !mask) return fail(HOPE_EINVAL, "hope_env_redraw: null argument");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_redraw: hope_env_set_scenes has not been called");
     if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_redraw: no scene pool (hope_env_set_pool / hope_env_set_dlp_cases)");
@@ -1248,6 +1286,7 @@ int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* str
 // counter) and of the pool / case lists, so a map is restored by repeating its draw: the counters go back by one and k_redraw runs
 // for the scenes that held a drawn map.  Pose / t / accumulator are restored separately (hope_env_upload_state, afterwards).
 int hope_env_download_pool_state(hope_env_t* h, int32_t* pool_index, uint32_t* episode) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h) return fail(HOPE_EINVAL, "hope_env_download_pool_state: null handle");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
@@ -1258,6 +1297,7 @@ int hope_env_download_pool_state(hope_env_t* h, int32_t* pool_index, uint32_t* e
 }
 
 int hope_env_restore_maps(hope_env_t* h, const uint8_t* drawn /* host [N]: the scene held a drawn map */, const uint32_t* episode, uint64_t seed) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || !drawn || !episode) return fail(HOPE_EINVAL, "hope_env_restore_maps: null argument");
     if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_restore_maps: no scene pool");
     DeviceGuard guard(h->device);
@@ -1276,6 +1316,7 @@ int hope_env_restore_maps(hope_env_t* h, const uint8_t* drawn /* host [N]: the s
 }
 
 int hope_env_download_pool_index(hope_env_t* h, int32_t* out) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || !out) return fail(HOPE_EINVAL, "hope_env_download_pool_index: null argument");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
@@ -1285,6 +1326,7 @@ int hope_env_download_pool_index(hope_env_t* h, int32_t* out) {
 }
 
 int hope_env_restart(hope_env_t* h, const uint8_t* mask, void* stream) {
+    if (h) { DeviceGuard g0(h->device); int rcs = join_rs(h, (hipStream_t)stream); if (rcs != HOPE_OK) return rcs; }
     if (!h || !mask) return fail(HOPE_EINVAL, "hope_env_restart: null argument");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_restart: hope_env_set_scenes has not been called");
     DeviceGuard guard(h->device);
@@ -1337,6 +1379,13 @@ int hope_env_step(hope_env_t* h, const void* actions, const uint8_t* active, uin
     return launch_step(h, actions, active, stages, out, stream, 1);
 }
 
+int hope_env_wait_rs(hope_env_t* h, void* stream) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_wait_rs: null handle");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    return join_rs(h, (hipStream_t)stream);
+}
+
 int hope_env_reset_obs(hope_env_t* h, const uint8_t* active, uint32_t stages, const hope_step_out* out, void* stream) {
     return launch_step(h, nullptr, active, stages & ~HOPE_STAGE_MOTION, out, stream, 0);
 }
@@ -1350,6 +1399,7 @@ int hope_debug_math(int fn, int n, const double* a, const double* b, double* out
 }
 
 int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* accum) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h) return fail(HOPE_EINVAL, "hope_env_download_state: null handle");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
@@ -1365,6 +1415,7 @@ int hope_env_download_state(hope_env_t* h, double* pose, int32_t* t, double* acc
 }
 
 int hope_env_upload_state(hope_env_t* h, const double* pose, const int32_t* t, const double* accum) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h) return fail(HOPE_EINVAL, "hope_env_upload_state: null handle");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");

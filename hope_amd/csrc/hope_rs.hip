@@ -993,10 +993,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     //      edge flags[cap]
     float2* fv = (float2*)lds;
     float4* fbox = (float4*)(lds + 4 * p.tile_cap);
-    double* tile64 = lds + 6 * p.tile_cap;
-    float4* obb64 = (float4*)(lds + 14 * p.tile_cap);
-    double* scr = lds + 16 * p.tile_cap;
-    bool have_tile64 = false;
+    double* scr = lds + 6 * p.tile_cap;            // (the float64 re-evaluation reads its few obstacle edges from global memory)
     double* segp = scr + RSB_SEG;
     double* qpd = scr + RSB_QPD;
     int* cand = (int*)(scr + RSB_WORDS);
@@ -1022,10 +1019,21 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     const double step = RS_STEP * MAXC;
     // Obstacle vertices relative to the start position, float32 (subtraction in float64: one rounding, <= 4e-6 m); lane = vertex,
     // so a quad of lanes holds one obstacle: its box and its edges' flags come from quad DPP, no second pass over the tile.
-    for (int base = 0; base < 4 * n_obst; base += WAVE) {
+    for (int base0 = 0; base0 < 4 * n_obst; base0 += 4 * WAVE) {
+        // (four loads in flight per round: a large tile is 8 chunks of 64 vertices, one exposed latency each when taken one by one)
+        double2 qq[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = base0 + u * WAVE + lane;
+            qq[u] = v < 4 * n_obst ? ((const double2*)verts_g)[v] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        const int base = base0 + u * WAVE;
+        if (base >= 4 * n_obst) break;
         const int v = base + lane;
         const bool in = v < 4 * n_obst;
-        const double2 q = in ? ((const double2*)verts_g)[v] : make_double2(0.0, 0.0);
+        const double2 q = qq[u];
         const float fx = (float)(q.x - q0x), fy = (float)(q.y - q0y);
         if (in) fv[v] = make_float2(fx, fy);
         // An edge's coordinate box must not be degenerate: both extents >= FETA_EDGE.  One degenerate case IS robust: an edge that
@@ -1042,6 +1050,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
         if (in && (lane & 3) == 0) {
             fbox[v >> 2] = make_float4(mnx, mxx, mny, mxy);
             eflag[v >> 2] = (unsigned char)((rb >> lane) & 0xF);
+        }
         }
     }
     int found = -1;
@@ -1063,7 +1072,11 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
         bool invalid = false;
         if (lane < RS_SEG_TABLE) segp[lane] = tcur;
         if (TIMING) tsec[9] += 1;
-        if (lane == 0) { qpd[0] = 0.0; qseg[0] = 0; }
+        {   // (a zero made here: as a loop invariant the allocator kept it in SCRATCH and reloaded it for every word)
+            double zero;
+            asm volatile("v_mov_b64 %0, 0" : "=v"(zero));
+            if (lane == 0) { qpd[0] = zero; qseg[0] = (unsigned char)__double2loint(zero); }
+        }
         int nq = 1;
         wsync();
         RS_T(1);
@@ -1272,14 +1285,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 bool bad = hit;
                 const bool any_hit = __any(hit);
                 const bool need64 = (STATS && paranoid) || (!any_hit && __any(unc));
-                if (need64 && !have_tile64) {                    // the float64 tile and its world boxes, once per search
-                    const double2* src = (const double2*)verts_g;
-                    double2* dst = (double2*)tile64;
-                    for (int v = lane; v < 4 * n_obst; v += WAVE) dst[v] = src[v];
-                    for (int o = lane; o < n_obst; o += WAVE) obb64[o] = obb_g[o];
-                    have_tile64 = true;
-                    wsync();
-                }
+                (void)need64;
                 if (STATS) {
                     st_pass += 1;
                     if (any_hit) st_hit += 1;
@@ -1292,7 +1298,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                     }
                 }
                 if (STATS && paranoid) {                         // float64 for every sample; compare with the float32 verdicts
-                    const bool ex = exact_pass<true>(active ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, tile64, obb64, cand, n_obst, xmin, xmax, ymin, ymax, lane);
+                    const bool ex = exact_pass<true>(active ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, verts_g, obb_g, cand, n_obst, xmin, xmax, ymin, ymax, lane);
                     st_samples += __popcll(__ballot(active));
                     st_bad_hit += __popcll(__ballot(active && hit && !ex));
                     if (active && ((hit && !ex) || (!any_hit && !hit && !unc && ex))) {
@@ -1314,9 +1320,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                     bad = ex;
                 } else if (!any_hit && __any(unc)) {
                     if (STATS) { st_exact += 1; st_unc += __popcll(__ballot(unc)); }
-                    bad = exact_edges(unc, sidx, ua, ub, segp, qpd, qseg, tile64, c_q, s_q, q0x, q0y, q0w, xmin, xmax, ymin, ymax);
+                    bad = exact_edges(unc, sidx, ua, ub, segp, qpd, qseg, verts_g, c_q, s_q, q0x, q0y, q0w, xmin, xmax, ymin, ymax);
                     if (__any(uover))                            // (a sample with open edges on more than two obstacles: rare)
-                        bad = exact_pass<false>(uover ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, tile64, obb64, cand, n_obst, xmin, xmax, ymin, ymax, lane) || bad;
+                        bad = exact_pass<false>(uover ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, verts_g, obb_g, cand, n_obst, xmin, xmax, ymin, ymax, lane) || bad;
                 }
                 if (TIMING) t0_ = __builtin_readcyclecounter();
                 if (__any(bad)) {
@@ -1377,9 +1383,9 @@ static size_t rs_lds_bytes_exact(int max_obst) {
     return (size_t)(10 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP;
 }
 static size_t rs_lds_bytes_filter(int max_obst) {
-    return (size_t)(16 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP + (size_t)((max_obst + 3) & ~3);
+    return (size_t)(6 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP + (size_t)((max_obst + 3) & ~3);
 }
-size_t rs_lds_bytes(int max_obst) { return rs_lds_bytes_filter(max_obst); }    // the larger of the two
+size_t rs_lds_bytes(int max_obst) { return std::max(rs_lds_bytes_exact(max_obst), rs_lds_bytes_filter(max_obst)); }
 size_t rs_rec_bytes_per_scene() { return sizeof(double) * RS_REC_DOUBLES; }
 
 hipError_t rs_prof_read(unsigned long long* out, int reset) {
@@ -1447,7 +1453,16 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     const int occ = getenv("HOPE_RS_OCC") ? atoi(getenv("HOPE_RS_OCC")) : 0;   // exact kernel: 3 (168 VGPRs, default) or 4 (128, spills); filter: 4 (default), 5, 6
     const int dbg = getenv("HOPE_RS_DEBUG") ? (int)strtol(getenv("HOPE_RS_DEBUG"), nullptr, 0) : 0;   // profiling / self-check switches
     const bool stats = (dbg & 0x6000) != 0;                              // float32-filter statistics / self-check build
-    const size_t lds = exact ? rs_lds_bytes_exact(p.tile_cap) : rs_lds_bytes_filter(p.tile_cap);
+    size_t lds = exact ? rs_lds_bytes_exact(p.tile_cap) : rs_lds_bytes_filter(p.tile_cap);
+    if (!exact) {
+        // Waves of this kernel per CU, enforced through the LDS request (HOPE_RS_WPC1 / HOPE_RS_WPC0: large- / small-tile launch).
+        // The large-tile launch shares the GPU with the observation half of k_env_step: measured at 65 536 scenes, steady state,
+        // 0.692 ms per step with 4 .. 8 waves per CU, 0.705 with 10, 0.73 with the 13 its 9.5 KB of LDS would allow -- the step
+        // kernel's waves are the better use of the wave slots.  The small-tile launch must not be limited (8 per CU: 0.92 ms).
+        const char* w = getenv(p.tile_cap > 32 ? "HOPE_RS_WPC1" : "HOPE_RS_WPC0");
+        const int wpc = w ? atoi(w) : (p.tile_cap > 32 ? 8 : 0);
+        if (wpc > 0) lds = std::max(lds, (size_t)((158 * 1024 / wpc) & ~255));
+    }
     const void* vk = exact ? (timing ? (const void*)k_rs_validate<3, true> : occ != 4 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>)
                            : (timing ? (const void*)k_rs_validate_f<RSF_OCC, true, false> : stats ? (const void*)k_rs_validate_f<RSF_OCC, false, true>
                               : occ == 5 ? (const void*)k_rs_validate_f<5, false, false>

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 5
+#define HOPE_ABI_VERSION 6
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -118,6 +118,16 @@ extern "C" {
  * so far) -- is copied into the scene inside the step kernel.  Equivalent to hope_env_step + hope_env_redraw(done, seed) +
  * hope_env_reset_obs(active = done) without the extra launches.  HOPE_ESTATE without a pool. */
 #define HOPE_AUTO_REDRAW 0x100
+/* modifier bit: TWO completion points per step.  Without it `stream` is ordered after every output of the step when
+ * hope_env_step returns.  With it `stream` is ordered after the observation half only -- lidar / action_mask / target / img,
+ * reward / reward_info / status / done / pose -- so that the caller's policy forward (which reads the observation,
+ * parking_agent.py:78-99) runs while the Reeds-Shepp kernels of the step finish on the library's own streams; rs_word /
+ * rs_lengths are ordered by hope_env_wait_rs(h, stream) (the planner override just before the next step), or by the next
+ * hope_env_step itself: its launches follow the unfinished ones on the same library streams, so consecutive steps
+ * pipeline.  The outputs are the same bits either way.  The bit takes effect in the two-launch form of the step (handles
+ * with HOPE_F_OVERLAP from 16 384 scenes on, without HOPE_F_GRAPH); elsewhere the step is joined as without it and
+ * hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself. */
+#define HOPE_DEFER_RS 0x200
 
 typedef struct hope_env hope_env_t;
 
@@ -168,6 +178,10 @@ int hope_env_set_scenes(hope_env_t *h, const int32_t *scene_ids, int n, const do
  * active  = optional DEVICE u8 [N]; scenes with active[i]==0 are left untouched (outputs too). */
 int hope_env_step(hope_env_t *h, const void *actions, const uint8_t *active, uint32_t stages,
                   const hope_step_out *out, void *stream);
+
+/* Orders `stream` after the Reeds-Shepp outputs of the last hope_env_step that carried HOPE_DEFER_RS (no-op if none is
+ * outstanding). */
+int hope_env_wait_rs(hope_env_t *h, void *stream);
 
 /* The action-less step of CarParking.reset (:138) / CarParkingWrapper.step(None) (:74-75):
  * t += 1, observation, status, reward; no motion. */

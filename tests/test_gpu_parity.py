@@ -95,7 +95,7 @@ def rollout(env, orc, rng, steps, tol, with_rs=False, stages=None):
 def test_library_is_native():
     from hope_amd import load_library
     L = load_library()
-    assert L.hope_abi_version() == 5
+    assert L.hope_abi_version() == 6
 
 
 def test_step_parity_f64_dlp():
@@ -469,6 +469,61 @@ def _overlap_modes_body(ParkingBatch, SceneSource):
     assert len({int(x) for x in envs[0].status.unique().tolist()}) >= 2
     for e in envs:
         e.close()
+
+
+def test_deferred_rs_join_equals_the_joined_step():
+    """HOPE_DEFER_RS (two completion points per step: the caller's stream is ordered after the observation half, the
+    Reeds-Shepp outputs by hope_env_wait_rs or by the next step on the library's streams) must produce the same bits as the
+    joined step: every output, every step, with auto-reset on new maps; entry points that read the state while the search of
+    the last step is still unjoined (download_state, restart) join by themselves."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scene_gen import mixed_arrays, generate_arrays
+    os.environ['HOPE_SPLIT_MIN'] = '1'
+    try:
+        n = 6144
+        arrs = mixed_arrays(n, seed=77, max_obst=128)
+        parts = [generate_arrays(lv, 256, seed=78 + j, max_obst=128) for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
+        pool = tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(6))
+        envs = [ParkingBatch(n, 128, overlap=True) for _ in range(2)]
+        for e in envs:
+            e.set_scene_arrays(np.arange(n), *arrs[:5])
+            e.set_draw_class(np.arange(3, n, 4), 1)          # the Dragon-Lake slots (scene k has level k % 4) keep drawing cases
+            e.set_pool(pool)
+            e.set_dlp_cases()
+            e.set_redraw_seed(5)
+            e.reset_obs()
+        g = torch.Generator(device='cuda').manual_seed(11)
+        names = ('lidar', 'action_mask', 'target', 'reward', 'reward_info', 'status', 'done', 'pose', 'rs_word', 'rs_lengths')
+        side = torch.cuda.Stream()
+        found = 0
+        for it in range(24):
+            a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+            envs[0].step(a, auto_reset=True, fresh=True)
+            envs[1].step(a, auto_reset=True, fresh=True, defer_rs=True)
+            if it % 3 == 0:                                   # the observation half is ordered on the current stream already
+                torch.cuda.current_stream().synchronize()
+                for k in names[:8]:
+                    assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), (it, k)
+            if it % 4 == 1:                                   # a state download joins by itself
+                p0, t0, _ = envs[0].download_state()
+                p1, t1, _ = envs[1].download_state()
+                assert np.array_equal(p0, p1) and np.array_equal(t0, t1)
+            if it % 2 == 0:
+                envs[1].wait_rs()
+                torch.cuda.current_stream().synchronize()
+                for k in names:
+                    assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), (it, k)
+                found += int((envs[1].rs_word[:, 6] > 0).sum())
+        envs[1].wait_rs()
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), k
+        assert found > 0
+        for e in envs:
+            e.close()
+    finally:
+        del os.environ['HOPE_SPLIT_MIN']
 
 
 def test_config3_exact_size_16384_scenes():

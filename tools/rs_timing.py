@@ -49,12 +49,17 @@ def main():
     waves = max(v[8], 1)
     names = ['prologue', 'word setup', 'sample generator', 'interpolate + transform', 'pose_hits: hull / union / cull',
              'pose_hits: candidate loop']
+    extra = {7: 'decision (float64 re-evaluation)', 14: 'bad-sample bookkeeping', 15: 'carry'}
     tot = v[6]
     print(f'searches (waves with work) per step: {waves / args.steps:.0f};  cycles per search: {tot / waves:.0f}')
     acc = 0
     for i, nm in enumerate(names):
         print(f'  {nm:34s} {v[i] / waves:9.0f} cycles/search  {100 * v[i] / tot:5.1f} %')
         acc += v[i]
+    for i, nm in extra.items():
+        if v[i]:
+            print(f'  {nm:34s} {v[i] / waves:9.0f} cycles/search  {100 * v[i] / tot:5.1f} %')
+            acc += v[i]
     print(f'  {"rest (bookkeeping, carry, output)":34s} {(tot - acc) / waves:9.0f} cycles/search  {100 * (tot - acc) / tot:5.1f} %')
     print(f'  words tested / search {v[9] / waves:.2f}; generator rounds {v[10] / waves:.2f}; passes {v[11] / waves:.2f}; '
           f'passes with candidates {v[12] / waves:.2f}; candidate obstacles per such pass {v[13] / max(v[12], 1):.2f}')
