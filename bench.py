@@ -202,11 +202,12 @@ def main():
             refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5)
         if args.algo == 'ppo':
             agent = A.BatchedPPO(device=dev, use_img=args.image, mini_batch=args.mini_batch, mini_epoch=args.mini_epoch)
-            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=fresh, pool_refresher=refresher)
+            trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=fresh, pool_refresher=refresher,
+                                 defer_rs=defer)
         else:
             agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
             trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac',
-                                 fresh_scenes=fresh, pool_refresher=refresher)
+                                 fresh_scenes=fresh, pool_refresher=refresher, defer_rs=defer)
         one_step = lambda i: trainer.step()  # noqa: E731
 
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY
@@ -379,7 +380,7 @@ def main():
                        'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
                        'rs_join': ('deferred: the caller\'s stream is ordered after each step\'s observation / reward / status outputs, its '
                                    'Reeds-Shepp outputs by the next step on the library\'s streams (HOPE_DEFER_RS); all work of the K steps '
-                                   'is complete at the closing synchronize') if (defer and trainer is None) else 'joined',
+                                   'is complete at the closing synchronize') if defer else 'joined',
                        'episode_turnover': (f'new map per episode, drawn inside the step kernel (HOPE_AUTO_REDRAW): generated lots from a device-resident pool of '
                                             f'{args.pool} scenes, Dragon-Lake cases drawn on the device (start candidate, jitter, flips, cull per episode)'
                                             if fresh else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),

@@ -77,11 +77,13 @@ class _AgentCommon:
         return torch.clamp(self.actor(nobs), -1, 1)                              # ppo_agent.py:137
 
     @torch.no_grad()
-    def act(self, obs, use_mask=True, generator=None, planned=None, executing=None):
+    def act(self, obs, use_mask=True, generator=None, planned=None, executing=None, plan_fn=None):
         """choose_action (mask-weighted discrete sampling, ppo_agent.py:163-169 + action_mask.py:199-227) or
         get_action (plain Gaussian sample, :171-185), clamped to [-1, 1]; scenes flagged in `executing` take the
         planner's action instead (ParkingAgent.choose_action, parking_agent.py:80-99).  Returns (action [N,2] float32,
-        log_prob [N,2] under the current policy, normalised obs dict that was fed to the actor)."""
+        log_prob [N,2] under the current policy, normalised obs dict that was fed to the actor).
+        plan_fn: called AFTER the policy forward and the sampling, returns (planned, executing) -- the forward needs the
+        observation only, so it is enqueued before the caller waits for the Reeds-Shepp outputs of the env step."""
         nobs = self._norm_obs(obs)
         mean = self.policy_mean(nobs)
         log_std = self.log_std.expand_as(mean)
@@ -91,6 +93,8 @@ class _AgentCommon:
         else:
             a = mean + log_std.exp() * torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
         a = torch.clamp(a, -1, 1)
+        if plan_fn is not None:
+            planned, executing = plan_fn()
         if planned is not None:
             a = torch.where(executing.unsqueeze(1), planned.to(a.dtype), a)
         return a, P.gaussian_log_prob(mean, log_std, a), nobs

@@ -134,14 +134,20 @@ class TransitionRing:
 
 
 class HopeRollout:
-    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True, fresh_scenes=False, pool_refresher=None):
-        """fresh_scenes: finished episodes continue on a NEW map drawn from the env's device-resident scene pool
+    def __init__(self, env, agent, horizon, use_mask=True, seed=0, use_planner=True, fresh_scenes=False, pool_refresher=None,
+                 defer_rs=True):
+        """defer_rs: step the env with two completion points (HOPE_DEFER_RS): the next policy forward is enqueued as soon as the
+        observation is written, the planner reads rs_word / rs_lengths (after ParkingBatch.wait_rs) just before its override --
+        the same actions as with the joined step, the forward overlaps the Reeds-Shepp kernels.
+        fresh_scenes: finished episodes continue on a NEW map drawn from the env's device-resident scene pool
         (ParkingBatch.set_pool / set_dlp_cases), as the reference's loop does with `env.reset(...)`; otherwise on the same map.
         pool_refresher: a `scene_gen.PoolRefresher`; the trainers poll it after every update, so the pool of generated lots is
         replaced by new ones in the background (asynchronous upload, no synchronisation with the step loop)."""
         self.env, self.agent, self.use_mask, self.fresh = env, agent, use_mask, fresh_scenes
         self.refresher = pool_refresher
         self.seed = seed
+        self.defer_rs = bool(defer_rs) and hasattr(env, 'wait_rs')
+        self._plan_pending = False                    # the planner has not yet seen the last step's done / RS outputs
         dev = env.device
         self.ring = TransitionRing(env.n, horizon, agent.keys, dev)
         self.planner = G.BatchedRsPlanner(env.n, device=dev) if use_planner else None
@@ -163,11 +169,29 @@ class HopeRollout:
             o['img'] = e.img
         return o
 
+    def _plan(self):
+        """the planner's part of ParkingAgent.choose_action: bookkeeping of the last step (its done flags and RS paths), then
+        the actions of the scenes that are replaying a path"""
+        if self.planner is None:
+            return None, None
+        if self._plan_pending:
+            env = self.env
+            if self.defer_rs:
+                env.wait_rs()
+            self.planner.reset(env.done.bool())                     # ParkingAgent.reset at episode end
+            self.planner.set_paths(env.rs_word, env.rs_lengths)     # info['path_to_dest'] -> set_planner_path
+            self._plan_pending = False
+        return self.planner.get_actions()
+
     @torch.no_grad()
     def collect_step(self, random_action=False):
         env, agent = self.env, self.agent
-        planned, executing = self.planner.get_actions() if self.planner is not None else (None, None)
-        action, log_prob, nobs = agent.act(self._raw_obs(), self.use_mask, self.gen, planned, executing)
+        executing = None
+        if random_action:
+            planned, executing = self._plan()
+            action, log_prob, nobs = agent.act(self._raw_obs(), self.use_mask, self.gen, planned, executing)
+        else:
+            action, log_prob, nobs = agent.act(self._raw_obs(), self.use_mask, self.gen, plan_fn=self._plan)
         if random_action:                             # train_HOPE_sac.py:196-198: uniform exploration while the memory fills
             rnd = torch.rand(action.shape, device=action.device, generator=self.gen) * 2 - 1
             action = rnd if executing is None else torch.where(executing.unsqueeze(1), action, rnd)
@@ -175,19 +199,18 @@ class HopeRollout:
             from .policy import gaussian_log_prob
             log_prob = gaussian_log_prob(mean, agent.log_std.expand_as(mean), action)
         self.ring.write_before(nobs, action, log_prob)              # copies: env.step overwrites the buffers in place
+        kw = {'defer_rs': True} if self.defer_rs else {}
         if self.fresh:                                # new map per episode, drawn inside the step kernel (HOPE_AUTO_REDRAW)
-            env.step(action.to(env.action_dtype).contiguous(), auto_reset=True, fresh=True)
+            env.step(action.to(env.action_dtype).contiguous(), auto_reset=True, fresh=True, **kw)
         else:
-            env.step(action.to(env.action_dtype).contiguous(), auto_reset=True)
+            env.step(action.to(env.action_dtype).contiguous(), auto_reset=True, **kw)
         self.ring.write_after(env.reward, env.done)
         agent.observe(self._raw_obs())                              # push_memory: state_norm(next_obs, update=True)
         done = env.done.bool()
         self.episodes += done.sum()
         self.successes += (env.status == 2).sum()
         self.reward_sum += env.reward.sum(dtype=torch.float64)
-        if self.planner is not None:
-            self.planner.reset(done)                                # ParkingAgent.reset at episode end
-            self.planner.set_paths(env.rs_word, env.rs_lengths)     # info['path_to_dest'] -> set_planner_path
+        self._plan_pending = self.planner is not None               # (its bookkeeping runs in _plan, before the next override)
         self.steps += 1
 
     def last_obs(self):
@@ -204,9 +227,9 @@ class PPOTrainer(HopeRollout):
     """train_HOPE_ppo.py:177-213: act -> step -> push; when the buffer is full (`horizon` steps of all scenes,
     the batched `len(memory) % batch_size == 0`) run PPO.update and clear."""
 
-    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True, fresh_scenes=False, pool_refresher=None):
+    def __init__(self, env, agent, horizon=16, seed=0, use_planner=True, fresh_scenes=False, pool_refresher=None, defer_rs=True):
         super().__init__(env, agent, horizon, use_mask=True, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes,
-                         pool_refresher=pool_refresher)
+                         pool_refresher=pool_refresher, defer_rs=defer_rs)
         self.updates = 0
 
     def step(self):
@@ -227,9 +250,9 @@ class SACTrainer(HopeRollout):
     sample, no action mask), one SAC update every `update_every` env steps on a uniform batch from the ring."""
 
     def __init__(self, env, agent, horizon=8, update_every=10, seed=0, use_planner=True, learn=True, fresh_scenes=False,
-                 pool_refresher=None):
+                 pool_refresher=None, defer_rs=True):
         super().__init__(env, agent, horizon, use_mask=False, seed=seed, use_planner=use_planner, fresh_scenes=fresh_scenes,
-                         pool_refresher=pool_refresher)
+                         pool_refresher=pool_refresher, defer_rs=defer_rs)
         self.update_every, self.learn, self.updates = update_every, learn, 0
 
     def step(self):

@@ -230,3 +230,35 @@ def test_rccl_gradient_allreduce_and_eval_gather_two_gpus():
     assert res[0][2] == res[1][2] == 1 and res[0][3] > 0
     assert np.array_equal(res[0][1], res[1][1])
     assert res[0][4] == res[1][4] == (4096, 4) and res[0][5] == res[1][5]
+
+
+def test_rollout_with_deferred_rs_join_takes_the_same_actions():
+    """with two completion points per step (HOPE_DEFER_RS) the policy forward is enqueued before the
+    Reeds-Shepp outputs are joined and the planner override reads them after ParkingBatch.wait_rs: the actions, log-probs,
+    rewards and done flags of the rollout must be bit-identical to the joined form, planner replays included."""
+    from hope_amd import agents as A
+    from hope_amd.rollout import HopeRollout
+    os.environ['HOPE_SPLIT_MIN'] = '1'                 # the two-launch form of the step (the bit only acts there) at this size
+    try:
+        runs = []
+        for defer in (False, True):
+            env, _ = make_env(4096, seed=21)
+            torch.manual_seed(3)
+            agent = A.BatchedSAC(device='cuda', batch_size=1024)
+            ro = HopeRollout(env, agent, horizon=16, use_mask=False, seed=4, defer_rs=defer)
+            assert ro.defer_rs == defer
+            for _ in range(16):
+                ro.collect_step()
+            torch.cuda.synchronize()
+            obs, action, reward, done, log_prob = ro.ring.ordered()
+            runs.append((action.clone(), reward.clone(), done.clone(), log_prob.clone(), ro.planner.executing.clone(),
+                         {k: v.clone() for k, v in obs.items()}))
+            env.close()
+        a, b = runs
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y)
+        for k in a[5]:
+            assert torch.equal(a[5][k], b[5][k]), k
+        assert bool(a[4].any())                        # some scenes were replaying a Reeds-Shepp path
+    finally:
+        del os.environ['HOPE_SPLIT_MIN']
