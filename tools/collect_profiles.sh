@@ -51,5 +51,17 @@ py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
   echo "== 2 ranks sharing the GPU (gloo): strong scaling 16384 scenes total, PPO with gradient all-reduce"
   HOPE_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 $R/bench.py --gpus 2 --scaling strong --scenes 16384 --policy hope --algo ppo --steps 16 --warmup 8 2>/dev/null | tail -1
 } > $O/${TAG}_bench_modes.txt
+# the caller's stream joined with every output before the next step is enqueued (the default defers the Reeds-Shepp join)
+py $R/bench.py --rs-join joined --no-cpu-baseline | tail -1 > $O/${TAG}_bench_joined.json
+# timeline of one step (joined form: consecutive steps do not overlap, so one step can be cut out of the trace)
+rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/bench.py --rs-join joined --steps 8 --warmup 8 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+{ python $R/tools/timeline.py $O/tl 3; python $R/tools/timeline.py $O/tl 2; } > $O/${TAG}_step_timeline.txt 2>&1
+rm -rf $O/tl
+# cycle accounting (instrumented builds), float32-filter statistics + self-check, randomised equality soak
+HOPE_STEP_TIMING=1 python $R/tools/step_timing.py > $O/${TAG}_env_step_cycles.txt 2>/dev/null
+HOPE_RS_TIMING=1 python $R/tools/rs_timing.py > $O/${TAG}_rs_validate_cycles.txt 2>/dev/null
+python $R/tools/rs_filter_stats.py --check > $O/${TAG}_rs_filter_stats.txt 2>/dev/null
+python $R/tools/rs_bench.py > $O/${TAG}_rs_bench.txt 2>/dev/null
+python $R/tools/soak.py --seeds 10 --scenes 4096 --steps 12 > $O/${TAG}_soak.txt 2>/dev/null
 rm -rf $O/kstats $O/kstats_img $O/pmc_* $O/pmc*_FETCH_SIZE $O/pmc*_WRITE_SIZE $O/busy*
 ls -la $O
