@@ -124,9 +124,9 @@ extern "C" {
  * parking_agent.py:78-99) runs while the Reeds-Shepp kernels of the step finish on the library's own streams; rs_word /
  * rs_lengths are ordered by hope_env_wait_rs(h, stream) (the planner override just before the next step), or by the next
  * hope_env_step itself: its launches follow the unfinished ones on the same library streams, so consecutive steps
- * pipeline.  The outputs are the same bits either way.  The bit takes effect in the two-launch form of the step (handles
- * with HOPE_F_OVERLAP from 16 384 scenes on, without HOPE_F_GRAPH); elsewhere the step is joined as without it and
- * hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself. */
+ * pipeline.  The outputs are the same bits either way.  The bit takes effect in the two-launch form of the step and from
+ * 32 768 scenes on (handles with HOPE_F_OVERLAP, without HOPE_F_GRAPH; below that size the joined form is the faster one);
+ * elsewhere the step is joined as without it and hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself. */
 #define HOPE_DEFER_RS 0x200
 
 typedef struct hope_env hope_env_t;
