@@ -59,6 +59,9 @@ def parse():
     ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
     ap.add_argument('--unique', type=int, default=2048, help='distinct generated scenes (tiled to --scenes)')
     ap.add_argument('--image', action='store_true', help="also render obs['img'] (USE_IMG, configs.py:100) every step")
+    ap.add_argument('--policy-amp', action='store_true',
+                    help='--policy hope --image: run the image encoders under bf16 autocast + channels_last (stock PyTorch levers; '
+                         'changes the policy\'s numerics, reported next to the fp32 default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scenes', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=12)
@@ -208,6 +211,11 @@ def main():
             agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
             trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac',
                                  fresh_scenes=fresh, pool_refresher=refresher, defer_rs=defer)
+        if args.policy_amp:
+            from hope_amd.policy import set_img_amp
+            for net in (getattr(agent, 'actor', None), getattr(agent, 'critic', None), getattr(agent, 'critic_target', None)):
+                if net is not None:
+                    set_img_amp(net, True)
         one_step = lambda i: trainer.step()  # noqa: E731
 
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY

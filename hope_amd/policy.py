@@ -159,9 +159,24 @@ class _ImgEncoder(nn.Module):
         self.net = nn.Sequential(*mods)
         self.output_mean = nn.Linear(n, embed)
         self.output_std = nn.Linear(n, embed)           # in the checkpoints; unused by the policy (network.py:180)
+        self.amp = False                                # set_img_amp(): bf16 autocast + channels_last for the conv stack
 
     def forward(self, x):
+        if self.amp and x.is_cuda:                      # stock PyTorch levers only (inference-side report, not the default)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = self.net(x.contiguous(memory_format=torch.channels_last))
+            return self.output_mean(y.float())
         return self.output_mean(self.net(x))
+
+
+def set_img_amp(module, on=True):
+    """bf16 autocast + channels_last for every image encoder under `module` (the reference runs them in fp32; this changes the
+    numerics of the policy, not of the env: off by default, `bench.py --policy-amp` reports it)"""
+    for m in module.modules():
+        if isinstance(m, _ImgEncoder):
+            m.amp = bool(on)
+            if on:
+                m.net.to(memory_format=torch.channels_last)
 
 
 class HopeNet(nn.Module):
