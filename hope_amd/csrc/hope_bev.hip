@@ -615,6 +615,23 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             }
         }
 
+        // ---- a tile without moving boxes (12 of the 16) does not use its LDS window: the layer blocks its world window covers
+        // (32 x 16 px = 128 B each, at most 4 x 7 of them) are copied there with 16-byte loads and the gather reads LDS
+        // instead of issuing 16 single-byte global loads per lane
+        const int cbx0 = w.x0 >> 5, cby0 = w.y0 >> 4;
+        const int ncx = (w.x1 >> 5) - cbx0 + 1, ncy = (w.y1 >> 4) - cby0 + 1;
+        const bool cached = !has_dyn && w.x0 <= w.x1 && w.y0 <= w.y1 && ncx <= 4 && ncx * ncy * 128 <= FB_BYTES && !(p.debug & 16);
+        if (cached) {
+            wave_phase();                                                    // the previous tile's gather is done
+            const int l = lane & 31;
+            if (l < 8 * ncx) {
+                const int bx = l >> 3, piece = l & 7;
+                for (int r = lane >> 5; r < ncy; r += 2)
+                    *(uint4*)(fb + ((r * ncx + bx) << 7) + (piece << 4)) =
+                        *(const uint4*)(layer + ((((cby0 + r) << 4) + cbx0 + bx) << 7) + (piece << 4));
+            }
+            wave_phase();
+        }
         // ---- gather: lane = 4 consecutive outputs of one tile row; cv2.resize reads crop pixels (4u+1|2, 4v+1|2) -----
         if (p.debug & 8) continue;
         const int v = TILE_OUT * ty + (lane >> 2);
@@ -626,6 +643,12 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         map_raw(m, 4 * u0 + 1, 4 * v + 1, dxb, dyb);                          // first sample of this lane
         const bool row_out0 = (unsigned)(4 * v + 1 + m.roy) >= (unsigned)WIN, row_out1 = (unsigned)(4 * v + 2 + m.roy) >= (unsigned)WIN;
         uint32_t ids[4] = {0, 0, 0, 0};                                       // 4 palette ids per output, one byte each
+        auto gather = [&](auto cached_tag) {
+        constexpr bool CACHED = decltype(cached_tag)::value;
+        auto static_byte = [&](int px, int py) -> int {
+            if (CACHED) return fb[((((py >> 4) - cby0) * ncx + ((px >> 5) - cbx0)) << 7) + ((py & 15) << 3) + ((px & 31) >> 2)];
+            return layer[layer_byte(px, py)];
+        };
         const int dxx4 = m.dxx << 2, dyx4 = m.dyx << 2;
         // the usual tile lies completely inside `rotate` and inside the source: no border tests, no clamps
         const int rxa = 4 * TILE_OUT * tx + 1 + m.rox, rxb = rxa + 4 * TILE_OUT - 3, rya = 4 * TILE_OUT * ty + 1 + m.roy, ryb = rya + 4 * TILE_OUT - 3;
@@ -637,7 +660,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                 for (int s = 0; s < 4; s++) {
                     const int dx = dxb + ((s & 1) ? m.dxx : 0) + ((s >> 1) ? m.dxy : 0), dy = dyb + ((s & 1) ? m.dyx : 0) + ((s >> 1) ? m.dyy : 0);
                     const int wx = dx >> 16, wy = dy >> 16;
-                    int id = (layer[layer_byte(wx, wy)] >> ((wx & 3) * 2)) & 3;
+                    int id = (static_byte(wx, wy) >> ((wx & 3) * 2)) & 3;
                     if (p.debug & 2) id = 0;
                     if (has_dyn) { const int did = fb[__mul24(wy - w.y0, FB_STRIDE) + wx - w.x0]; id = did ? did : id; }
                     ids[jj] |= (uint32_t)id << (8 * s);
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                     const bool outside = (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
                     const int sx = min(max(dx >> 16, w.x0), wx1), sy = min(max(dy >> 16, w.y0), wy1);
                     const int lx = min(sx, WIN - 1), ly = min(sy, WIN - 1);  // (an empty window lies beyond the surface: the read is discarded, keep it in bounds)
-                    int id = (layer[layer_byte(lx, ly)] >> ((lx & 3) * 2)) & 3;
+                    int id = (static_byte(lx, ly) >> ((lx & 3) * 2)) & 3;
                     if (p.debug & 2) id = 0;
                     if (has_dyn) { const int did = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0]; id = did ? did : id; }
                     id = outside ? bg_id : id;                                // rotate()'s bgcolor
@@ -665,6 +688,8 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                 dxb += dxx4; dyb += dyx4;
             }
         }
+        };
+        if (cached) gather(std::true_type{}); else gather(std::false_type{});
         uint32_t out_r = 0, out_g = 0, out_b = 0;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
