@@ -49,7 +49,7 @@ constexpr int FB_BYTES = FB_DIM * FB_STRIDE;
 constexpr int SL_ROWS = 16, SL_STRIDE = 516;   // 500 pixels + pad: 129 dwords (odd)
 constexpr int SL_BYTES = SL_ROWS * SL_STRIDE;
 constexpr int SL_SLOT = (SL_BYTES + 72 + 15) / 16 * 16;
-constexpr int SL_PARTS = 4;                    // workgroups per rebuilt scene
+constexpr int SL_PARTS = 8;                    // workgroups per rebuilt scene (x 4 waves = the 32 bands of 16 rows: one band per wave)
 constexpr int FB_SLOT = (FB_BYTES + 72 + 15) / 16 * 16;   // window + 64 dummy bytes, 16-byte aligned
 constexpr int BEV_WAVES = 4;                   // waves per workgroup = per scene (they share the span tables)
 constexpr double RENDER_K = 12.0;              // K  configs.py:103
@@ -62,7 +62,25 @@ constexpr int TAB_ROWS = 64;                   // a car box is at most 62 px hig
 constexpr int HDR_INTS = 16;
 constexpr int OFF_MAP = 0, OFF_HDR = 16, OFF_TAB = OFF_HDR + N_BOX * HDR_INTS;
 static_assert(OFF_TAB + N_TAB * TAB_ROWS == BEV_SCENE_INTS, "scratch layout");
-enum { M_DXX, M_DXY, M_DX0, M_DYX, M_DYY, M_DY0, M_ROX, M_ROY, M_VEH_HIDDEN };
+enum { M_DXX, M_DXY, M_DX0, M_DYX, M_DYY, M_DY0, M_ROX, M_ROY, M_VEH_HIDDEN,
+       M_DIRTY_X0, M_DIRTY_X1, M_DIRTY_Y0, M_DIRTY_Y1,   // box around everything painted into the trajectory layer this episode
+       M_DYN_BAD,                                         // a trajectory box of this episode is not a plain one-span-per-row box: per-tile raster instead
+       M_DYN_CODE };                                      // code of the newest trajectory entry
+// ---- trajectory layer (round 3) --------------------------------------------------------------------------------------------
+// A trajectory box keeps its pixels for the 20 steps it is drawn; only its COLOUR changes (TRAJ_COLORS by recency,
+// car_parking_base.py:313-320).  Rasterising all <= 20 boxes into the LDS window of every tile they touch, every step, was the
+// larger half of k_bev_image.  Instead a per-scene layer in HBM holds, per world pixel, the CODE of the newest trajectory entry that
+// covers it: code(e) = e % DYN_MOD + 1 for entry e of vehicle.trajectory (0 = none).  k_bev_prep paints only the entries that are
+// new (in chronological order, unconditionally: a newer box hides an older one, and older boxes leave the drawn set first, so "the
+// newest box covering the pixel" is all the painter's algorithm ever shows); the gather turns a code into the age
+// (code_newest - code) mod DYN_MOD and, if age < min(len, 20), into palette id 24 - age.  Pixels of entries that have left the drawn
+// set are simply older than 20: nothing is ever erased, except that every DYN_REFRESH entries (and at every reset) the painted
+// region is cleared and the <= 20 live boxes are repainted, so that no stale code gets old enough to alias (114 < 192).
+constexpr int DYN_MOD = 192, DYN_REFRESH = 96;
+// box around the <= 20 trajectory boxes that are drawn NOW (the tiles it misses need not look at the layer): spare header words
+constexpr int OFF_LIVE_X = OFF_HDR + 14, OFF_LIVE_Y = OFF_HDR + HDR_INTS + 14;
+__device__ __forceinline__ int dyn_code(int e) { return e % DYN_MOD + 1; }
+__device__ __forceinline__ int dyn_byte(int x, int y) { return ((((y >> 3) << 5) + (x >> 4)) << 7) + ((y & 7) << 4) + (x & 15); }
 enum { H_MINY, H_NROWS, H_FLAGS, H_MINX, H_MAXX, H_MAXY, H_VX, H_VY = H_VX + 4 };
 constexpr int F_SIMPLE = 1;                    // every row has exactly one span and the border pass adds nothing outside
 constexpr uint32_t SPAN_EMPTY = 2u | (1u << 16);   // a0 = 1 > a1 = 0 (stored + 1)
@@ -231,6 +249,42 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
     const int traj_len = p.traj_len[scene];
     const int valid = p.traj_valid[scene];             // trajectory entries [.., valid) already have their spans
     const double* ring = p.traj + (size_t)scene * BEV_TRAJ_LEN * 3;
+    // trajectory layer bookkeeping of the episode so far (zeros on the first use of the scratch)
+    uint8_t* dyn = p.dyn + (size_t)scene * BEV_DYN_BYTES;
+    int dirty_x0 = out[OFF_MAP + M_DIRTY_X0], dirty_x1 = out[OFF_MAP + M_DIRTY_X1];
+    int dirty_y0 = out[OFF_MAP + M_DIRTY_Y0], dirty_y1 = out[OFF_MAP + M_DIRTY_Y1];
+    int dyn_bad = out[OFF_MAP + M_DYN_BAD];
+    // a reset (new episode), or a multiple of DYN_REFRESH among the new entries: clear what was painted, repaint the live boxes
+    const bool dyn_reset = valid == 0;
+    const bool dyn_refresh = dyn_reset || (traj_len - 1) / DYN_REFRESH != (valid - 1) / DYN_REFRESH;
+    if (dyn_refresh) {
+        if (dirty_x0 <= dirty_x1 && dirty_y0 <= dirty_y1) {
+            const int bx0 = dirty_x0 >> 4, nbx = (dirty_x1 >> 4) - bx0 + 1, by0 = dirty_y0 >> 3, nby = (dirty_y1 >> 3) - by0 + 1;
+            for (int i = lane; i < nbx * nby * 8; i += WAVE) {
+                const int blk = i >> 3, byi = blk / nbx, bxi = blk - byi * nbx;
+                *(uint4*)(dyn + ((((by0 + byi) << 5) + bx0 + bxi) << 7) + ((i & 7) << 4)) = make_uint4(0, 0, 0, 0);
+            }
+        }
+        dirty_x0 = 1; dirty_x1 = 0; dirty_y0 = 1; dirty_y1 = 0;
+        if (dyn_reset) dyn_bad = 0;
+    }
+    // box with the clamped spans `sp` (lane = row) painted with `code`
+    auto dyn_paint = [&](uint32_t sp, int miny, int nrows, int minx, int maxx, int code) {
+        const int y = miny + lane;
+        const int a = max((int)(sp & 0xffff) - 1, 0), b = min((int)(sp >> 16) - 1, WIN - 1);
+        if (lane < nrows && y >= 0 && y < WIN) {
+            uint8_t* row = dyn + (((y >> 3) << 5) << 7) + ((y & 7) << 4);
+            for (int x = a; x <= b;) {
+                if ((x & 3) == 0 && x + 3 <= b) { *(uint32_t*)(row + ((x >> 4) << 7) + (x & 15)) = 0x01010101u * (uint32_t)code; x += 4; }
+                else { row[((x >> 4) << 7) + (x & 15)] = (uint8_t)code; x += 1; }
+            }
+        }
+        const int cx0 = max(minx, 0), cx1 = min(maxx, WIN - 1), cy0 = max(miny, 0), cy1 = min(miny + nrows - 1, WIN - 1);
+        if (cx0 <= cx1 && cy0 <= cy1) {
+            if (dirty_x0 > dirty_x1) { dirty_x0 = cx0; dirty_x1 = cx1; dirty_y0 = cy0; dirty_y1 = cy1; }
+            else { dirty_x0 = min(dirty_x0, cx0); dirty_x1 = max(dirty_x1, cx1); dirty_y0 = min(dirty_y0, cy0); dirty_y1 = max(dirty_y1, cy1); }
+        }
+    };
 
     // the vehicle box is exactly the newest trajectory box whenever that entry is the current pose (always, unless the
     // pose was set from outside): it is then completely overdrawn and needs neither spans nor drawing
@@ -323,10 +377,8 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
             for (int k = 0; k < 4; k++) { vx[k] = to_px(bb.x[k], bb.y[k], RENDER_K, 0.0, offx); vy[k] = to_px(bb.x[k], bb.y[k], 0.0, RENDER_K, offy); }
         }
     }
-    unsigned long long mask = __ballot(need);
-    while (mask) {
-        const int l = __builtin_ctzll(mask);
-        mask &= mask - 1;
+    // spans and header of box `l` (wave-uniform); returns this lane's clamped span and the box's shape through the references
+    auto do_box = [&](int l, uint32_t& sp_out, int& o_miny, int& o_nrows, int& o_minx, int& o_maxx, bool& o_simple) {
         int qx[5], qy[5];
 #pragma unroll
         for (int k = 0; k < 4; k++) { qx[k] = __builtin_amdgcn_readlane(vx[k], l); qy[k] = __builtin_amdgcn_readlane(vy[k], l); }
@@ -353,11 +405,52 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
 #pragma unroll
         for (int k = 0; k < 4; k++) { hv = lane == H_VX + k ? qx[k] : hv; hv = lane == H_VY + k ? qy[k] : hv; }
         if (lane < HDR_INTS) hdr[lane] = hv;
+        uint32_t sp = SPAN_EMPTY;
         if (l >= 1) {                                                        // spans clamped to the surface (+1: unsigned)
-            uint32_t sp = SPAN_EMPTY;
             if (y <= maxy && c.cnt >= 2) sp = (uint32_t)(min(max(c.a0, -1), WIN) + 1) | ((uint32_t)(min(max(c.a1, -1), WIN) + 1) << 16);
             out[OFF_TAB + (l - 1) * TAB_ROWS + lane] = (int)sp;
         }
+        sp_out = sp; o_miny = miny; o_nrows = min(nrows, TAB_ROWS); o_minx = minx; o_maxx = maxx; o_simple = simple;
+    };
+    const unsigned long long needm = __ballot(need);
+    for (unsigned long long mask = needm & 7ull; mask; mask &= mask - 1) {   // start, dest, vehicle
+        uint32_t sp; int a_, b_, c_, d_; bool e_;
+        do_box(__builtin_ctzll(mask), sp, a_, b_, c_, d_, e_);
+    }
+    // trajectory entries, oldest first: the live ones that already have their tables when the layer was cleared, then the new ones
+    const int e_first = max(traj_len - BEV_TRAJ_LEN, 0);
+    if (dyn_refresh && !dyn_bad) {
+        for (int e = e_first; e < min(valid, traj_len); e++) {
+            const int s = e % BEV_TRAJ_LEN;
+            const int* hdr = out + OFF_HDR + (3 + s) * HDR_INTS;
+            if (!(hdr[H_FLAGS] & F_SIMPLE)) { dyn_bad = 1; break; }
+            dyn_paint((uint32_t)out[OFF_TAB + (2 + s) * TAB_ROWS + lane], hdr[H_MINY], hdr[H_NROWS], hdr[H_MINX], hdr[H_MAXX], dyn_code(e));
+        }
+    }
+    for (int e = max(valid, e_first); e < traj_len; e++) {
+        const int l = 3 + e % BEV_TRAJ_LEN;
+        if (!((needm >> l) & 1)) continue;
+        uint32_t sp; int bminy, bnrows, bminx, bmaxx; bool bsimple;
+        do_box(l, sp, bminy, bnrows, bminx, bmaxx, bsimple);
+        if (!bsimple) dyn_bad = 1;
+        if (!dyn_bad) dyn_paint(sp, bminy, bnrows, bminx, bmaxx, dyn_code(e));
+    }
+    {   // lane = ring slot: box around the live entries' boxes (headers written above / in earlier launches)
+        const int s_ = lane, e_ = (traj_len - 1) - (((traj_len - 1 - s_) % BEV_TRAJ_LEN) + BEV_TRAJ_LEN) % BEV_TRAJ_LEN;
+        const bool lv = s_ < BEV_TRAJ_LEN && e_ >= e_first && e_ < traj_len;
+        const int* hdr = out + OFF_HDR + (3 + s_) * HDR_INTS;
+        int lx0 = lv ? hdr[H_MINX] : INT_MAX, lx1 = lv ? hdr[H_MAXX] : INT_MIN, ly0 = lv ? hdr[H_MINY] : INT_MAX, ly1 = lv ? hdr[H_MAXY] : INT_MIN;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lx0 = min(lx0, __shfl_xor(lx0, o)); lx1 = max(lx1, __shfl_xor(lx1, o));
+            ly0 = min(ly0, __shfl_xor(ly0, o)); ly1 = max(ly1, __shfl_xor(ly1, o));
+        }
+        if (lane == 0) { out[OFF_LIVE_X] = lx0; out[OFF_LIVE_X + 1] = lx1; out[OFF_LIVE_Y] = ly0; out[OFF_LIVE_Y + 1] = ly1; }
+    }
+    if (lane == 0) {
+        out[OFF_MAP + M_DIRTY_X0] = dirty_x0; out[OFF_MAP + M_DIRTY_X1] = dirty_x1;
+        out[OFF_MAP + M_DIRTY_Y0] = dirty_y0; out[OFF_MAP + M_DIRTY_Y1] = dirty_y1;
+        out[OFF_MAP + M_DYN_BAD] = dyn_bad; out[OFF_MAP + M_DYN_CODE] = dyn_code(max(traj_len - 1, 0));
     }
     if (lane == 0) {
         p.traj_valid[scene] = traj_len;
@@ -499,15 +592,19 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
     const int traj_len = p.traj_len[scene];
     const int m_traj = min(traj_len, BEV_TRAJ_LEN);
     const int n_box = (p.debug & 4) ? 0 : 3 + (traj_len > 1 ? m_traj : 0);
+    // `legacy`: a moving box of this episode is not a plain one-span-per-row box (never for car-shaped boxes inside the surface):
+    // the per-tile raster of all boxes, which needs every span table; otherwise only the vehicle's table is ever read
+    const bool legacy = scr[OFF_MAP + M_DYN_BAD] != 0 || (n_box > 2 && !veh_hidden && !(scr[OFF_HDR + 2 * HDR_INTS + H_FLAGS] & F_SIMPLE)) || (p.debug & 32);
     {
         const uint4* src = (const uint4*)(scr + OFF_TAB);
-        for (int i = threadIdx.x; i < N_TAB * TAB_ROWS / 4; i += BEV_WAVES * WAVE) ((uint4*)tabs)[i] = src[i];
+        if (legacy) { for (int i = threadIdx.x; i < N_TAB * TAB_ROWS / 4; i += BEV_WAVES * WAVE) ((uint4*)tabs)[i] = src[i]; }
+        else if (threadIdx.x < TAB_ROWS / 4) ((uint4*)tabs)[TAB_ROWS / 4 + threadIdx.x] = src[TAB_ROWS / 4 + threadIdx.x];
     }
     if (threadIdx.x < 25) pal[threadIdx.x] = palette(threadIdx.x);
     __syncthreads();                                                         // the only workgroup-wide barrier
     // lane = box in draw order: start outline, dest, vehicle, trajectory oldest -> newest (:307-320)
     int bslot = 0, bid = 0, h_miny = 0, h_nrows = 0, h_flags = 0, h_minx = 0, h_maxx = 0, h_maxy = 0;
-    if (lane < n_box) {
+    if (lane < n_box && (legacy || lane == 2)) {
         if (lane < 3) { bslot = lane; bid = 2 + lane; }
         else {
             const int i = lane - 3;
@@ -519,6 +616,32 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         h_miny = hdr[H_MINY]; h_nrows = hdr[H_NROWS]; h_flags = hdr[H_FLAGS]; h_minx = hdr[H_MINX]; h_maxx = hdr[H_MAXX]; h_maxy = hdr[H_MAXY];
     }
     const uint8_t* layer = p.layer + (size_t)scene * BEV_LAYER_ROWS * BEV_LAYER_STRIDE;      // the static layer (k_bev_static)
+    // the trajectory layer (k_bev_prep) and the vehicle box's span table replace the per-tile raster of the moving boxes, unless a box
+    // of this episode is not a plain one-span-per-row box (`legacy`: never for car-shaped boxes inside the surface; kept exact)
+    const uint8_t* dynl = p.dyn + (size_t)scene * BEV_DYN_BYTES;
+    const int dirty_x0 = scr[OFF_LIVE_X], dirty_x1 = scr[OFF_LIVE_X + 1];          // (the box around the boxes drawn now)
+    const int dirty_y0 = scr[OFF_LIVE_Y], dirty_y1 = scr[OFF_LIVE_Y + 1];
+    const int code_new = scr[OFF_MAP + M_DYN_CODE];
+    const int v_miny = __builtin_amdgcn_readlane(h_miny, 2), v_nrows = __builtin_amdgcn_readlane(h_nrows, 2);
+    const int v_minx = __builtin_amdgcn_readlane(h_minx, 2), v_maxx = __builtin_amdgcn_readlane(h_maxx, 2), v_maxy = __builtin_amdgcn_readlane(h_maxy, 2);
+    const bool veh_drawn = n_box > 2 && !veh_hidden;
+    const bool traj_drawn = n_box > 3;
+    // palette id of the moving boxes at world pixel (x, y) inside the surface, 0 = none (vehicle below the trajectory, :312-320)
+    auto moving_id = [&](int x, int y, bool veh_on, bool traj_on) -> int {
+        int did = 0;
+        if (veh_on) {
+            const int r = y - v_miny;
+            const uint32_t sp = ((unsigned)r < (unsigned)v_nrows) ? tabs[TAB_ROWS + r] : SPAN_EMPTY;
+            did = (x + 1 >= (int)(sp & 0xffff) && x + 1 <= (int)(sp >> 16)) ? 4 : 0;
+        }
+        if (traj_on) {
+            const int c = dynl[dyn_byte(x, y)];
+            int age = code_new - c;
+            age += age < 0 ? DYN_MOD : 0;
+            did = (c != 0 && age < m_traj) ? 24 - age : did;
+        }
+        return did;
+    };
 
     for (int it = 0; it < TILES * TILES / BEV_WAVES; it++) {
         const int tile = tile_of(wave, it);
@@ -526,6 +649,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         // ---- world window of this tile: the map is affine, so the extremes are at the corner samples ----------------
         Window w;
         bool need_bg = false;
+        int qcx[4], qcy[4];                                                  // world pixels of the tile's corner samples
         {
             const int cxa = 4 * TILE_OUT * tx + 1, cxb = 4 * TILE_OUT * tx + 4 * TILE_OUT - 2;
             const int cya = 4 * TILE_OUT * ty + 1, cyb = 4 * TILE_OUT * ty + 4 * TILE_OUT - 2;
@@ -534,6 +658,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             for (int c = 0; c < 4; c++) {
                 int dx, dy;
                 map_raw(m, (c & 1) ? cxb : cxa, (c & 2) ? cyb : cya, dx, dy);
+                qcx[c] = dx >> 16; qcy[c] = dy >> 16;
                 lo_x = min(lo_x, dx >> 16); hi_x = max(hi_x, dx >> 16); lo_y = min(lo_y, dy >> 16); hi_y = max(hi_y, dy >> 16);
                 need_bg = need_bg || (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
             }
@@ -549,7 +674,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             // The LDS window only holds what MOVES -- the vehicle and the trajectory boxes (0 = nothing drawn) -- and only for
             // tiles such a box reaches (the centre of the crop and the trail behind the car); the static part of the surface
             // (background, obstacles, start outline, dest) is sampled straight from the scene's packed layer by the gather.
-            bool hit = live && lane >= 2 && lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
+            bool hit = legacy && live && lane >= 2 && lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
             if (lane == 2 && veh_hidden) hit = false;
             unsigned long long mask = __ballot(hit);
             const bool dyn = mask != 0;
@@ -610,7 +735,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             }
             wave_phase();
             if (pass == 0) {                                                 // rotate()'s background: the surface's pixel (0, 0)
-                const int did = dyn ? fb[0] : 0;
+                const int did = legacy ? (dyn ? fb[0] : 0) : ((live && !(p.debug & 4)) ? moving_id(0, 0, veh_drawn, traj_drawn) : 0);
                 bg_id = did ? did : ((p.debug & 2) ? 0 : (layer[0] & 3));
             }
         }
@@ -620,6 +745,26 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         // instead of issuing 16 single-byte global loads per lane
         const int cbx0 = w.x0 >> 5, cby0 = w.y0 >> 4;
         const int ncx = (w.x1 >> 5) - cbx0 + 1, ncy = (w.y1 >> 4) - cby0 + 1;
+        // which of the moving boxes can reach this tile's window (wave-uniform)
+        const bool mv_on = !legacy && !(p.debug & 1);
+        // Does the axis-aligned box [x0, x1] x [y0, y1] meet the tile?  The tile's samples lie in the (rotated) square spanned by its
+        // corner samples: besides the window test (the world axes) the box is projected on the square's two edge directions
+        // (2 px of slack for the 16.16 truncation of the corners).
+        auto meets_tile = [&](int x0, int x1, int y0, int y1) -> bool {
+            if (x1 < w.x0 || x0 > w.x1 || y1 < w.y0 || y0 > w.y1) return false;
+#pragma unroll
+            for (int ax = 1; ax <= 2; ax++) {                                // corner 1: along crop x, corner 2: along crop y
+                const int ux = qcx[ax] - qcx[0], uy = qcy[ax] - qcy[0];
+                const int t0 = 0, t1 = ux * ux + uy * uy;                   // the square projects onto [0, |u|^2] (from corner 0)
+                const int pa = (x0 - qcx[0]) * ux, pb = (x1 - qcx[0]) * ux, pc = (y0 - qcy[0]) * uy, pd = (y1 - qcy[0]) * uy;
+                const int lo = min(pa, pb) + min(pc, pd), hi = max(pa, pb) + max(pc, pd);
+                const int slack = 2 * (abs(ux) + abs(uy));
+                if (hi < t0 - slack || lo > t1 + slack) return false;
+            }
+            return true;
+        };
+        const bool veh_on = mv_on && veh_drawn && meets_tile(v_minx, v_maxx, v_miny, v_maxy);
+        const bool traj_on = mv_on && traj_drawn && meets_tile(dirty_x0, dirty_x1, dirty_y0, dirty_y1);
         const bool cached = !has_dyn && w.x0 <= w.x1 && w.y0 <= w.y1 && ncx <= 4 && ncx * ncy * 128 <= FB_BYTES && !(p.debug & 16);
         if (cached) {
             wave_phase();                                                    // the previous tile's gather is done
@@ -663,6 +808,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                     int id = (static_byte(wx, wy) >> ((wx & 3) * 2)) & 3;
                     if (p.debug & 2) id = 0;
                     if (has_dyn) { const int did = fb[__mul24(wy - w.y0, FB_STRIDE) + wx - w.x0]; id = did ? did : id; }
+                    if (veh_on || traj_on) { const int did = moving_id(wx, wy, veh_on, traj_on); id = did ? did : id; }
                     ids[jj] |= (uint32_t)id << (8 * s);
                 }
                 dxb += dxx4; dyb += dyx4;                                     // next output: 4 crop pixels to the right
@@ -681,6 +827,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
                     int id = (static_byte(lx, ly) >> ((lx & 3) * 2)) & 3;
                     if (p.debug & 2) id = 0;
                     if (has_dyn) { const int did = fb[__mul24(sy - w.y0, FB_STRIDE) + sx - w.x0]; id = did ? did : id; }
+                    if (veh_on || traj_on) { const int did = moving_id(lx, ly, veh_on, traj_on); id = did ? did : id; }
                     id = outside ? bg_id : id;                                // rotate()'s bgcolor
                     id = white ? 0 : id;                                      // observation.fill(BG_COLOR) -> black later
                     ids[jj] |= (uint32_t)id << (8 * s);

@@ -56,6 +56,7 @@ struct RsParams {
 constexpr int BEV_IMG = HOPE_IMG_SIZE;
 constexpr int BEV_TRAJ_LEN = HOPE_TRAJ_RENDER_LEN;
 constexpr int BEV_LAYER_ROWS = 512, BEV_LAYER_STRIDE = 128;   // 500 x 500 world pixels, 4 per byte, tiled in 32 x 16 pixel blocks of 128 bytes: 16 x 32 blocks = 64 KiB per scene
+constexpr size_t BEV_DYN_BYTES = 256 * 1024;   // trajectory layer: 500 x 500 world pixels, one byte each, tiled in 16 x 8 pixel blocks of 128 bytes (32 x 64 blocks)
 constexpr int BEV_SCENE_INTS = 16 + (3 + BEV_TRAJ_LEN) * 16 + (2 + BEV_TRAJ_LEN) * 64;   // k_bev_prep's per-scene scratch
 struct BevParams {
     int n, max_obst;
@@ -67,6 +68,7 @@ struct BevParams {
     const int32_t* traj_len;  // [n] len(vehicle.trajectory)
     int32_t* traj_valid;      // [n] trajectory entries below this index already have their span table
     uint8_t* layer;           // [n][BEV_LAYER_ROWS][BEV_LAYER_STRIDE] static layer (obstacles, start outline, dest): 2 bits per pixel
+    uint8_t* dyn;             // [n][BEV_DYN_BYTES] trajectory layer: per pixel the code of the NEWEST trajectory box that covers it (0: none)
     int32_t* layer_valid;     // [n] the layer matches the scene's map
     int32_t* rebuild;         // [1 + n] count, then the scenes k_bev_prep found with a stale layer (k_bev_static rebuilds them)
     int* scratch;             // [n][BEV_SCENE_INTS] map + box headers + span tables (k_bev_prep -> k_bev_image)

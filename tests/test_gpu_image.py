@@ -236,3 +236,37 @@ def test_image_with_more_than_128_obstacles():
     img = env.img.cpu().numpy()
     assert (img == 150).any()                               # obstacles are visible
     env.close()
+
+
+def test_image_rollout_with_the_per_tile_raster_of_the_moving_boxes(monkeypatch):
+    """The trajectory layer replaced the per-tile raster of the moving boxes for plain car-shaped boxes; the raster stays as the
+    exact path for any other box shape and must keep producing the same pixels (HOPE_BEV_LEGACY forces it)."""
+    monkeypatch.setenv('HOPE_BEV_LEGACY', '1')
+    test_image_rollout_matches_oracle('mixed')
+
+
+def test_image_trajectory_layer_over_a_long_episode():
+    """More than 192 trajectory entries without a reset: the codes of the trajectory layer wrap and the layer is cleared and
+    repainted every 96 entries (hope_bev.hip: DYN_MOD, DYN_REFRESH).  Every uint8 equal to the oracle's."""
+    from hope_amd.scenes import SceneSource
+    rng = np.random.default_rng(23)
+    n = 48
+    src = SceneSource(levels=('Normal',), seed=29)
+    scenes = [src.draw() for _ in range(n)]
+    env, orc = make_img_pair(scenes, max_obst=32)
+    env.reset_obs(); orc.reset_obs()
+    mask = torch.ones(n, dtype=torch.uint8, device=env.device)
+    checked = 0
+    pushes = np.ones(n, np.int64)                   # entries of vehicle.trajectory so far (reset leaves [start])
+    for it in range(236):
+        # slow wiggles: few collisions, the car moves nearly every step; finished scenes are NOT restarted, they keep stepping
+        act = np.stack([rng.uniform(-1, 1, n), 0.3 * np.where((it // 7) % 2 == 0, 1.0, -1.0) * np.ones(n)], 1)
+        before = orc.pose.copy()
+        env.step(torch.from_numpy(act).to(env.device))
+        orc.step(act)
+        pushes += (orc.pose != before).any(axis=1)  # (a step that kept >= 1 sub-step appends its final state)
+        if it % 9 == 0 or 90 <= it <= 100 or it >= 186:
+            assert_images_equal(env, orc, f'step {it}')
+            checked += 1
+    assert pushes.max() > 200 and checked > 60, (pushes.max(), checked)
+    env.close()
