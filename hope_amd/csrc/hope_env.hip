@@ -873,7 +873,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (fork && n_chain == 2) {
             // the image depends on the step kernels only (pose, trajectory ring), not on the Reeds-Shepp search: render it on
             // a third stream while the two chains run k_rs_words / k_rs_validate
-            hipStream_t si = h->side[2];
+            // (with HOPE_DEFER_RS both chains run on library streams and the caller's stream is idle during the step: the image,
+            // which the caller waits for anyway, goes there -- the third library stream shares a hardware queue with a chain)
+            hipStream_t si = defer ? s : h->side[2];
             HIPCHK(hipStreamWaitEvent(si, h->ev_step[0], 0));
             HIPCHK(hipStreamWaitEvent(si, h->ev_step[1], 0));
             HIPCHK(launch_bev_image(b, si, tm));
