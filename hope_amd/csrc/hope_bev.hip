@@ -567,13 +567,21 @@ __device__ __forceinline__ int tile_of(int wave, int it) {
     return (t >> (4 * it)) & 15;
 }
 
+// Two instantiations, two launches.  LEGACY = false: the scenes whose moving boxes are all plain car-shaped boxes -- every scene
+// in practice: trajectory layer + vehicle span table, no raster, LDS = palette + two tables + a 3.5 KB block cache per wave
+// (15 KB per workgroup instead of 39 KB: more resident waves, fewer registers).  LEGACY = true: the per-tile raster of the
+// moving boxes for the other scenes; its launch finds none and its workgroups exit at once.
+constexpr int CACHE_SLOT = 28 * 128;           // layer blocks of one tile's window (4 x 7 at most)
+template <bool LEGACY>
 __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
-    // LDS: palette (128 B) | span tables shared by the workgroup's waves (5.6 KB) | one window per wave (8.3 KB + 72)
+    // LDS: palette (128 B) | span tables shared by the workgroup's waves (LEGACY: all, 5.6 KB; else dest + vehicle) | per wave:
+    // LEGACY the window (8.3 KB + 72), else the block cache
     extern __shared__ __align__(16) uint8_t lds_raw[];
     uint32_t* pal = (uint32_t*)lds_raw;
     uint32_t* tabs = pal + 32;                                               // [N_TAB][TAB_ROWS]
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    uint8_t* fb = lds_raw + 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + wave * FB_SLOT;   // + 64 dummy bytes (fill_span)
+    constexpr int SLOT = LEGACY ? FB_SLOT : CACHE_SLOT, SLOT_BYTES = LEGACY ? FB_BYTES : CACHE_SLOT;
+    uint8_t* fb = lds_raw + 32 * sizeof(uint32_t) + (LEGACY ? N_TAB : 2) * TAB_ROWS * sizeof(uint32_t) + wave * SLOT;   // (LEGACY: + 64 dummy bytes, fill_span)
     const int scene = scene_of_block(blockIdx.x, p.n);
     // k_bev_static (the launch before this one) has consumed the list of stale layers: it starts empty for the next image
     if (blockIdx.x == 0 && threadIdx.x == 0) p.rebuild[0] = 0;
@@ -595,16 +603,17 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
     // `legacy`: a moving box of this episode is not a plain one-span-per-row box (never for car-shaped boxes inside the surface):
     // the per-tile raster of all boxes, which needs every span table; otherwise only the vehicle's table is ever read
     const bool legacy = scr[OFF_MAP + M_DYN_BAD] != 0 || (n_box > 2 && !veh_hidden && !(scr[OFF_HDR + 2 * HDR_INTS + H_FLAGS] & F_SIMPLE)) || (p.debug & 32);
+    if (legacy != LEGACY) return;                                            // the other launch renders this scene (workgroup-uniform)
     {
         const uint4* src = (const uint4*)(scr + OFF_TAB);
-        if (legacy) { for (int i = threadIdx.x; i < N_TAB * TAB_ROWS / 4; i += BEV_WAVES * WAVE) ((uint4*)tabs)[i] = src[i]; }
+        if (LEGACY) { for (int i = threadIdx.x; i < N_TAB * TAB_ROWS / 4; i += BEV_WAVES * WAVE) ((uint4*)tabs)[i] = src[i]; }
         else if (threadIdx.x < TAB_ROWS / 4) ((uint4*)tabs)[TAB_ROWS / 4 + threadIdx.x] = src[TAB_ROWS / 4 + threadIdx.x];
     }
     if (threadIdx.x < 25) pal[threadIdx.x] = palette(threadIdx.x);
     __syncthreads();                                                         // the only workgroup-wide barrier
     // lane = box in draw order: start outline, dest, vehicle, trajectory oldest -> newest (:307-320)
     int bslot = 0, bid = 0, h_miny = 0, h_nrows = 0, h_flags = 0, h_minx = 0, h_maxx = 0, h_maxy = 0;
-    if (lane < n_box && (legacy || lane == 2)) {
+    if (lane < n_box && (LEGACY || lane == 2)) {
         if (lane < 3) { bslot = lane; bid = 2 + lane; }
         else {
             const int i = lane - 3;
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             // The LDS window only holds what MOVES -- the vehicle and the trajectory boxes (0 = nothing drawn) -- and only for
             // tiles such a box reaches (the centre of the crop and the trail behind the car); the static part of the surface
             // (background, obstacles, start outline, dest) is sampled straight from the scene's packed layer by the gather.
-            bool hit = legacy && live && lane >= 2 && lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
+            bool hit = LEGACY && live && lane >= 2 && lane < n_box && !(h_maxx < cw.x0 || h_minx > cw.x1 || h_maxy < cw.y0 || h_miny > cw.y1);
             if (lane == 2 && veh_hidden) hit = false;
             unsigned long long mask = __ballot(hit);
             const bool dyn = mask != 0;
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
             }
             wave_phase();
             if (pass == 0) {                                                 // rotate()'s background: the surface's pixel (0, 0)
-                const int did = legacy ? (dyn ? fb[0] : 0) : ((live && !(p.debug & 4)) ? moving_id(0, 0, veh_drawn, traj_drawn) : 0);
+                const int did = LEGACY ? (dyn ? fb[0] : 0) : ((live && !(p.debug & 4)) ? moving_id(0, 0, veh_drawn, traj_drawn) : 0);
                 bg_id = did ? did : ((p.debug & 2) ? 0 : (layer[0] & 3));
             }
         }
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         const int cbx0 = w.x0 >> 5, cby0 = w.y0 >> 4;
         const int ncx = (w.x1 >> 5) - cbx0 + 1, ncy = (w.y1 >> 4) - cby0 + 1;
         // which of the moving boxes can reach this tile's window (wave-uniform)
-        const bool mv_on = !legacy && !(p.debug & 1);
+        const bool mv_on = !LEGACY && !(p.debug & 1);
         // Does the axis-aligned box [x0, x1] x [y0, y1] meet the tile?  The tile's samples lie in the (rotated) square spanned by its
         // corner samples: besides the window test (the world axes) the box is projected on the square's two edge directions
         // (2 px of slack for the 16.16 truncation of the corners).
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
         };
         const bool veh_on = mv_on && veh_drawn && meets_tile(v_minx, v_maxx, v_miny, v_maxy);
         const bool traj_on = mv_on && traj_drawn && meets_tile(dirty_x0, dirty_x1, dirty_y0, dirty_y1);
-        const bool cached = !has_dyn && w.x0 <= w.x1 && w.y0 <= w.y1 && ncx <= 4 && ncx * ncy * 128 <= FB_BYTES && !(p.debug & 16);
+        const bool cached = !has_dyn && w.x0 <= w.x1 && w.y0 <= w.y1 && ncx <= 4 && ncx * ncy * 128 <= SLOT_BYTES && !(p.debug & 16);
         if (cached) {
             wave_phase();                                                    // the previous tile's gather is done
             const int l = lane & 31;
@@ -853,7 +862,10 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
 
 }  // namespace
 
-size_t bev_lds_bytes() { return 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * FB_SLOT; }
+size_t bev_lds_bytes(bool legacy) {
+    return legacy ? 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * FB_SLOT
+                  : 32 * sizeof(uint32_t) + 2 * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * CACHE_SLOT;
+}
 
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer) {
     hipError_t e = hipSuccess;
@@ -873,7 +885,8 @@ hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer*
     if (timer) timer->end(stream);
     const dim3 grid(p.n), block(BEV_WAVES * WAVE);
     if (timer) timer->begin(HOPE_K_IMAGE, stream);
-    hipLaunchKernelGGL(k_bev_image, grid, block, bev_lds_bytes(), stream, p);
+    hipLaunchKernelGGL(k_bev_image<false>, grid, block, bev_lds_bytes(false), stream, p);
+    hipLaunchKernelGGL(k_bev_image<true>, grid, block, bev_lds_bytes(true), stream, p);      // (scenes with a box that is not a plain car box: none in practice)
     if (timer) timer->end(stream);
     return hipGetLastError();
 }

@@ -92,6 +92,6 @@ hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset);   // 
 size_t rs_lds_bytes(int max_obst);
 size_t rs_rec_bytes_per_scene();
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer);
-size_t bev_lds_bytes();
+size_t bev_lds_bytes(bool legacy);
 
 }  // namespace hope
