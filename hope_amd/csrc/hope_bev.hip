@@ -571,9 +571,12 @@ __device__ __forceinline__ int tile_of(int wave, int it) {
 // in practice: trajectory layer + vehicle span table, no raster, LDS = palette + two tables + a 3.5 KB block cache per wave
 // (15 KB per workgroup instead of 39 KB: more resident waves, fewer registers).  LEGACY = true: the per-tile raster of the
 // moving boxes for the other scenes; its launch finds none and its workgroups exit at once.
+#ifndef BEV_OCC
+#define BEV_OCC 5                             // (6: 80 VGPRs + 8 spilled, 2.20 ms; 5: 90 VGPRs, 2.15 ms per 65 536 scenes)
+#endif
 constexpr int CACHE_SLOT = 28 * 128;           // layer blocks of one tile's window (4 x 7 at most)
 template <bool LEGACY>
-__global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_image(BevParams p) {
+__global__ __launch_bounds__(BEV_WAVES * 64, LEGACY ? 4 : BEV_OCC) void k_bev_image(BevParams p) {
     // LDS: palette (128 B) | span tables shared by the workgroup's waves (LEGACY: all, 5.6 KB; else dest + vehicle) | per wave:
     // LEGACY the window (8.3 KB + 72), else the block cache
     extern __shared__ __align__(16) uint8_t lds_raw[];
