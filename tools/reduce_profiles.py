@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KERNELS = ('k_kinematics', 'k_env_step', 'k_post', 'k_rs_compact', 'k_rs_words', 'k_rs_segs', 'k_rs_validate', 'k_bev_image', 'k_bev_prep')
+KERNELS = ('k_kinematics', 'k_env_step', 'k_post', 'k_rs_compact', 'k_rs_words', 'k_rs_segs', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_bev_static')
 
 
 def find(d, pat):
