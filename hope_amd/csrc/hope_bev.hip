@@ -169,7 +169,9 @@ __device__ __forceinline__ void fill_span(uint8_t* row, uint8_t* dummy, int id, 
     }
 }
 // draw_fillpoly on the LDS window: n points (closing point included), wave-uniform; lane = row
-template <int STRIDE, int BYTES>
+// QUAD (windows of at most 16 rows: the bands of k_bev_static): four lanes per row, each filling a quarter of the row's span -- a
+// wall that crosses the whole surface is 500 pixels = 125 trips of fill_span for one lane
+template <int STRIDE, int BYTES, bool QUAD = false>
 __device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, int wx0, const int (&px)[5], const int (&py)[5], int n,
                                           int id, int lane) {
     int miny = py[0], maxy = py[0], minx = px[0], maxx = px[0];
@@ -178,13 +180,26 @@ __device__ __forceinline__ void fill_poly(uint8_t* fb, const Window& w, int wx0,
         if (i < n) { miny = min(miny, py[i]); maxy = max(maxy, py[i]); minx = min(minx, px[i]); maxx = max(maxx, px[i]); }
     if (miny == maxy) { hline<STRIDE>(fb, w, wx0, id, minx, miny, maxx, lane); return; }
     const int ylo = max(miny, w.y0), yhi = min(maxy, w.y1);
-    for (int yb = ylo; yb <= yhi; yb += WAVE) {
-        const int y = yb + lane;
+    const int rl = QUAD ? (lane & 15) : lane, quarter = QUAD ? (lane >> 4) : 0;
+    auto part = [&](int& a, int& b) {                                    // this lane's quarter of [a, b], cut at multiples of 4 pixels
+        if (!QUAD || a > b) return;
+        const int piece = (((b - a + 1 + 3) >> 2) + 3) & ~3;
+        a += quarter * piece;
+        b = min(b, a + piece - 1);
+    };
+    for (int yb = ylo; yb <= yhi; yb += QUAD ? 16 : WAVE) {
+        const int y = yb + rl;
         const Spans c = row_spans(px, py, n, maxy, y, y <= yhi);
         uint8_t* row = fb + __mul24(y - w.y0, STRIDE) - wx0;
         uint8_t* dummy = fb + BYTES + lane;
-        fill_span(row, dummy, id, c.cnt >= 2 ? max(c.a0, w.x0) : 1, c.cnt >= 2 ? min(c.a1, w.x1) : 0);
-        if (__any(c.cnt >= 4)) fill_span(row, dummy, id, c.cnt >= 4 ? max(c.a2, w.x0) : 1, c.cnt >= 4 ? min(c.a3, w.x1) : 0);
+        int a0 = c.cnt >= 2 ? max(c.a0, w.x0) : 1, b0 = c.cnt >= 2 ? min(c.a1, w.x1) : 0;
+        part(a0, b0);
+        fill_span(row, dummy, id, a0, b0);
+        if (__any(c.cnt >= 4)) {
+            int a1 = c.cnt >= 4 ? max(c.a2, w.x0) : 1, b1 = c.cnt >= 4 ? min(c.a3, w.x1) : 0;
+            part(a1, b1);
+            fill_span(row, dummy, id, a1, b1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 5; i++) {                                        // horizontal border edges strictly inside in y
@@ -519,13 +534,13 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_static(BevParams p) {
                     const int qn = __builtin_amdgcn_readlane(nv, l);
                     if (qn == 3) { qx[3] = qx[0]; qy[3] = qy[0]; qx[4] = qx[0]; qy[4] = qy[0]; }
                     else { qx[4] = qx[0]; qy[4] = qy[0]; }
-                    fill_poly<SL_STRIDE, SL_BYTES>(fb, cw, 0, qx, qy, qn + 1, 1, lane);
+                    fill_poly<SL_STRIDE, SL_BYTES, true>(fb, cw, 0, qx, qy, qn + 1, 1, lane);
                 }
             }
 #pragma unroll
             for (int k = 1; k < 5; k++) line<SL_STRIDE>(fb, cw, 0, 2, sx[k - 1], sy[k - 1], sx[k], sy[k], lane);      // start: lines(closed=True), width 1
             line<SL_STRIDE>(fb, cw, 0, 2, sx[4], sy[4], sx[0], sy[0], lane);
-            fill_poly<SL_STRIDE, SL_BYTES>(fb, cw, 0, dx, dy, 5, 3, lane);                                              // dest
+            fill_poly<SL_STRIDE, SL_BYTES, true>(fb, cw, 0, dx, dy, 5, 3, lane);                                        // dest
             wave_phase();
             // pack: 16 pixels (bytes 0..3) -> one dword of the layer; lane = dword of a row (32 per row), rows two at a time
             const int rows = cw.y1 - cw.y0 + 1;
