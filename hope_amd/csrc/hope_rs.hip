@@ -1485,7 +1485,10 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->end(stream);
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
     static const bool no_prio = getenv("HOPE_RS_PRIO") && atoi(getenv("HOPE_RS_PRIO")) == 0;
-    const int flags = (p.obs_f64 ? 1 : 0) | dbg | ((no_prio || p.n < 32768) ? 0x10000 : 0);     // (below 32 768 scenes: neutral to -1.6 %)
+    // only for the launch of the class with more scenes, i.e. the longer chain (both launches: 0.657 ms / steady 0.688; only the
+    // longer chain's: 0.657 / 0.678; only the shorter chain's: 0.672 / 0.696); below 32 768 scenes neutral to -1.6 %: off
+    const bool longer_chain = 2 * (long long)p.max_queue >= p.n;
+    const int flags = (p.obs_f64 ? 1 : 0) | dbg | ((no_prio || p.n < 32768 || !longer_chain) ? 0x10000 : 0);
     if (exact) {
         if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
         else if (occ != 4) hipLaunchKernelGGL((k_rs_validate<3, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
