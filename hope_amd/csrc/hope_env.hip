@@ -1087,7 +1087,7 @@ int hope_env_pool_staging(hope_env_t* h, int n_pool, double** start, double** de
 }
 
 int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
-    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
+    // (no join of an unjoined Reeds-Shepp chain here: only the motion launches read the pool, and ev_last_step covers them)
     if (!h || n_pool <= 0) return fail(HOPE_EINVAL, "hope_env_commit_pool: bad argument");
     if (n_pool > h->pstage.cap) return fail(HOPE_ESTATE, "hope_env_commit_pool: more entries than hope_env_pool_staging provided");
     for (int k = 0; k < n_pool; k++)
