@@ -102,6 +102,9 @@ class ParkingBatch:
         start, dest, bbox, verts, nob, _nv = pack_scenes(scenes, self.max_obst) if isinstance(scenes, list) else scenes
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (start, dest, bbox, verts)]
         nob = np.ascontiguousarray(nob, dtype=np.int32)
+        if getattr(self, '_refresher_filling', False):
+            raise L.HopeError('set_pool while a PoolRefresher fill is running: the pinned staging arrays are being written by its '
+                              'thread (close() / poll(wait=True) the refresher first)')
         torch.cuda.synchronize(self.device)
         L.check(self.lib.hope_env_set_pool(self.h, len(nob), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
                                            a[3].ctypes.data, nob.ctypes.data), 'hope_env_set_pool')
@@ -117,6 +120,19 @@ class ParkingBatch:
         for q, shp, ct in zip(ptr, shapes, (C.c_double,) * 4 + (C.c_int32,)):
             out.append(np.ctypeslib.as_array(C.cast(q, C.POINTER(ct)), shape=(int(np.prod(shp)),)).reshape(shp))
         return tuple(out)
+
+    def pool_staging_ready(self):
+        """True when pool_staging() would not wait (the previous commit's copies have left the pinned arrays)"""
+        rc = self.lib.hope_env_pool_staging_ready(self.h)
+        if rc < 0:
+            L.check(rc, 'hope_env_pool_staging_ready')
+        return bool(rc)
+
+    def pool_generation(self):
+        """changes whenever the set of maps a draw can return changes (set_pool / commit_pool / set_dlp_cases)"""
+        g = C.c_uint64(0)
+        L.check(self.lib.hope_env_pool_generation(self.h, C.byref(g)), 'hope_env_pool_generation')
+        return int(g.value)
 
     def commit_pool(self, n_pool):
         """asynchronous upload of the staged pool + swap: steps enqueued afterwards draw from it (no synchronisation)"""
@@ -165,17 +181,20 @@ class ParkingBatch:
         return start, dest, bbox, verts, nob
 
     def pool_state(self):
-        """(pool index, episode counter) of every scene: with download_state() the whole snapshot of a run that draws maps"""
+        """(pool index, episode counter) of every scene: with download_state() and pool_generation() the whole snapshot of a
+        run that draws maps from a pool that is NOT replaced in the meantime (refreshed runs: download_scenes / set_scene_arrays)"""
         idx, ep = np.zeros(self.n, np.int32), np.zeros(self.n, np.uint32)
         L.check(self.lib.hope_env_download_pool_state(self.h, idx.ctypes.data, ep.ctypes.data), 'hope_env_download_pool_state')
         return idx, ep
 
-    def restore_maps(self, pool_index, episode, seed):
-        """repeat the draws of a snapshot (same pool / cases resident, the seed in use then); follow with upload_state()"""
+    def restore_maps(self, pool_index, episode, seed, generation=0):
+        """repeat the draws of a snapshot (the seed in use then); `generation` = pool_generation() saved with the snapshot: the
+        call fails (HOPE_ESTATE) if the pool has been replaced since -- the draws would return other maps; 0 skips the check.
+        Follow with upload_state()"""
         drawn = np.ascontiguousarray(np.asarray(pool_index) != -1, dtype=np.uint8)
         ep = np.ascontiguousarray(episode, dtype=np.uint32)
-        L.check(self.lib.hope_env_restore_maps(self.h, drawn.ctypes.data, ep.ctypes.data, C.c_uint64(int(seed) & (2 ** 64 - 1))),
-                'hope_env_restore_maps')
+        L.check(self.lib.hope_env_restore_maps(self.h, drawn.ctypes.data, ep.ctypes.data, C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                               C.c_uint64(int(generation))), 'hope_env_restore_maps')
         return self
 
     def redraw(self, mask, seed=0):

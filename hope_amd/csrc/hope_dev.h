@@ -70,20 +70,27 @@ __device__ __forceinline__ void two_prod(double a, double b, double& p, double& 
     e = __builtin_fma(a, b, -p);
 }
 
-// exact sign of ax*by - ax*cy - cx*by - ay*bx + ay*cx + cy*bx; rarely executed -> keep out of line
-__device__ __noinline__ int orient_exact(double ax, double ay, double bx, double by, double cx, double cy) {
-    double t[12];
-    two_prod(ax, by, t[0], t[1]);
-    two_prod(-ax, cy, t[2], t[3]);
-    two_prod(-cx, by, t[4], t[5]);
-    two_prod(-ay, bx, t[6], t[7]);
-    two_prod(ay, cx, t[8], t[9]);
-    two_prod(cy, bx, t[10], t[11]);
-    double ex[16];
+// Exact sign of ax*by - ax*cy - cx*by - ay*bx + ay*cx + cy*bx (the determinant GEOS's Orientation::index takes the sign of), by an
+// expansion sum with zero elimination.  Executed by ONE active lane, practically never (an orientation inside its rounding error
+// bound: exactly collinear / touching input); its two work arrays t[12], ex[16] are dynamically indexed, so they live in LDS
+// (`w`, 28 doubles) -- as private arrays they would be the kernel's only scratch memory, and out of line (the first version) every
+// call site of the four-deep unrolled collision tests carried a call sequence: 100+ of them, 40 % of the kernel's code size.
+__device__ __forceinline__ int orient_exact_lds(double ax, double ay, double bx, double by, double cx, double cy, double* w) {
+    double* t = w;
+    double* ex = w + 12;
+    double p_, e_;
+    two_prod(ax, by, p_, e_); t[0] = p_; t[1] = e_;
+    two_prod(-ax, cy, p_, e_); t[2] = p_; t[3] = e_;
+    two_prod(-cx, by, p_, e_); t[4] = p_; t[5] = e_;
+    two_prod(-ay, bx, p_, e_); t[6] = p_; t[7] = e_;
+    two_prod(ay, cx, p_, e_); t[8] = p_; t[9] = e_;
+    two_prod(cy, bx, p_, e_); t[10] = p_; t[11] = e_;
     int m = 0;
+#pragma unroll 1
     for (int i = 0; i < 12; i++) {
         double q = t[i];
         int mm = 0;
+#pragma unroll 1
         for (int j = 0; j < m; j++) {
             double s, e;
             two_sum(q, ex[j], s, e);
@@ -93,6 +100,7 @@ __device__ __noinline__ int orient_exact(double ax, double ay, double bx, double
         ex[mm++] = q;
         m = mm;
     }
+#pragma unroll 1
     for (int j = m - 1; j >= 0; j--) {
         if (ex[j] > 0) return 1;
         if (ex[j] < 0) return -1;
@@ -100,39 +108,49 @@ __device__ __noinline__ int orient_exact(double ax, double ay, double bx, double
     return 0;
 }
 
-__device__ __forceinline__ int orient(double ax, double ay, double bx, double by, double cx, double cy) {
-    double detleft = (ax - cx) * (by - cy);
-    double detright = (ay - cy) * (bx - cx);
-    double det = detleft - detright;
-    double detsum = 0;
-    bool ok = false;
+// Orientation::index, fast filter only: the sign of the determinant when its floating-point value is outside the error bound,
+// ORIENT_UNDECIDED otherwise (the caller then takes the robust path).
+constexpr int ORIENT_UNDECIDED = 2;
+__device__ __forceinline__ int orient_filter(double ax, double ay, double bx, double by, double cx, double cy) {
+    const double detleft = (ax - cx) * (by - cy);
+    const double detright = (ay - cy) * (bx - cx);
+    const double det = detleft - detright;
+    const int sg = det > 0 ? 1 : (det < 0 ? -1 : 0);
+    double detsum;
     if (detleft > 0.0) {
-        if (detright <= 0.0) ok = true; else detsum = detleft + detright;
+        if (detright <= 0.0) return sg;
+        detsum = detleft + detright;
     } else if (detleft < 0.0) {
-        if (detright >= 0.0) ok = true; else detsum = -detleft - detright;
-    } else ok = true;
-    if (!ok) {
-        double errbound = 1e-15 * detsum;
-        if (det >= errbound || -det >= errbound) ok = true;
-    }
-    if (ok) return det > 0 ? 1 : (det < 0 ? -1 : 0);
-    return orient_exact(ax, ay, bx, by, cx, cy);
+        if (detright >= 0.0) return sg;
+        detsum = -detleft - detright;
+    } else return sg;
+    const double errbound = 1e-15 * detsum;
+    if (det >= errbound || -det >= errbound) return sg;
+    return ORIENT_UNDECIDED;
 }
 
-// RobustLineIntersector::computeIntersect(p1,p2,q1,q2) != NO_INTERSECTION
-__device__ __forceinline__ bool segments_intersect(double p1x, double p1y, double p2x, double p2y, double q1x,
-                                                   double q1y, double q2x, double q2y) {
+// the exact sign: filter, then the expansion (one active lane, LDS work area w[28])
+__device__ __forceinline__ int orient_robust_lds(double ax, double ay, double bx, double by, double cx, double cy, double* w) {
+    const int f = orient_filter(ax, ay, bx, by, cx, cy);
+    return f != ORIENT_UNDECIDED ? f : orient_exact_lds(ax, ay, bx, by, cx, cy, w);
+}
+
+// RobustLineIntersector::computeIntersect(p1,p2,q1,q2) != NO_INTERSECTION with the orientation FILTER only:
+// 0 = the segments share no point, 1 = they do, 2 = undecided (an orientation the filter could not sign and the others leave open).
+__device__ __forceinline__ int segments_intersect_fast(double p1x, double p1y, double p2x, double p2y, double q1x,
+                                                       double q1y, double q2x, double q2y) {
     double minq = fmin(q1x, q2x), maxq = fmax(q1x, q2x), minp = fmin(p1x, p2x), maxp = fmax(p1x, p2x);
-    if (minp > maxq || maxp < minq) return false;
+    if (minp > maxq || maxp < minq) return 0;
     minq = fmin(q1y, q2y); maxq = fmax(q1y, q2y); minp = fmin(p1y, p2y); maxp = fmax(p1y, p2y);
-    if (minp > maxq || maxp < minq) return false;
-    int Pq1 = orient(p1x, p1y, p2x, p2y, q1x, q1y);
-    int Pq2 = orient(p1x, p1y, p2x, p2y, q2x, q2y);
-    if ((Pq1 > 0 && Pq2 > 0) || (Pq1 < 0 && Pq2 < 0)) return false;
-    int Qp1 = orient(q1x, q1y, q2x, q2y, p1x, p1y);
-    int Qp2 = orient(q1x, q1y, q2x, q2y, p2x, p2y);
-    if ((Qp1 > 0 && Qp2 > 0) || (Qp1 < 0 && Qp2 < 0)) return false;
-    return true;
+    if (minp > maxq || maxp < minq) return 0;
+    const int Pq1 = orient_filter(p1x, p1y, p2x, p2y, q1x, q1y);
+    const int Pq2 = orient_filter(p1x, p1y, p2x, p2y, q2x, q2y);
+    if ((Pq1 == 1 && Pq2 == 1) || (Pq1 == -1 && Pq2 == -1)) return 0;
+    const int Qp1 = orient_filter(q1x, q1y, q2x, q2y, p1x, p1y);
+    const int Qp2 = orient_filter(q1x, q1y, q2x, q2y, p2x, p2y);
+    if ((Qp1 == 1 && Qp2 == 1) || (Qp1 == -1 && Qp2 == -1)) return 0;
+    if (Pq1 == ORIENT_UNDECIDED || Pq2 == ORIENT_UNDECIDED || Qp1 == ORIENT_UNDECIDED || Qp2 == ORIENT_UNDECIDED) return 2;
+    return 1;
 }
 
 // hull corners for a pose; matrix [cos,-sin,sin,cos,x,y] applied to VehicleBox (vehicle.py:32-36)
@@ -147,6 +165,49 @@ __device__ __forceinline__ Box make_box(double px, double py, double ct, double 
         b.y[k] = st * car_x(k) + ct * car_y(k) + py;
     }
     return b;
+}
+
+// The robust form of "any hull edge of the pose shares a point with the obstacle edge (x1,y1)-(x2,y2)" (_detect_collision,
+// car_parking_base.py:153-158): exact orientation signs.  ONE active lane; xl = 40 doubles of LDS (12 coordinates + the expansion's
+// work area).  Rolled loops on purpose: one copy of the expansion code per call site.
+constexpr int ROBUST_LDS_WORDS = 40;
+__device__ __forceinline__ bool hull_edge_intersect_robust(double px, double py, double ct, double st, double x1, double y1,
+                                                           double x2, double y2, double* xl) {
+    {
+        const Box b = make_box(px, py, ct, st);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { xl[2 * k] = b.x[k]; xl[2 * k + 1] = b.y[k]; }
+        xl[8] = x1; xl[9] = y1; xl[10] = x2; xl[11] = y2;
+    }
+    bool hit = false;
+#pragma unroll 1
+    for (int k = 0; k < 4 && !hit; k++) {
+        const int k2 = (k + 1) & 3;
+        const double p1x = xl[2 * k], p1y = xl[2 * k + 1], p2x = xl[2 * k2], p2y = xl[2 * k2 + 1];
+        double minq = fmin(x1, x2), maxq = fmax(x1, x2), minp = fmin(p1x, p2x), maxp = fmax(p1x, p2x);
+        if (minp > maxq || maxp < minq) continue;
+        minq = fmin(y1, y2); maxq = fmax(y1, y2); minp = fmin(p1y, p2y); maxp = fmax(p1y, p2y);
+        if (minp > maxq || maxp < minq) continue;
+        // the four orientations of computeIntersect: (p1,p2,q1) (p1,p2,q2) (q1,q2,p1) (q1,q2,p2); points p1 p2 q1 q2 = 0..3
+        int sgn = 0;                                       // two bits per orientation: sign + 1
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            const int ia = j < 2 ? 0 : 2, ic = j < 2 ? 2 + j : j - 2;
+            double P[3][2];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int idx = q == 0 ? ia : (q == 1 ? ia + 1 : ic);             // point index 0..3
+                const int w = idx == 0 ? 2 * k : (idx == 1 ? 2 * k2 : (idx == 2 ? 8 : 10));
+                P[q][0] = xl[w]; P[q][1] = xl[w + 1];
+            }
+            sgn |= (orient_robust_lds(P[0][0], P[0][1], P[1][0], P[1][1], P[2][0], P[2][1], xl + 12) + 1) << (2 * j);
+        }
+        const int Pq1 = (sgn & 3) - 1, Pq2 = ((sgn >> 2) & 3) - 1, Qp1 = ((sgn >> 4) & 3) - 1, Qp2 = ((sgn >> 6) & 3) - 1;
+        if ((Pq1 > 0 && Pq2 > 0) || (Pq1 < 0 && Pq2 < 0)) continue;
+        if ((Qp1 > 0 && Qp2 > 0) || (Qp1 < 0 && Qp2 < 0)) continue;
+        hit = true;
+    }
+    return hit;
 }
 
 // XCD-aware block -> scene map.  Workgroup b runs on XCD b % 8 (8 XCDs, each with its own L2 and 32 CUs).  With

@@ -65,6 +65,15 @@ struct hope_env {
     std::vector<uint8_t> slot_cls_host;          // draw / launch class of every scene slot (0: <= 32 obstacles, 1: larger lots)
     uint8_t* slot_cls = nullptr;                 // the same on the device
     double* rs_rec = nullptr;
+    uint8_t* active_snap = nullptr; // [n] the caller's `active` mask as the motion launch saw it (read by k_rs_compact, HOPE_DEFER_RS)
+    // StepCold (rarely used kernel parameters) in device memory: a ring of immutable versions, uploaded stream-ordered on change
+    static constexpr int COLD_RING = 8;
+    StepCold* cold_dev = nullptr;   // [COLD_RING]
+    StepCold* cold_host = nullptr;  // [COLD_RING] pinned
+    hipEvent_t cold_ev[COLD_RING] = {};
+    int cold_idx = -1;
+    StepCold cold_last;
+    uint64_t pool_generation = 0;   // bumped by every change of what a draw can return (pool commit / upload, Dragon-Lake cases)
     uint64_t redraw_seed = 0;       // HOPE_AUTO_REDRAW
     float4* obb = nullptr;          // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
     // staging for set_scenes
@@ -118,9 +127,9 @@ struct hope_env {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     struct GraphKey {
-        const void* actions; const uint8_t* active; uint32_t stages; int has_action; hope_step_out out;
+        const void* actions; const uint8_t* active; uint32_t stages; int has_action; hope_step_out out; const StepCold* cold;
         bool operator==(const GraphKey& o) const {
-            return actions == o.actions && active == o.active && stages == o.stages && has_action == o.has_action &&
+            return actions == o.actions && active == o.active && stages == o.stages && has_action == o.has_action && cold == o.cold &&
                    memcmp(&out, &o.out, sizeof(out)) == 0;
         }
     };
@@ -489,6 +498,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->episode, N * sizeof(uint32_t));
     ALLOC(h->pool_overflow, sizeof(int32_t));
     ALLOC(h->slot_cls, N);
+    ALLOC(h->active_snap, N);
+    ALLOC(h->cold_dev, hope_env::COLD_RING * sizeof(StepCold));
     if (flags & HOPE_F_IMAGE) {
         ALLOC(h->traj, N * BEV_TRAJ_LEN * 3 * sizeof(double));
         ALLOC(h->traj_len, N * sizeof(int32_t));
@@ -519,6 +530,10 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
     HIPCHK(hipMemset(h->pool_overflow, 0, sizeof(int32_t)));
     HIPCHK(hipMemset(h->slot_cls, 0, N));
+    HIPCHK(hipMemset(h->active_snap, 1, N));
+    HIPCHK(hipHostMalloc((void**)&h->cold_host, hope_env::COLD_RING * sizeof(StepCold)));
+    for (int i = 0; i < hope_env::COLD_RING; i++) HIPCHK(hipEventCreateWithFlags(&h->cold_ev[i], hipEventDisableTiming));
+    memset(&h->cold_last, 0, sizeof(h->cold_last));
     if (getenv("HOPE_DEBUG_PTRS")) {
         fprintf(stderr, "hope_env %p: verts %p obb %p scene_c %p state %p kin %p post %p rs_rec %p rs_list %p cls0 %p cls1 %p", (void*)h, (void*)h->verts, (void*)h->obb, (void*)h->scene_c,
                 (void*)h->state, (void*)h->kin, (void*)h->post, (void*)h->rs_rec, (void*)h->rs_list, (void*)h->cls_list[0], (void*)h->cls_list[1]);
@@ -578,11 +593,13 @@ int hope_env_destroy(hope_env_t* h) {
     }
     if (h->gstream) hipStreamDestroy(h->gstream);
     if (h->pool_stream) hipStreamDestroy(h->pool_stream);
+    for (hipEvent_t e : h->cold_ev) if (e) hipEventDestroy(e);
+    if (h->cold_host) hipHostFree(h->cold_host);
     for (hipEvent_t e : {h->ev_pool_ready, h->ev_pool_copied, h->ev_last_step}) if (e) hipEventDestroy(e);
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->obb, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -722,22 +739,44 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     return HOPE_OK;
 }
 
+// The rarely used parameters of the step kernel (StepCold) live in device memory: when their content differs from the version
+// uploaded last, the next ring slot is filled and copied on the caller's stream -- ahead of every launch of the step, whose chains
+// fork from that stream.  A slot is immutable while launches may read it: it comes round again after COLD_RING changes, and its
+// event (the copy that last filled it) is waited for before the pinned source is rewritten.
+static int sync_cold(hope_env_t* h, hipStream_t s) {
+    StepCold c;
+    memset(&c, 0, sizeof(c));
+    c.traj = h->traj; c.traj_len = h->traj_len; c.traj_valid = h->traj_valid; c.layer_valid = h->layer_valid;
+    c.pool_verts = h->pool_verts; c.pool_c = h->pool_c; c.pool_nobst = h->pool_nobst;
+    c.pool_cls[0] = h->pool_cls[0]; c.pool_cls[1] = h->pool_cls[1]; c.pool_cls_n[0] = h->pool_cls_n[0]; c.pool_cls_n[1] = h->pool_cls_n[1];
+    c.cur_pool = h->cur_pool; c.episode = h->episode; c.redraw_seed = h->redraw_seed;
+    c.dlp = h->dlp; c.pool_overflow = h->pool_overflow; c.slot_cls = h->slot_cls;
+    if (h->cold_idx >= 0 && memcmp(&c, &h->cold_last, sizeof(c)) == 0) return HOPE_OK;
+    const int slot = (h->cold_idx + 1) % hope_env::COLD_RING;
+    HIPCHK(hipEventSynchronize(h->cold_ev[slot]));
+    memcpy(&h->cold_host[slot], &c, sizeof(c));
+    HIPCHK(hipMemcpyAsync(h->cold_dev + slot, h->cold_host + slot, sizeof(c), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(h->cold_ev[slot], s));
+    h->cold_idx = slot;
+    memcpy(&h->cold_last, &c, sizeof(c));
+    return HOPE_OK;
+}
+
 // Enqueues the launches of one step on `s`.  With a side stream `s2` (HOPE_F_OVERLAP) the two tile classes run
 // concurrently: fork -> { k_kinematics, k_env_step, k_rs_compact, k_rs_words, k_rs_validate of class 1 | of class 0 } -> join -> image.  Every class kernel is latency-bound per wave, so at
 // <= 16 k scenes per GPU (BASELINE config 4: 8 192) one class alone cannot fill the 1024 SIMDs.
 static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages, const hope_step_out* out,
                         hipStream_t s, bool overlap, int has_action, LaunchTimer* tm) {
     StepParams p;
+    memset(&p, 0, sizeof(p));
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
+    p.hflags = h->traj ? STEP_HF_TRAJ : 0;
     p.verts = h->verts; p.obb = h->obb; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
-    p.actions = actions; p.active = active; p.kin = h->kin; p.post = h->post;
-    p.traj = h->traj; p.traj_len = h->traj_len; p.traj_valid = h->traj_valid; p.layer_valid = h->layer_valid;
+    p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.post = h->post;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
-    p.out = *out;
-    p.pool_verts = h->pool_verts; p.pool_c = h->pool_c; p.pool_nobst = h->pool_nobst;
-    p.pool_cls[0] = h->pool_cls[0]; p.pool_cls[1] = h->pool_cls[1]; p.pool_cls_n[0] = h->pool_cls_n[0]; p.pool_cls_n[1] = h->pool_cls_n[1];
-    p.cur_pool = h->cur_pool; p.episode = h->episode; p.redraw_seed = h->redraw_seed;
-    p.dlp = h->dlp; p.pool_overflow = h->pool_overflow; p.slot_cls = h->slot_cls;
+    p.lidar = out->lidar; p.action_mask = out->action_mask;
+    p.cold = h->cold_dev + h->cold_idx;                     // (sync_cold ran on the caller's stream before any launch of this step)
+    const uint8_t* active_rs = active ? h->active_snap : nullptr;   // what the Reeds-Shepp chain reads instead of the caller's mask
     const bool of64 = h->flags & HOPE_F_OBS_F64, af64 = h->flags & HOPE_F_ACTION_F64;
     dim3 block(WAVE);
 
@@ -803,7 +842,6 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.scene_list = h->cls_list[c] + ch.a;
         p.n_list = ch.b - ch.a;
-        p.rs_flag = h->rs_flag;
         p.rs_count_zero = want_rs ? counter : nullptr;
         if (order_mode >= 2 && fork && n_chain == 2 && i == 1 && (split || (stages & HOPE_STAGE_IMG)))
             HIPCHK(hipStreamWaitEvent(sc, h->ev_step[0], 0));   // staggered: behind the first chain's motion launch
@@ -827,8 +865,8 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         {                                                       // scalar outputs, reward / target arithmetic: one lane per scene
             dim3 pg((p.n_list + WAVE - 1) / WAVE);
             if (tm) tm->begin(HOPE_K_POST, so);
-            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
-            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, p.out);
+            if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, *out);
+            else hipLaunchKernelGGL((k_post<float>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, *out);
             if (tm) tm->end(so);
         }
         if (split) {
@@ -842,9 +880,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
         {
             const dim3 cg((p.n_list + COMPACT_THREADS - 1) / COMPACT_THREADS);
-            if (of64) hipLaunchKernelGGL(k_rs_compact<double>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active, qlist,
+            if (of64) hipLaunchKernelGGL(k_rs_compact<double>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
                                          counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
-            else hipLaunchKernelGGL(k_rs_compact<float>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active, qlist,
+            else hipLaunchKernelGGL(k_rs_compact<float>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
                                     counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
         }
         if (tm) tm->end(sc);
@@ -939,6 +977,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         HIPCHK(hipStreamWaitEvent(s, h->ev_pool_ready, 0));
         h->pool_wait_pending = false;
     }
+    { int rcc = sync_cold(h, s); if (rcc != HOPE_OK) return rcc; }
     struct LastStep {                                       // (the next pool upload must not overwrite a set this step still reads)
         hope_env_t* h; hipStream_t s;
         ~LastStep() { if (h->pactive >= 0 && h->ev_last_step) hipEventRecord(h->ev_last_step, s); }
@@ -946,7 +985,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     if (h->flags & HOPE_F_GRAPH) {
         // The caller's stream may be the null stream, which cannot be captured: the graph lives on a library stream that
         // is ordered after / before the caller's stream with two events.
-        hope_env::GraphKey key{actions, active, stages, has_action, *out};
+        hope_env::GraphKey key{actions, active, stages, has_action, *out, h->cold_dev + h->cold_idx};
         hope_env::GraphEntry* hit = nullptr;
         for (auto& g : h->graphs) if (g.key == key) { hit = &g; break; }
         if (!hit) {
@@ -1086,6 +1125,23 @@ int hope_env_pool_staging(hope_env_t* h, int n_pool, double** start, double** de
     return HOPE_OK;
 }
 
+int hope_env_pool_staging_ready(hope_env_t* h) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_pool_staging_ready: null handle");
+    if (!h->pstage.busy) return 1;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    const hipError_t e = hipEventQuery(h->ev_pool_copied);
+    if (e == hipSuccess) { h->pstage.busy = false; return 1; }
+    if (e == hipErrorNotReady) return 0;
+    return fail(HOPE_EHIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+}
+
+int hope_env_pool_generation(hope_env_t* h, uint64_t* generation) {
+    if (!h || !generation) return fail(HOPE_EINVAL, "hope_env_pool_generation: null argument");
+    *generation = h->pool_generation;
+    return HOPE_OK;
+}
+
 int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     // (no join of an unjoined Reeds-Shepp chain here: only the motion launches read the pool, and ev_last_step covers them)
     if (!h || n_pool <= 0) return fail(HOPE_EINVAL, "hope_env_commit_pool: bad argument");
@@ -1099,6 +1155,8 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     if ((int)(l0.size() + l1.size()) > h->pstage.cap + 4096) return fail(HOPE_EINVAL, "hope_env_commit_pool: too many Dragon-Lake cases for the list staging");
     const int t = h->pactive < 0 ? 0 : 1 - h->pactive;
     hope_env::PoolSet& ps = h->pset[t];
+    // two commits without a hope_env_pool_staging call in between: the previous upload may still be reading the pinned arrays
+    if (h->pstage.busy) { HIPCHK(hipEventSynchronize(h->ev_pool_copied)); h->pstage.busy = false; }
     int rc = pool_set_reserve(h, ps, n_pool, (int)std::max(l0.size(), l1.size()) + 1);
     if (rc != HOPE_OK) return rc;
     if (3 * 32 * n_pool / 8 > h->pstage_dev_cap) {           // start | dest | bbox: 24 + 24 + 32 bytes per entry
@@ -1137,6 +1195,7 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     h->pool_nobst_host.assign(h->pstage.nobst, h->pstage.nobst + n_pool);
     h->pactive = t;
     h->pool_wait_pending = true;
+    h->pool_generation++;
     (void)stream;
     drop_graphs(h);                                         // the pool pointers are kernel arguments of the captured launches
     return HOPE_OK;
@@ -1177,6 +1236,7 @@ static int refresh_pool_lists_sync(hope_env_t* h) {
     if (!l1.empty()) HIPCHK(hipMemcpy(ps.list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
     h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
+    h->pool_generation++;
     drop_graphs(h);
     return HOPE_OK;
 }
@@ -1217,14 +1277,16 @@ int hope_env_set_draw_class(hope_env_t* h, const int32_t* scene_ids, int n, cons
     { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || n < 0 || (n > 0 && (!scene_ids || !cls))) return fail(HOPE_EINVAL, "hope_env_set_draw_class: null argument");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_set_draw_class: hope_env_set_scenes has not been called");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    // the obstacle counts as they are NOW: device-side draws (HOPE_AUTO_REDRAW, hope_env_redraw) change them behind the host copy
+    HIPCHK(hipMemcpy(h->n_obst_host.data(), h->n_obst, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int k = 0; k < n; k++) {
         if (scene_ids[k] < 0 || scene_ids[k] >= h->n) return fail(HOPE_EINVAL, "hope_env_set_draw_class: scene id out of range");
         if (!cls[k] && h->n_obst_host[scene_ids[k]] > SMALL_TILE)
             return fail(HOPE_EINVAL, "hope_env_set_draw_class: a scene with more than 32 obstacles cannot join the small class");
     }
-    DeviceGuard guard(h->device);
-    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
-    HIPCHK(hipDeviceSynchronize());
     for (int k = 0; k < n; k++) h->slot_cls_host[scene_ids[k]] = (cls[k] && h->max_obst > SMALL_TILE) ? 1 : 0;
     int rc = rebuild_class_lists(h);
     if (rc != HOPE_OK) return rc;
@@ -1305,10 +1367,15 @@ int hope_env_download_pool_state(hope_env_t* h, int32_t* pool_index, uint32_t* e
     return HOPE_OK;
 }
 
-int hope_env_restore_maps(hope_env_t* h, const uint8_t* drawn /* host [N]: the scene held a drawn map */, const uint32_t* episode, uint64_t seed) {
+int hope_env_restore_maps(hope_env_t* h, const uint8_t* drawn /* host [N]: the scene held a drawn map */, const uint32_t* episode, uint64_t seed,
+                          uint64_t pool_generation) {
     { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || !drawn || !episode) return fail(HOPE_EINVAL, "hope_env_restore_maps: null argument");
     if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_restore_maps: no scene pool");
+    if (pool_generation != 0 && pool_generation != h->pool_generation)
+        return fail(HOPE_ESTATE, "hope_env_restore_maps: the scene pool has been replaced since the snapshot (pool generation " +
+                                 std::to_string(h->pool_generation) + " now, " + std::to_string(pool_generation) + " in the snapshot): repeating the draws "
+                                 "would give other maps -- snapshot refreshed runs with hope_env_download_scenes / hope_env_set_scenes");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     HIPCHK(hipDeviceSynchronize());

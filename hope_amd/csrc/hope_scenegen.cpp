@@ -9,6 +9,8 @@
 // The reference delegates `distance` / `intersects` to shapely; here they are the boundary-only ring predicates of
 // hope_amd/scenes.py (rings_intersect / rings_distance), restated.
 #include <math.h>
+#include <sched.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -236,21 +238,37 @@ bool one_case(int level, bool bay, Rng& rng, Case& out) {
 
 int level_index(int level) { return level < 0 || level > 2 ? -1 : level; }
 
+// Default fan-out: HOPE_HOST_THREADS if set, else the CPUs this process may run on (sched_getaffinity) -- NOT every hardware
+// thread of the node: with one process per GPU each rank pins itself to its share of the cores (hope_amd.dist.pin_rank_to_cores),
+// and 8 ranks x hardware_concurrency() threads would oversubscribe the host eightfold.
+int default_threads() {
+    if (const char* e = getenv("HOPE_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return c; }
+    const int hc = (int)std::thread::hardware_concurrency();
+    return hc > 0 ? hc : 1;
+}
+
 }  // namespace
 
 extern "C" {
+
+// what hope_scenegen_generate uses when n_threads <= 0 (reported by bench.py next to the rank count)
+int hope_scenegen_default_threads(void) { return default_threads(); }
 
 // n scenes of `level` (0 Normal, 1 Complex, 2 Extrem) as ParkingMapNormal.reset draws them (parking_map_normal.py:474-494: bay
 // with probability 1/2 for Normal / Complex, parallel otherwise; bbox = floor / ceil of min / max(start, dest) -/+ 10 m).
 // bay_mode: -1 as the reference, 0 parallel only, 1 bay only (the test hook of the distribution tests).  Outputs (host): start
 // [n][3], dest [n][3], bbox [n][4], verts [n][max_obstacles][4][2] (unused slots untouched), n_obst [n], case_id [n] (0 bay,
-// 1 parallel; may be null).  Scene i depends only on (seed, first_index + i).  n_threads <= 0: all hardware threads.
+// 1 parallel; may be null).  Scene i depends only on (seed, first_index + i).  n_threads <= 0: HOPE_HOST_THREADS, else the CPUs in
+// this process's affinity mask (a rank's share of the node once hope_amd.dist.pin_rank_to_cores ran).
 // Returns 0, HOPE_EINVAL, or -100 - i if scene i had more than max_obstacles obstacles (cannot happen for max_obstacles >= 18).
 int hope_scenegen_generate(int level, int bay_mode, int n, uint64_t seed, int64_t first_index, int max_obstacles, double* start,
                            double* dest, double* bbox, double* verts, int32_t* n_obst, int32_t* case_id, int n_threads) {
     if (level_index(level) < 0 || n < 0 || max_obstacles <= 0 || !start || !dest || !bbox || !verts || !n_obst) return HOPE_EINVAL;
     if (n == 0) return HOPE_OK;
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : default_threads();
     nt = std::max(1, std::min(nt, (n + 31) / 32));
     std::atomic<int> next{0}, err{0};
     auto work = [&]() {

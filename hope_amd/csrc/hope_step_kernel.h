@@ -119,31 +119,15 @@ __device__ __forceinline__ int draw_dlp_case(const DlpCases& D, int cs, uint64_t
     return cnt;
 }
 
-struct StepParams {
-    int n, max_obst;          // max_obst = HBM tile stride (obstacle slots per scene)
-    int tile_cap;             // LDS tile capacity of THIS launch (obstacles)
-    const int32_t* scene_list; // scenes of this launch's tile class (dense launch: grid = n_list)
-    int n_list;
-    uint32_t stages;
-    int has_action;
-    const double* verts;      // [n][max_obst][4][2]
-    const float4* obb;        // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
-    const int32_t* n_obst;    // [n]
-    const double* scene_c;    // [n][SC_WORDS]
-    double* state;            // [n][ST_WORDS]
-    int32_t* tstep;           // [n]
-    const void* actions;      // [n][2]
-    double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
+// What the step kernel touches rarely (episode turnover, image bookkeeping): read through ONE pointer at the point of use.
+// As by-value kernel arguments these ~25 pointers were all loaded at kernel entry and stayed live in SGPRs to their (rare) use:
+// 106 SGPRs, 68 of them spilled to VGPR lanes, in a kernel that sits on the 128-VGPR occupancy step.  The record lives in
+// device memory (a small ring in the handle, re-uploaded stream-ordered when its content changes: a pool commit, a new seed).
+struct StepCold {
     double* traj;             // HOPE_F_IMAGE: [n][20][3] ring of vehicle.trajectory (entry e in slot e % 20), else null
     int32_t* traj_len;        // HOPE_F_IMAGE: [n] len(vehicle.trajectory)
     int32_t* traj_valid;      // HOPE_F_IMAGE: [n] span-table watermark of the image kernels (0 after a reset)
     int32_t* layer_valid;     // HOPE_F_IMAGE: [n] the static image layer matches the scene's map (0 after a new map)
-    const uint8_t* active;    // [n] or null
-    const double* tab;        // prefix-max mask table [NL][NITER][NACT]
-    const double* pmax;       // [NL] max over (a,k) of tab
-    const double* hull_base;  // [NBEAM]
-    const double* beam_ab;    // [NBEAM][2]
-    hope_step_out out;
     // HOPE_AUTO_REDRAW: the device-resident scene pool (hope_env_set_pool), or null pointers
     const double* pool_verts; // [pool_n][max_obst][8]
     const double* pool_c;     // [pool_n][SC_WORDS]
@@ -156,8 +140,36 @@ struct StepParams {
     DlpCases dlp;             // HOPE_AUTO_REDRAW: Dragon-Lake-Parking cases drawn on the device (hope_env_set_dlp_cases), or n_cases = 0
     int32_t* pool_overflow;   // [1] draws whose culled obstacle set exceeded max_obst (truncated): must stay 0
     const uint8_t* slot_cls;  // [n] draw class of every scene slot (0: lots of <= 32 obstacles, 1: larger)
+};
+
+constexpr uint32_t STEP_HF_TRAJ = 1;   // StepParams::hflags: the handle keeps vehicle.trajectory (HOPE_F_IMAGE)
+
+struct StepParams {
+    int n, max_obst;          // max_obst = HBM tile stride (obstacle slots per scene)
+    int tile_cap;             // LDS tile capacity of THIS launch (obstacles)
+    const int32_t* scene_list; // scenes of this launch's tile class (dense launch: grid = n_list)
+    int n_list;
+    uint32_t stages;
+    int has_action;
+    uint32_t hflags;          // STEP_HF_*
+    const double* verts;      // [n][max_obst][4][2]
+    const float4* obb;        // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
+    const int32_t* n_obst;    // [n]
+    const double* scene_c;    // [n][SC_WORDS]
+    double* state;            // [n][ST_WORDS]
+    int32_t* tstep;           // [n]
+    double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
+    const uint8_t* active;    // [n] or null (the caller's mask: only read by launches the caller's stream is ordered after)
+    uint8_t* active_out;      // [n] or null: the motion launch snapshots the mask here for the Reeds-Shepp chain (k_rs_compact), which
+                              //   with HOPE_DEFER_RS runs after the caller's stream has been released
+    const double* tab;        // prefix-max mask table [NL][NITER][NACT]
+    const double* pmax;       // [NL] max over (a,k) of tab
+    const double* hull_base;  // [NBEAM]
+    const double* beam_ab;    // [NBEAM][2]
+    void* lidar;              // hope_step_out.lidar / .action_mask (the other outputs are written by k_post / the Reeds-Shepp kernels)
+    void* action_mask;
+    const StepCold* cold;     // device memory
     double* post;             // [n][POST_WORDS] per-scene hand-over to k_post (reward / target arithmetic, lane = scene)
-    uint8_t* rs_flag;         // [n] 1: the scene passes the Reeds-Shepp gate this step (k_rs_compact builds the queues)
     int32_t* rs_count_zero;   // this tile class's RS queue counter, cleared here for the k_rs_compact that follows; or null
 };
 
@@ -167,7 +179,8 @@ struct StepParams {
 //     lidar     : best[128] u64 + queue[384] i32
 //     mask      : x[121]
 constexpr int LDS_TX = 0, LDS_SH = 0, LDS_X = 0, LDS_HB = 320, LDS_CB = 330, LDS_SB = 340, LDS_PX = 350,
-              LDS_PY = 360, LDS_DBOX = 370, LDS_W2 = 378, LDS_KEEP = 388, LDS_SCRATCH_WORDS = 388;
+              LDS_PY = 360, LDS_DBOX = 370, LDS_W2 = 378, LDS_KEEP = 388, LDS_SCRATCH_WORDS = 388,
+              LDS_ROBUST = 96;   // [ROBUST_LDS_WORDS] in region A, behind sh[64] and the turnover's constant record [64..88)
 constexpr int KIN_WORDS = 56;   // h[10] cos[10] sin[10] x[10] y[10], [50] = int2(arrival-possible bits of the ten poses, 0), [51] pad,
                                 // [52..55] = box (xmin, xmax, ymin, ymax) around the hulls of the start pose and the ten poses
 // k_env_step -> k_post record: previous pose, final pose of the finished step, overlap area, (status | t << 8 | flags << 24)
@@ -182,6 +195,7 @@ constexpr int SMALL_TILE = 32;   // scenes with <= 32 obstacles run in a launch 
 __device__ __forceinline__ double ring_area_signed_lds(const double* px, const double* py, int n) {
     if (n < 3) return 0.0;
     double sum = 0.0, x0 = px[0];
+#pragma unroll 1
     for (int i = 1; i < n; i++) {
         double x = px[i] - x0;
         int ip = (i + 1 == n) ? 0 : i + 1;
@@ -192,17 +206,21 @@ __device__ __forceinline__ double ring_area_signed_lds(const double* px, const d
 
 // Polygon(A).intersection(Polygon(B)).area for convex CCW quads: Sutherland-Hodgman + shoelace.
 // Runs on ONE lane with LDS scratch sh[64] (two 8-vertex ping-pong buffers of x and y); quad A is already in
-// sh[0..3] (x) and sh[16..19] (y).  Out of line (it is long and rare), so every argument is an LDS pointer: a Box
-// passed by reference would have to live in scratch memory, and those stores were most of the kernel's HBM writes.
-__device__ __noinline__ double quad_intersection_area_lane0(const double* B /*8 words x,y*/, double* sh) {
+// sh[0..3] (x) and sh[16..19] (y).  Every argument is an LDS pointer (a Box passed by reference to an out-of-line function had
+// to live in scratch memory: those stores were most of the round-1 kernel's HBM writes).  Inlined with ROLLED loops since
+// round 4: a call in the middle of the step kernel made the register allocator spill what was live across it, and the kernel
+// is to run without any scratch memory.
+__device__ __forceinline__ double quad_intersection_area_lane0(const double* B /*8 words x,y*/, double* sh) {
     double* ax = sh;      double* ay = sh + 16;
     double* bx = sh + 32; double* by = sh + 48;
     int n = 4;
+#pragma unroll 1
     for (int e = 0; e < 4 && n > 0; e++) {
         double c1x = B[2 * e], c1y = B[2 * e + 1];
         double c2x = B[2 * ((e + 1) & 3)], c2y = B[2 * ((e + 1) & 3) + 1];
         double ex = c2x - c1x, ey = c2y - c1y;
         int m = 0;
+#pragma unroll 1
         for (int i = 0; i < n; i++) {
             int i2 = (i + 1 == n) ? 0 : i + 1;
             double sx = ax[i], sy = ay[i], tx = ax[i2], ty = ay[i2];
@@ -270,7 +288,8 @@ __device__ __noinline__ double quad_intersection_area_private(const double* B /*
 
 // |hull ∩ dest| with an exact quick reject: both boxes lie inside discs of radius rho about their
 // centres; disjoint discs -> GEOS returns an empty intersection, area 0.0.
-__device__ __forceinline__ double overlap_area(const Box& box, const double* dbox_lds, double* sh, int lane) {
+__device__ __forceinline__ double overlap_area(double px, double py, double ct, double st, const double* dbox_lds, double* sh, int lane) {
+    const Box box = make_box(px, py, ct, st);
     double cx = 0.5 * (box.x[0] + box.x[2]), cy = 0.5 * (box.y[0] + box.y[2]);
     double dx = 0.5 * (dbox_lds[0] + dbox_lds[4]) - cx, dy = 0.5 * (dbox_lds[1] + dbox_lds[5]) - cy;
     const double reach = 5.2;   // 2 * half-diagonal (2.5378) + slack
@@ -368,30 +387,48 @@ __device__ __forceinline__ int stage_near(const float4* obb, const double2* src,
 }
 
 // _detect_collision (car_parking_base.py:153-158): any hull edge x any obstacle edge share a point.
-// Edges are taken from the obstacles in list[0..n_list).
-__device__ __forceinline__ bool detect_collision(const Box& b, const double* tile, const int* list, int n_list, int lane) {
+// Edges are taken from the obstacles in list[0..n_list).  The hull is that of pose (px, py, cos, sin).  Fast path: the
+// orientation filter (segments_intersect_fast); a lane whose pair it leaves undecided -- and only if no lane has a certain hit --
+// takes the robust path, one lane at a time, with the LDS work area xl[ROBUST_LDS_WORDS].
+__device__ __forceinline__ bool detect_collision(double px, double py, double ct, double st, const double* tile, const int* list,
+                                                 int n_list, double* xl, int lane) {
     const int n_slots = 4 * n_list;
+    const Box b = make_box(px, py, ct, st);
     double hminx = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3]));
     double hmaxx = fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3]));
     double hminy = fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3]));
     double hmaxy = fmax(fmax(b.y[0], b.y[1]), fmax(b.y[2], b.y[3]));
+#pragma unroll 1
     for (int base = 0; base < n_slots; base += WAVE) {
         int e = base + lane;
-        bool hit = false;
+        bool hit = false, und = false;
+        double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
         if (e < n_slots) {
             const double* v = tile + 8 * list[e >> 2];
             int j = e & 3, j2 = (e + 1) & 3;
-            double x1 = v[2 * j], y1 = v[2 * j + 1], x2 = v[2 * j2], y2 = v[2 * j2 + 1];
+            x1 = v[2 * j]; y1 = v[2 * j + 1]; x2 = v[2 * j2]; y2 = v[2 * j2 + 1];
             // envelope of the obstacle edge vs envelope of the hull: necessary for any segment pair
             if (!(fmin(x1, x2) > hmaxx || fmax(x1, x2) < hminx || fmin(y1, y2) > hmaxy || fmax(y1, y2) < hminy)) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     int k2 = (k + 1) & 3;
-                    hit = hit || segments_intersect(b.x[k], b.y[k], b.x[k2], b.y[k2], x1, y1, x2, y2);
+                    const int r = segments_intersect_fast(b.x[k], b.y[k], b.x[k2], b.y[k2], x1, y1, x2, y2);
+                    hit = hit || r == 1;
+                    und = und || r == 2;
                 }
             }
         }
         if (__any(hit)) return true;
+        unsigned long long um = __ballot(und);
+        if (um) {
+            bool hit2 = false;
+            while (um) {
+                const int l = __ffsll((long long)um) - 1;
+                um &= um - 1;
+                if (lane == l) hit2 = hull_edge_intersect_robust(px, py, ct, st, x1, y1, x2, y2, xl);
+            }
+            if (__any(hit2)) return true;
+        }
     }
     return false;
 }
@@ -592,7 +629,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     ST_T0();
     if (PART != 2 && p.rs_count_zero && blockIdx.x == 0 && threadIdx.x == 0) p.rs_count_zero[0] = 0;   // this class's queue length
     const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
-    if (p.active && !p.active[scene]) return;
+    {
+        const bool act = !(p.active && !p.active[scene]);
+        if (PART != 2 && p.active_out && lane == 0) p.active_out[scene] = act;
+        if (!act) return;
+    }
 
     int n_obst = p.n_obst[scene];
     // the sub-step poses of this step (k_kinematics), requested together with everything else the scene needs
@@ -613,9 +654,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         for (int v = lane; v < n_slots; v += WAVE) dst[v] = src[v];   // 16 B/lane, coalesced
     }
     double* dbox = scr + LDS_DBOX;
-    if (lane < 8) dbox[lane] = sc[SC_DBOX + lane];
-    const double destx = sc[SC_DEST], desty = sc[SC_DEST + 1], desth = sc[SC_DEST + 2];
-    double dest_area = sc[SC_DAREA];
+    double* xl = scr + LDS_ROBUST;                       // work area of the robust collision path (one lane at a time)
+    if (PART != 2 && lane < 8) dbox[lane] = sc[SC_DBOX + lane];
+    double dest_area = PART != 2 ? sc[SC_DAREA] : 0.0;
     double* st = p.state + (size_t)scene * ST_WORDS;
     double x = st[0], y = st[1], h = st[2], accum = st[3];
     const double prev_x = x, prev_y = y, prev_h = h;      // prev_state (car_parking_base.py:255)
@@ -681,7 +722,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 const int kk = kv ? k : NUM_STEP - 1;
                 const double qx = scr[LDS_PX + kk], qy = scr[LDS_PY + kk], qc = scr[LDS_CB + kk], qs = scr[LDS_SB + kk];
                 const bool ap = kv && e == 0 && ((apmask >> kk) & 1);
-                bool hit = false;
+                bool hit = false, und = false;
                 if (kv && has_edge) {
                     const Box b = make_box(qx, qy, qc, qs);
                     const double hminx = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3]));
@@ -692,8 +733,18 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             const int c2 = (c + 1) & 3;
-                            hit = hit || segments_intersect(b.x[c], b.y[c], b.x[c2], b.y[c2], ex1, ey1, ex2, ey2);
+                            const int r = segments_intersect_fast(b.x[c], b.y[c], b.x[c2], b.y[c2], ex1, ey1, ex2, ey2);
+                            hit = hit || r == 1;
+                            und = und || r == 2;
                         }
+                    }
+                }
+                {   // pairs the orientation filter left open (practically never): the robust path, one lane at a time
+                    unsigned long long um = __ballot(und && !hit);
+                    while (um) {
+                        const int l = __ffsll((long long)um) - 1;
+                        um &= um - 1;
+                        if (lane == l) hit = hull_edge_intersect_robust(qx, qy, qc, qs, ex1, ey1, ex2, ey2, xl);
                     }
                 }
                 const unsigned long long hm = __ballot(hit), am = __ballot(ap);
@@ -702,8 +753,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                         const unsigned long long gm = gmask0 << (gg * S);
                         const int kq = k0 + gg;
                         if (am & gm) {                                                   // _check_arrived :164-170
-                            const Box bq = make_box(scr[LDS_PX + kq], scr[LDS_PY + kq], scr[LDS_CB + kq], scr[LDS_SB + kq]);
-                            ua = overlap_area(bq, dbox, scr + LDS_SH, lane);
+                            ua = overlap_area(scr[LDS_PX + kq], scr[LDS_PY + kq], scr[LDS_CB + kq], scr[LDS_SB + kq], dbox, scr + LDS_SH, lane);
                             if (ua / dest_area > 0.95) { ev_k = kq; ev_arrive = true; break; }
                         }
                         if (hm & gm) { ev_k = kq; break; }                               // _detect_collision :264
@@ -713,12 +763,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         } else {
             for (int k = 0; k < NUM_STEP; k++) {
                 const double qx = scr[LDS_PX + k], qy = scr[LDS_PY + k], qc = scr[LDS_CB + k], qs = scr[LDS_SB + k];
-                const Box b = make_box(qx, qy, qc, qs);
                 if ((apmask >> k) & 1) {                                                  // _check_arrived :164-170
-                    ua = overlap_area(b, dbox, scr + LDS_SH, lane);
+                    ua = overlap_area(qx, qy, qc, qs, dbox, scr + LDS_SH, lane);
                     if (ua / dest_area > 0.95) { ev_k = k; ev_arrive = true; break; }
                 }
-                if (detect_collision(b, tile, nlist, n_near, lane)) { ev_k = k; break; }  // _detect_collision :264
+                if (detect_collision(qx, qy, qc, qs, tile, nlist, n_near, xl, lane)) { ev_k = k; break; }  // _detect_collision :264
             }
         }
         // final pose of the motion: the arrival pose, the pose BEFORE the colliding sub-step (retreat :264-271), or
@@ -738,7 +787,6 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     t += 1;                                                             // :277
 
     if (!have_cs) hm_sincos(h, &sn, &ct);
-    Box box = make_box(x, y, ct, sn);
 
     ST_T(1);
     // ---- status (:279-282, _check_status :175-184) -------------------------------------------------
@@ -747,14 +795,14 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         if (arrive) status = HOPE_STATUS_ARRIVED;
         else {
             const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
-            bool coll = known_free ? false : detect_collision(box, tile, nlist, n_near, lane);
+            bool coll = known_free ? false : detect_collision(x, y, ct, sn, tile, nlist, n_near, xl, lane);
             if (coll) status = HOPE_STATUS_COLLIDED;
             else if (x > xmax || x < xmin || y > ymax || y < ymin) status = HOPE_STATUS_OUTBOUND;
             else {
                 bool arrived = false;
                 if (have_ua) arrived = ua / dest_area > 0.95;
                 else if (kf_pose >= 0 ? ((apmask >> kf_pose) & 1) != 0 : arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {
-                    ua = overlap_area(box, dbox, scr + LDS_SH, lane);
+                    ua = overlap_area(x, y, ct, sn, dbox, scr + LDS_SH, lane);
                     have_ua = true;
                     arrived = ua / dest_area > 0.95;
                 }
@@ -780,36 +828,41 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         // picked exactly as hope_env_redraw picks it, copied into the scene's slots by this wave; the rest of the turnover
         // (and of this kernel, in the one-launch form) then works on the new scene, whose whole tile is staged in LDS
         bool redrawn = false;
-        if ((p.stages & HOPE_AUTO_REDRAW) && (p.pool_verts || p.dlp.n_cases > 0)) {
-            const int cls = p.slot_cls[scene] ? 1 : 0;                 // the slot's class, not the current map's size
-            const int cnt = p.pool_cls_n[cls];
-            if (cnt > 0) {
-                const uint32_t ep = p.episode[scene];
-                const uint64_t key = mix64(p.redraw_seed ^ mix64(((uint64_t)scene << 32) | ep));
-                const int j = p.pool_cls[cls][(int)(key % (uint64_t)cnt)];
+        if (p.stages & HOPE_AUTO_REDRAW) {
+            const StepCold* cp = p.cold;                               // (loaded here, by the few waves that turn over)
+            const int cls = cp->slot_cls[scene] ? 1 : 0;               // the slot's class, not the current map's size
+            const int cnt = cp->pool_cls_n[cls];
+            if (cnt > 0 && (cp->pool_verts || cp->dlp.n_cases > 0)) {
+                const uint32_t ep = cp->episode[scene];
+                const uint64_t key = mix64(cp->redraw_seed ^ mix64(((uint64_t)scene << 32) | ep));
+                const int j = cp->pool_cls[cls][(int)(key % (uint64_t)cnt)];
                 double2* gdst = (double2*)(const_cast<double*>(p.verts) + (size_t)scene * p.max_obst * 8);
                 float4* gobb = const_cast<float4*>(p.obb) + (size_t)scene * p.max_obst;
                 double* gsc = const_cast<double*>(p.scene_c) + (size_t)scene * SC_WORDS;
                 int nob;
                 wsync();
                 if (j >= 0) {                                           // a complete scene of the pool
-                    nob = p.pool_nobst[j];
-                    const double2* psrc = (const double2*)(p.pool_verts + (size_t)j * p.max_obst * 8);
+                    nob = cp->pool_nobst[j];
+                    const double* pv = cp->pool_verts + (size_t)j * p.max_obst * 8;
+                    const double2* psrc = (const double2*)pv;
                     double2* ldst = (double2*)tile;
                     for (int v = lane; v < 4 * nob; v += WAVE) { const double2 q2 = psrc[v]; gdst[v] = q2; ldst[v] = q2; }
-                    for (int o = lane; o < nob; o += WAVE) gobb[o] = obstacle_box(p.pool_verts + ((size_t)j * p.max_obst + o) * 8);
-                    const double* pc = p.pool_c + (size_t)j * SC_WORDS;
+                    for (int o = lane; o < nob; o += WAVE) gobb[o] = obstacle_box(pv + (size_t)o * 8);
+                    const double* pc = cp->pool_c + (size_t)j * SC_WORDS;
                     if (lane < SC_WORDS) gsc[lane] = pc[lane];
                     sc = pc;                                            // the new scene's constants, straight from the pool
                 } else {                                                // a Dragon-Lake-Parking case: drawn here (ParkingMapDLP.reset)
                     double* c24 = scr + LDS_SH + 64;                    // (region A is free between the sub-step loop and the lidar)
-                    nob = draw_dlp_case(p.dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), p.max_obst, (double*)gdst, gobb, c24, tile,
-                                        p.pool_overflow, lane);
+                    nob = draw_dlp_case(cp->dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), p.max_obst, (double*)gdst, gobb, c24, tile,
+                                        cp->pool_overflow, lane);
                     wsync();
                     if (lane < SC_WORDS) gsc[lane] = c24[lane];
                     sc = c24;
                 }
-                if (lane == 0) { const_cast<int32_t*>(p.n_obst)[scene] = nob; p.cur_pool[scene] = j; p.episode[scene] = ep + 1; if (p.layer_valid) p.layer_valid[scene] = 0; }
+                if (lane == 0) {
+                    const_cast<int32_t*>(p.n_obst)[scene] = nob; cp->cur_pool[scene] = j; cp->episode[scene] = ep + 1;
+                    if (cp->layer_valid) cp->layer_valid[scene] = 0;
+                }
                 if (lane < 8) dbox[lane] = sc[SC_DBOX + lane];
                 dest_area = sc[SC_DAREA];
                 n_obst = nob;
@@ -821,16 +874,15 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         accum = 0.0;
         t = 1;                                                          // reset: t = 0, then step() -> t = 1
         hm_sincos(h, &sn, &ct);
-        box = make_box(x, y, ct, sn);
         // the action-less step's status decides whether _get_reward runs (it only touches accum_arrive_reward)
         wsync();
         const int n_near0 = (PART == 0 || redrawn) ? build_near_list(tile, n_obst, x, y, 3.9, nlist, lane)
                                                    : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
         wsync();
         const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
-        bool cont = !detect_collision(box, tile, nlist, n_near0, lane) && !(x > xmax || x < xmin || y > ymax || y < ymin);
+        bool cont = !detect_collision(x, y, ct, sn, tile, nlist, n_near0, xl, lane) && !(x > xmax || x < xmin || y > ymax || y < ymin);
         if (cont) {
-            const double ua0 = overlap_area(box, dbox, scr + LDS_SH, lane);
+            const double ua0 = overlap_area(x, y, ct, sn, dbox, scr + LDS_SH, lane);
             if (!(ua0 / dest_area > 0.95)) {                            // not ARRIVED (and t = 1 is not OUTTIME): CONTINUE
                 const double bur = ua0 / (2 * dest_area - ua0);
                 if (!(bur < accum)) accum = bur;                        // :221-226 with accum = 0
@@ -842,16 +894,18 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (lane == 0) {
         st[0] = x; st[1] = y; st[2] = h; st[3] = accum;
         p.tstep[scene] = t;
-        if (p.traj) {
+        if (p.hflags & STEP_HF_TRAJ) {
             // vehicle.trajectory: of the sub-step states only the last kept one stays (car_parking_base.py:259-276,
             // vehicle.py:144,158); a step blocked at its first sub-step adds nothing; reset leaves [start]
-            double* tr = p.traj + (size_t)scene * 60;
-            int tl = turnover ? 0 : p.traj_len[scene];
-            if (turnover) p.traj_valid[scene] = 0;
+            const StepCold* cp = p.cold;
+            double* tr = cp->traj + (size_t)scene * 60;
+            int32_t* tlen = cp->traj_len;
+            int tl = turnover ? 0 : tlen[scene];
+            if (turnover) cp->traj_valid[scene] = 0;
             if (turnover || moved) {
                 double* e = tr + 3 * (tl % 20);
                 e[0] = x; e[1] = y; e[2] = h;
-                p.traj_len[scene] = tl + 1;
+                tlen[scene] = tl + 1;
             }
         }
         {   // hand-over to k_post, which also writes the per-scene scalar outputs (pose, status, done, RS gate flag)
@@ -1037,13 +1091,13 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     const double base0 = p.hull_base[i0], base1 = has1 ? p.hull_base[i1] : 0.0;
     const double lid0 = clipd(best0, 0, LIDAR_RANGE) - base0;      // get_observation :46
     const double lid1 = clipd(best1, 0, LIDAR_RANGE) - base1;
-    if (p.out.lidar) {
-        OT* lo = (OT*)p.out.lidar + (size_t)NBEAM * scene;
+    if (p.lidar) {
+        OT* lo = (OT*)p.lidar + (size_t)NBEAM * scene;
         lo[i0] = (OT)lid0;
         if (has1) lo[i1] = (OT)lid1;
     }
     ST_T(5);
-    if (!p.out.action_mask || (p.stages & 0x2000)) { ST_FLUSH(); return; }    // 0x2000: internal profiling switch
+    if (!p.action_mask || (p.stages & 0x2000)) { ST_FLUSH(); return; }    // 0x2000: internal profiling switch
 
     // ---- action mask (action_mask.py:166-196) ----------------------------------------------------------
     wsync();                                                      // region A: best[]/queue[] are dead from here
@@ -1176,7 +1230,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     double mo = (double)mn / NITER;
     unsigned long long nz = __ballot(lane < NACT && mn > 0);
     if (nz == 0) mo = clipd(mo, 0.01, 1);                          // all-zero -> 0.01 (:182-183)
-    if (lane < NACT) ((OT*)p.out.action_mask)[(size_t)NACT * scene + lane] = (OT)mo;
+    if (lane < NACT) ((OT*)p.action_mask)[(size_t)NACT * scene + lane] = (OT)mo;
     ST_T(7);
     ST_FLUSH();
 }

@@ -94,9 +94,11 @@ def summarize(records, levels=None):
     status, steps, reward, plen = r[:, 0].astype(int), r[:, 1], r[:, 2], r[:, 3]
     succ = status == 2
 
-    def block(sel):
+    def block(sel, per_case):
+        # per_case: the per-case / all-episodes `step_record`, in which an OUTBOUND episode counts 200 steps (eval_utils.py:73-76);
+        # the per-level "step num" of result.txt comes from step_num_level = the raw step_num (:71, :143)
         s = sel & succ
-        step_rec = np.where(status[sel] == 4, float(TOLERANT_TIME), steps[sel])          # OUTBOUND counts 200 (:73-76)
+        step_rec = np.where(status[sel] == 4, float(TOLERANT_TIME), steps[sel]) if per_case else steps[sel]
         short = sel & (steps < TOLERANT_TIME)
         return {'episodes': int(sel.sum()), 'success_rate': float(succ[sel].mean()) if sel.any() else 0.0,
                 'step_num_mean': float(step_rec.mean()) if sel.any() else 0.0, 'step_num_std': float(step_rec.std()) if sel.any() else 0.0,
@@ -104,9 +106,9 @@ def summarize(records, levels=None):
                 'path_length_mean': float(plen[short].mean()) if short.any() else 0.0,
                 'path_length_std': float(plen[short].std()) if short.any() else 0.0,
                 'reward_mean': float(reward[sel].mean()) if sel.any() else 0.0}
-    out = {'all': block(np.ones(len(r), bool))}
+    out = {'all': block(np.ones(len(r), bool), True)}
     if levels is not None:
         lv = np.asarray(levels)
         for k in sorted(set(lv.tolist())):
-            out[str(k)] = block(lv == k)
+            out[str(k)] = block(lv == k, False)
     return out

@@ -83,17 +83,25 @@ class PoolRefresher:
         except Exception as e:                      # surfaced by poll()
             self.error = e
 
-    def start_fill(self):
+    def start_fill(self, block=True):
+        """start the next fill; block=False: only if the pinned staging is free already (the previous commit's copies are gated
+        on the last enqueued step, so waiting for them would stall the host until the GPU has drained its queue)"""
         assert self.thread is None
-        arrays = self.env.pool_staging(self.n)      # (waits at most for the previous upload's copy to leave the staging)
+        if not block and not self.env.pool_staging_ready():
+            return False
+        arrays = self.env.pool_staging(self.n)
+        self.env._refresher_filling = True           # (env.set_pool refuses while the fill thread writes the pinned arrays)
         self.thread = threading.Thread(target=self._fill, args=(arrays, self.batch), daemon=True)
         self.thread.start()
         self.batch += 1
+        return True
 
     def poll(self, wait=False):
-        """commit a finished batch and start the next; returns True when a new pool was committed"""
+        """commit a finished batch and start the next (as soon as the staging is free again: at a later poll() if the upload of
+        the batch just committed is still reading it); returns True when a new pool was committed.  Never blocks unless wait."""
         if self.thread is None:
-            self.start_fill()
+            if not self.start_fill(block=wait):
+                return False
             if not wait:
                 return False
         if wait:
@@ -101,14 +109,16 @@ class PoolRefresher:
         if self.thread.is_alive():
             return False
         self.thread = None
+        self.env._refresher_filling = False
         if self.error is not None:
             raise self.error
         self.env.commit_pool(self.n)
         self.commits += 1
-        self.start_fill()
+        self.start_fill(block=False)
         return True
 
     def close(self):
         if self.thread is not None:
             self.thread.join()
             self.thread = None
+        self.env._refresher_filling = False

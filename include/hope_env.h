@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 6
+#define HOPE_ABI_VERSION 7
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -126,7 +126,10 @@ extern "C" {
  * hope_env_step itself: its launches follow the unfinished ones on the same library streams, so consecutive steps
  * pipeline.  The outputs are the same bits either way.  The bit takes effect in the two-launch form of the step and from
  * 32 768 scenes on (handles with HOPE_F_OVERLAP, without HOPE_F_GRAPH; below that size the joined form is the faster one);
- * elsewhere the step is joined as without it and hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself. */
+ * elsewhere the step is joined as without it and hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself.
+ * Lifetime of the inputs: `actions` and `active` are only read by launches `stream` is ordered after when hope_env_step returns
+ * (the Reeds-Shepp chain reads a snapshot of `active` that the motion launch takes into a buffer of the handle), so the caller
+ * may free or overwrite both right after the call, in stream order, as without the bit. */
 #define HOPE_DEFER_RS 0x200
 
 typedef struct hope_env hope_env_t;
@@ -213,6 +216,12 @@ int hope_env_set_pool(hope_env_t *h, int n_pool, const double *start, const doub
  * for the previous upload's copy to leave the staging).  Both must be called from the thread that owns the handle. */
 int hope_env_pool_staging(hope_env_t *h, int n_pool, double **start, double **dest, double **bbox, double **verts, int32_t **n_obst);
 int hope_env_commit_pool(hope_env_t *h, int n_pool, void *stream);
+/* 1 when hope_env_pool_staging would return without waiting (the previous commit's copies have left the pinned arrays), 0 when not
+ * yet, < 0 on error: a background refresher polls this instead of blocking the thread that drives the step loop */
+int hope_env_pool_staging_ready(hope_env_t *h);
+/* A counter that changes whenever the set of maps a draw can return changes (hope_env_set_pool / hope_env_commit_pool /
+ * hope_env_set_dlp_cases).  Part of a snapshot of drawn maps: hope_env_restore_maps refuses a snapshot of another generation. */
+int hope_env_pool_generation(hope_env_t *h, uint64_t *generation);
 /* seed of HOPE_AUTO_REDRAW's draws (default 0) */
 int hope_env_set_redraw_seed(hope_env_t *h, uint64_t seed);
 int hope_env_redraw(hope_env_t *h, const uint8_t *mask, uint64_t seed, void *stream);
@@ -244,9 +253,12 @@ int hope_env_download_scenes(hope_env_t *h, const int32_t *scene_ids, int n, dou
 /* Snapshot / restore of drawn maps.  A draw is a pure function of (seed, scene, episode counter) and of the pool / case lists:
  * hope_env_download_pool_state returns the pool index and the episode counter of every scene; hope_env_restore_maps (host arrays:
  * drawn[i] != 0 where the scene held a drawn map, the saved counters, the seed in use when the maps were drawn) repeats those draws
- * with the SAME pool / cases resident.  Restore pose / t / accumulator afterwards with hope_env_upload_state.  Host-synchronous. */
+ * with the SAME pool / cases resident: pass the hope_env_pool_generation value saved with the snapshot and the call fails with
+ * HOPE_ESTATE when the pool has been replaced since (a background refresher, hope_env_commit_pool) instead of silently restoring
+ * other maps; 0 skips the check.  Runs whose pool is refreshed snapshot the maps themselves (hope_env_download_scenes ->
+ * hope_env_set_scenes).  Restore pose / t / accumulator afterwards with hope_env_upload_state.  Host-synchronous. */
 int hope_env_download_pool_state(hope_env_t *h, int32_t *pool_index /*[N]*/, uint32_t *episode /*[N]*/);
-int hope_env_restore_maps(hope_env_t *h, const uint8_t *drawn /*[N]*/, const uint32_t *episode /*[N]*/, uint64_t seed);
+int hope_env_restore_maps(hope_env_t *h, const uint8_t *drawn /*[N]*/, const uint32_t *episode /*[N]*/, uint64_t seed, uint64_t pool_generation);
 
 /* With HOPE_F_PROFILE every kernel launch is bracketed by its own HIP event pair on the launch stream.
  * Returns the accumulated time (ms) and launch count per kernel since the last call with reset != 0:
@@ -308,10 +320,14 @@ int hope_debug_step_prof(uint64_t *out /*[16]*/, int reset);
  * Complex, parallel otherwise; map box = floor / ceil of min / max(start, dest) -/+ 10 m.  bay_mode: -1 as the reference, 0
  * parallel only, 1 bay only.  Outputs are HOST arrays in the layout of hope_env_set_scenes / hope_env_set_pool: start [n][3],
  * dest [n][3], bbox [n][4], verts [n][max_obstacles][4][2] (slots beyond n_obst[i] untouched), n_obst [n], case_id [n] (0 bay,
- * 1 parallel; may be NULL).  Scene i depends only on (seed, first_index + i), not on n_threads (<= 0: all hardware threads).
+ * 1 parallel; may be NULL).  Scene i depends only on (seed, first_index + i), not on n_threads (<= 0: the environment variable
+ * HOPE_HOST_THREADS, else the CPUs in the calling process's affinity mask -- one rank's share of the node once it has pinned
+ * itself, hope_amd.dist.pin_rank_to_cores -- never more).
  * Returns 0, HOPE_EINVAL, or -100 - i when scene i has more than max_obstacles obstacles (impossible for max_obstacles >= 18). */
 int hope_scenegen_generate(int level, int bay_mode, int n, uint64_t seed, int64_t first_index, int max_obstacles, double *start,
                            double *dest, double *bbox, double *verts, int32_t *n_obst, int32_t *case_id, int n_threads);
+/* the fan-out hope_scenegen_generate uses for n_threads <= 0 in this process, now */
+int hope_scenegen_default_threads(void);
 
 /* ---- introspection ---------------------------------------------------------------------------- */
 int hope_env_num_scenes(const hope_env_t *h);

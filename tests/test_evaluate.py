@@ -72,11 +72,13 @@ def test_evaluator_bookkeeping_matches_a_scalar_replay_of_eval():
 
 
 def test_summarize_follows_result_txt_rules():
-    # status, steps, reward, path: OUTBOUND counts 200 steps; path length only of episodes shorter than 200 (eval_utils.py:62-76)
+    # status, steps, reward, path: an OUTBOUND episode counts 200 steps in the per-case step_record only (eval_utils.py:73-76);
+    # the per-level "step num" is the raw step_num (step_num_level :71, :143); path length only of episodes shorter than 200
     rec = np.array([[2, 30, 5.0, 12.0], [4, 10, -5.0, 4.0], [5, 201, -1.0, 90.0], [2, 50, 5.0, 20.0]], np.float32)
     s = E.summarize(rec, levels=['a', 'a', 'b', 'b'])
     assert s['all']['success_rate'] == 0.5 and s['all']['success_step_mean'] == 40.0
-    assert s['a']['step_num_mean'] == (30 + 200) / 2 and s['b']['step_num_mean'] == (201 + 50) / 2
+    assert s['all']['step_num_mean'] == (30 + 200 + 201 + 50) / 4              # step_record: the OUTBOUND episode counts 200
+    assert s['a']['step_num_mean'] == (30 + 10) / 2 and s['b']['step_num_mean'] == (201 + 50) / 2   # step_num_level: raw
     assert s['a']['path_length_mean'] == 8.0 and s['b']['path_length_mean'] == 20.0
 
 

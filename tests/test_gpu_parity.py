@@ -520,6 +520,22 @@ def test_deferred_rs_join_equals_the_joined_step():
         for k in names:
             assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), k
         assert found > 0
+        # the `active` mask may be freed / overwritten (in stream order) right after a deferred step: the Reeds-Shepp chain, which
+        # runs on after the caller's stream has been released, reads the snapshot the motion launch took, not the caller's buffer
+        for it in range(6):
+            a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+            keep = (torch.rand(n, device='cuda', generator=g) < 0.7).to(torch.uint8)
+            tmp = keep.clone()
+            envs[0].step(a, active=keep)
+            envs[1].step(a, active=tmp, defer_rs=True)
+            tmp.fill_(1 if it % 2 else 0)                     # overwritten at once on the caller's stream ...
+            del tmp
+            junk = torch.full((n,), 1 - it % 2, dtype=torch.uint8, device='cuda')      # ... and its memory recycled by the allocator
+            envs[1].wait_rs()
+            torch.cuda.synchronize()
+            for k in names:
+                assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), (it, k)
+            del junk
         for e in envs:
             e.close()
     finally:
@@ -995,15 +1011,27 @@ def test_device_side_dlp_draw_distribution_and_oracle_parity():
     # (e) snapshot: maps + state, then move on, then restore
     pose, tt, acc = env.download_state()
     pidx, ep = env.pool_state()
+    gen = env.pool_generation()
     snap = env.download_scenes(sub)
     env.redraw(ones, seed=900)
     assert not np.array_equal(env.download_scenes(sub)[0], snap[0])
-    env.restore_maps(pidx, ep, seed=500 + 6)
+    # a slot that now holds a device-drawn lot of > 32 obstacles cannot join the small class (the host's obstacle counts of the
+    # uploaded first maps say nothing about what the device drew since)
+    big = int(np.argmax(env.download_scenes(np.arange(64))[4]))
+    assert env.download_scenes(np.array([big]))[4][0] > 32
+    with pytest.raises(Exception, match='32 obstacles'):
+        env.set_draw_class(np.array([big]), 0)
+    env.restore_maps(pidx, ep, seed=500 + 6, generation=gen)
     env.upload_state(pose=pose, t=tt, accum=acc)
     back = env.download_scenes(sub)
     assert all(np.array_equal(snap[j], back[j]) for j in (0, 1, 2, 4))
     assert all(np.array_equal(snap[3][k, :snap[4][k]], back[3][k, :back[4][k]]) for k in range(len(sub)))     # (slots beyond n_obst are stale)
     assert np.array_equal(env.pool_state()[0], pidx) and np.array_equal(env.pool_state()[1], ep)
+    # a snapshot of another pool generation is refused: repeating its draws would silently restore other maps
+    env.set_dlp_cases(pool)                                   # (any change of what a draw can return bumps the generation)
+    assert env.pool_generation() != gen
+    with pytest.raises(Exception, match='generation'):
+        env.restore_maps(pidx, ep, seed=500 + 6, generation=gen)
     env.close()
 
     # (b) one case, one candidate: the residual IS the jitter
@@ -1129,7 +1157,7 @@ def test_pool_refresh_in_the_background_keeps_up_and_matches_the_synchronous_upl
     for it in range(60):
         if it % 10 == 0:
             # hand b the pool a is about to commit: generate it synchronously with the same (seed, batch) recipe
-            batch = ref.batch - 1 if it else 0
+            batch = (ref.batch - 1 if ref.thread is not None else ref.batch) if it else 0   # the batch being / about to be filled
             per = P // 3
             parts = [generate_arrays(lv, per if j < 2 else P - 2 * per, seed=9 * 1000003 + j, max_obst=mo, first_index=batch * P)
                      for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
