@@ -77,6 +77,12 @@ def parse():
                     help='extra passes of --repeat-steps steps after the timed region (outside the driver-timed K steps): '
                          'their run-to-run spread and the steady-state episode population are reported')
     ap.add_argument('--repeat-steps', type=int, default=200)
+    ap.add_argument('--preroll', type=int, default=300,
+                    help='untimed steps of SETUP before the W warm-up steps that bring the batch to its stationary episode '
+                         'population: every episode first gets a random age t ~ U[1, 200] (fresh episodes all time out together '
+                         'at t = 201, and for their first steps fewer of them pass the Reeds-Shepp gate, so K steps timed right '
+                         'after a reset ran ~5 % faster than the loop ever runs again), then this many steps run.  The driver-timed '
+                         '`value` is then the steady-state number (`repeat` cross-checks it).  0 = time fresh episodes')
     return ap.parse_args()
 
 
@@ -109,6 +115,8 @@ def main():
     share = os.environ.get('HOPE_BENCH_SHARE_GPU') == '1'
     if share:
         local_rank = 0
+    from hope_amd.dist import pin_rank_to_cores, local_world_size
+    host_cpus = pin_rank_to_cores(int(os.environ.get('LOCAL_RANK', 0)), local_world_size())    # this rank's share of the host cores
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -226,6 +234,12 @@ def main():
         env.profile_kernels([dom])
     if trainer is None:
         env.reset_obs(stages=stages)
+        if args.preroll > 0:
+            # setup, not measurement: the stationary episode population (mixed ages, cars spread along their episodes)
+            env.upload_state(t=np.random.default_rng(args.seed + 99 + rank).integers(1, 201, N).astype(np.int32))
+            for i in range(args.preroll):
+                one_step(i)
+            torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(dev)
@@ -288,10 +302,25 @@ def main():
     parity = None
     if args.witness > 0 and trainer is None and rank == 0:
         parity = parity_witness(env, stages, fresh, act_bank[3], args.witness, args.seed + 1234)
+    rank_ms = [elapsed / args.steps * 1e3]
+    rccl = None
     if dist is not None:
-        tt = torch.tensor([elapsed], device='cpu' if share else dev, dtype=torch.float64)
+        cdev = 'cpu' if share else dev
+        mine_ms = elapsed / args.steps * 1e3
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # who took part: an all-reduce of ones must count every rank, each on its own device (over RCCL unless the test hook
+        # HOPE_BENCH_SHARE_GPU put all ranks on one GPU with gloo); per-rank step times by all-gather
+        ones = torch.ones(1, device=cdev, dtype=torch.float32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        allms = [torch.zeros(1, device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allms, torch.tensor([mine_ms], device=cdev, dtype=torch.float64))
+        rank_ms = [float(x.item()) for x in allms]
+        devs = [None] * world
+        dist.all_gather_object(devs, f'{os.uname().nodename}:cuda:{local_rank}')
+        rccl = {'backend': dist.get_backend(), 'allreduce_of_ones': float(ones.item()), 'ok': float(ones.item()) == float(world),
+                'devices': devs, 'distinct_devices': len(set(devs))}
 
     result = None
     if rank == 0:
@@ -382,8 +411,12 @@ def main():
             'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'ranks': world, 'rccl_check': rccl,
+            'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'all': rank_ms},
+            'host': {'cpus_this_rank': host_cpus, 'cpus_node': os.cpu_count(), 'generator_threads': L.load_library().hope_scenegen_default_threads(),
+                     'pinned': world > 1 and os.environ.get('HOPE_NO_PIN') != '1'},
             'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
-                                   'auto-restart of finished episodes', 'scenes_per_gpu': N, 'mean_edges': float(edges.mean()),
+                                   'auto-restart of finished episodes', 'scenes_per_gpu': N, 'preroll_steps': args.preroll if trainer is None else 0, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
                        'rs_join': ('deferred: the caller\'s stream is ordered after each step\'s observation / reward / status outputs, its '
@@ -429,6 +462,7 @@ def main():
                                      'horizon': args.horizon, 'mini_batch': args.mini_batch,
                                      'mini_epoch': args.mini_epoch if args.algo == 'ppo' else None,
                                      'updates_in_run': trainer.updates, 'allreduce_bytes_total': trainer.agent.allreduce_bytes,
+                                     'gradient_allreduce': __import__('hope_amd.dist', fromlist=['x']).allreduce_stats(),
                                      'pool_refreshes_in_run': (trainer.refresher.commits if trainer.refresher is not None else 0),
                                      'rollout': trainer.stats()})
         if not args.no_cpu_baseline and world == 1 and trainer is None:
@@ -558,10 +592,17 @@ def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's
         dt = time.perf_counter() - t0
         res[omp] = nn * args.cpu_steps / dt
     cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = cores
     return {'value': res[False], 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
             'sample': f'first {n} scenes of the bench scene set x {args.cpu_steps} steps, same stages/actions, '
                       'oracle/hope_oracle.c (gcc -O2), 1 thread',
-            'allcore_value': res[True], 'allcore_threads': O.lib(True).orc_num_threads(), 'host_cores': cores}
+            'allcore_value': res[True], 'allcore_threads': O.lib(True).orc_num_threads(), 'host_cores': cores,
+            'host_cpus_usable': usable,
+            'allcore_note': 'OpenMP over scenes with omp_get_max_threads() threads = the CPUs this process may run on (affinity / '
+                            'cgroup), which can be fewer than the hardware threads os.cpu_count() reports (host_cores)'}
 
 
 if __name__ == '__main__':

@@ -239,6 +239,35 @@ __device__ __forceinline__ float4 obstacle_box(const double* v) {
                        __double2float_ru(fmax(fmax(v[1], v[3]), fmax(v[5], v[7]))));
 }
 
+// The float32 view of one obstacle that the Reeds-Shepp validation kernel's filter works on (k_rs_validate_f), made ONCE per
+// map -- wherever a scene's tile is written -- instead of once per search (it was a quarter of that kernel's cycles): the four
+// vertices relative to the scene's frame origin (ox, oy) = (map box xmin, ymin) (integers: floor / ceil of parking_map_*.py's
+// map box; the subtraction is done in float64, one rounding to float32, <= 8e-6 m for |coordinates| <= 128 m), their box, and one
+// flag per edge j (vertex j -> j + 1): the edge is ROBUST for the reference's tolerance-free box test (car_parking_base.py:518-526)
+// -- both extents of its coordinate box >= FETA_EDGE, or it lies exactly on the world line y = 0 / x = 0 (then the candidate
+// coordinate is an exact zero whatever the rounding; the back wall of every generated lot, parking_map_normal.py:70-78).
+constexpr float FETA_EDGE = 1e-2f;
+__device__ __forceinline__ void obstacle_f32(const double* v /*[8]*/, double ox, double oy, float4* fv /*[2]*/, float4* fbox, uint8_t* eflag) {
+    float fx[4], fy[4];
+    int fl = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        fx[j] = (float)(v[2 * j] - ox); fy[j] = (float)(v[2 * j + 1] - oy);
+        const int j2 = (j + 1) & 3;
+        const double x1 = v[2 * j], y1 = v[2 * j + 1], x2 = v[2 * j2], y2 = v[2 * j2 + 1];
+        const bool wide_x = fabs(x2 - x1) >= (double)FETA_EDGE, wide_y = fabs(y2 - y1) >= (double)FETA_EDGE;
+        const bool zero_line = (y1 == 0.0 && y2 == 0.0 && wide_x) || (x1 == 0.0 && x2 == 0.0 && wide_y);
+        fl |= ((wide_x && wide_y) || zero_line) ? (1 << j) : 0;
+    }
+    fv[0] = make_float4(fx[0], fy[0], fx[1], fy[1]);
+    fv[1] = make_float4(fx[2], fy[2], fx[3], fy[3]);
+    *fbox = make_float4(fminf(fminf(fx[0], fx[1]), fminf(fx[2], fx[3])), fmaxf(fmaxf(fx[0], fx[1]), fmaxf(fx[2], fx[3])),
+                        fminf(fminf(fy[0], fy[1]), fminf(fy[2], fy[3])), fmaxf(fmaxf(fy[0], fy[1]), fmaxf(fy[2], fy[3])));
+    *eflag = (uint8_t)fl;
+}
+// row stride of the per-obstacle flag bytes
+__host__ __device__ inline int eflag_stride(int max_obst) { return (max_obst + 3) & ~3; }
+
 // wave-uniform LDS synchronisation for a one-wave workgroup
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 

@@ -76,6 +76,9 @@ struct hope_env {
     uint64_t pool_generation = 0;   // bumped by every change of what a draw can return (pool commit / upload, Dragon-Lake cases)
     uint64_t redraw_seed = 0;       // HOPE_AUTO_REDRAW
     float4* obb = nullptr;          // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
+    float4* fverts = nullptr;       // [n][max_obst][2] float32 view of the obstacles relative to (map box xmin, ymin): obstacle_f32
+    float4* fbox = nullptr;         // [n][max_obst]
+    uint8_t* eflag = nullptr;       // [n][eflag_stride(max_obst)]
     // staging for set_scenes
     void* stage = nullptr;
     size_t stage_bytes = 0;
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
                                                const int32_t* pnob, double* verts, double* scene_c, int32_t* n_obst,
                                                double* state, int32_t* tstep, double* traj, int32_t* traj_len,
                                                int32_t* traj_valid, int32_t* cur_pool, uint32_t* episode, float4* obb, DlpCases dlp,
-                                               int32_t* overflow, const uint8_t* slot_cls, int32_t* layer_valid) {
+                                               int32_t* overflow, const uint8_t* slot_cls, int32_t* layer_valid, float4* fverts,
+                                               float4* fbox, uint8_t* eflag) {
     __shared__ double c24[SC_WORDS];
     const int s = blockIdx.x, lane = threadIdx.x;
     if (!mask[s]) return;
@@ -320,11 +324,18 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
             const double2* src = (const double2*)(pverts + (size_t)j * max_obst * 8);
             double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
             for (int v = lane; v < 4 * nob; v += WAVE) dst[v] = src[v];
-            for (int o = lane; o < nob; o += WAVE) obb[(size_t)s * max_obst + o] = obstacle_box(pverts + ((size_t)j * max_obst + o) * 8);
+            const double fox = pc[(size_t)j * SC_WORDS + SC_BBOX], foy = pc[(size_t)j * SC_WORDS + SC_BBOX + 2];
+            for (int o = lane; o < nob; o += WAVE) {
+                const double* pv = pverts + ((size_t)j * max_obst + o) * 8;
+                obb[(size_t)s * max_obst + o] = obstacle_box(pv);
+                obstacle_f32(pv, fox, foy, fverts + ((size_t)s * max_obst + o) * 2, fbox + (size_t)s * max_obst + o,
+                             eflag + (size_t)s * eflag_stride(max_obst) + o);
+            }
             if (lane < SC_WORDS) c24[lane] = pc[(size_t)j * SC_WORDS + lane];
         } else                                                // a Dragon-Lake-Parking case, drawn exactly as the fused turnover draws it
             nob = draw_dlp_case(dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), max_obst, verts + (size_t)s * max_obst * 8,
-                                obb + (size_t)s * max_obst, c24, nullptr, overflow, lane);
+                                obb + (size_t)s * max_obst, fverts + (size_t)s * max_obst * 2, fbox + (size_t)s * max_obst,
+                                eflag + (size_t)s * eflag_stride(max_obst), c24, nullptr, overflow, lane);
         __syncthreads();
         if (lane < SC_WORDS) c[lane] = c24[lane];
         if (lane == 0) { n_obst[s] = nob; cur_pool[s] = j; if (layer_valid) layer_valid[s] = 0; }
@@ -396,16 +407,23 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
 }
 
 // one block per uploaded scene: copy its obstacle tile
-__global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const double* verts_in, double* verts, float4* obb,
-                                  int max_obst) {
+__global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const double* verts_in, const double* bbox_in, double* verts,
+                                  float4* obb, float4* fverts, float4* fbox, uint8_t* eflag, int max_obst) {
     int k = blockIdx.x;
-    int s = ids[k];
+    int s = ids ? ids[k] : k;
     const double2* src = (const double2*)(verts_in + (size_t)k * max_obst * 8);
     double2* dst = (double2*)(verts + (size_t)s * max_obst * 8);
     int nv = 4 * nob[k];
     for (int v = threadIdx.x; v < nv; v += blockDim.x) dst[v] = src[v];
-    if (obb)
-        for (int o = threadIdx.x; o < nob[k]; o += blockDim.x) obb[(size_t)s * max_obst + o] = obstacle_box(verts_in + ((size_t)k * max_obst + o) * 8);
+    if (obb) {
+        const double fox = bbox_in[4 * (size_t)k], foy = bbox_in[4 * (size_t)k + 2];          // frame origin of the float32 view
+        for (int o = threadIdx.x; o < nob[k]; o += blockDim.x) {
+            const double* pv = verts_in + ((size_t)k * max_obst + o) * 8;
+            obb[(size_t)s * max_obst + o] = obstacle_box(pv);
+            obstacle_f32(pv, fox, foy, fverts + ((size_t)s * max_obst + o) * 2, fbox + (size_t)s * max_obst + o,
+                         eflag + (size_t)s * eflag_stride(max_obst) + o);
+        }
+    }
 }
 
 }  // namespace
@@ -478,6 +496,9 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     } while (0)
     ALLOC(h->verts, N * max_obstacles * 8 * sizeof(double));
     ALLOC(h->obb, N * max_obstacles * sizeof(float4));
+    ALLOC(h->fverts, N * max_obstacles * 2 * sizeof(float4));
+    ALLOC(h->fbox, N * max_obstacles * sizeof(float4));
+    ALLOC(h->eflag, N * (size_t)eflag_stride(max_obstacles));
     ALLOC(h->n_obst, N * sizeof(int32_t));
     ALLOC(h->scene_c, N * SC_WORDS * sizeof(double));
     ALLOC(h->state, N * ST_WORDS * sizeof(double));
@@ -542,7 +563,11 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         fprintf(stderr, "\n");
     }
     HIPCHK(rs_init_tables());        // (a synchronous symbol copy: here, never inside a captured step)
-    if (lds > 48 * 1024) {
+    if (getenv("HOPE_OBS_WPC0") || getenv("HOPE_OBS_WPC1")) {
+        for (const void* f : {(const void*)k_env_step<float, float, false, 2>, (const void*)k_env_step<float, double, false, 2>,
+                              (const void*)k_env_step<double, float, false, 2>, (const void*)k_env_step<double, double, false, 2>})
+            HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    } else if (lds > 48 * 1024) {
         for (const void* f : {(const void*)k_env_step<float, float>, (const void*)k_env_step<float, float, true>,
                               (const void*)k_env_step<float, double>, (const void*)k_env_step<double, float>,
                               (const void*)k_env_step<double, double>,
@@ -562,12 +587,44 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         // chain's kernels then wait hundreds of microseconds between launches behind the first chain's.
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        static const bool use_prio = getenv("HOPE_PRIO") != nullptr;
-        for (int i = 1; i < hope_env::MAX_CHAINS; i++) {
-            const int prio = !use_prio ? 0 : ((i >= 2 && i <= 4) ? prio_lo : prio_hi);
-            HIPCHK(hipStreamCreateWithPriority(&h->side[i], hipStreamNonBlocking, prio));
-            HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        // HOPE_PRIO (experiment): stream priorities by ROLE -- 1: chains highest, observation / image lowest; 2: chains default,
+        // observation lowest; 3: chains highest, observation default
+        static const int prio_mode = getenv("HOPE_PRIO") ? atoi(getenv("HOPE_PRIO")) : 0;
+        int perm[hope_env::MAX_CHAINS] = {0, 1, 2, 3, 7, 5, 6, 4};
+        // Which library stream plays which role decides which roles share a HARDWARE queue (the runtime spreads streams over a few
+        // queues in creation order, and launches of streams that share one serialise): HOPE_SIDE_PERM="a,b,c,d,e,f,g" gives role i
+        // (1: chain of the small-tile class, 2: image, 3 / 4: observation half of the large- / small-tile class, 5: chain of the
+        // large-tile class with HOPE_DEFER_RS) the a-th ... created stream.  Default: the two observation launches on streams that do
+        // not share a hardware queue (3 and 7; with 3 and 4 the larger class's observation started only when the smaller class's
+        // was done, 180 us after its motion launch): 0.695 -> 0.675 ms (profiles/r04_stream_roles.txt).
+        {
+            const char* pe = getenv("HOPE_SIDE_PERM");
+            if (pe) {
+                int k = 1, tmp[hope_env::MAX_CHAINS] = {0, 1, 2, 3, 4, 5, 6, 7};
+                for (const char* q = pe; *q && k < hope_env::MAX_CHAINS; k++) {
+                    tmp[k] = atoi(q);
+                    while (*q && *q != ',') q++;
+                    if (*q == ',') q++;
+                }
+                bool used[hope_env::MAX_CHAINS] = {};
+                bool ok = true;
+                for (int i = 1; i < hope_env::MAX_CHAINS; i++) { if (tmp[i] < 1 || tmp[i] >= hope_env::MAX_CHAINS || used[tmp[i]]) ok = false; else used[tmp[i]] = true; }
+                if (ok) for (int i = 1; i < hope_env::MAX_CHAINS; i++) perm[i] = tmp[i];
+            }
         }
+        hipStream_t created[hope_env::MAX_CHAINS] = {};
+        for (int c = 1; c < hope_env::MAX_CHAINS; c++) {          // streams in creation order; the role of the c-th decides its priority
+            int role = c;
+            for (int r = 1; r < hope_env::MAX_CHAINS; r++) if (perm[r] == c) role = r;
+            const bool is_obs = role >= 2 && role <= 4, is_chain = role == 1 || role == 5;
+            int prio = 0;
+            if (prio_mode == 1) prio = is_obs ? prio_lo : prio_hi;
+            else if (prio_mode == 2) prio = is_obs ? prio_lo : 0;
+            else if (prio_mode == 3) prio = is_chain ? prio_hi : 0;
+            HIPCHK(hipStreamCreateWithPriority(&created[c], hipStreamNonBlocking, prio));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
+        }
+        for (int r = 1; r < hope_env::MAX_CHAINS; r++) h->side[r] = created[perm[r]];
     }
     if (flags & HOPE_F_GRAPH) {
         HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
@@ -598,7 +655,7 @@ int hope_env_destroy(hope_env_t* h) {
     for (hipEvent_t e : {h->ev_pool_ready, h->ev_pool_copied, h->ev_last_step}) if (e) hipEventDestroy(e);
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
-    void* ptrs[] = {h->obb, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
+    void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
                     h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -751,6 +808,7 @@ static int sync_cold(hope_env_t* h, hipStream_t s) {
     c.pool_cls[0] = h->pool_cls[0]; c.pool_cls[1] = h->pool_cls[1]; c.pool_cls_n[0] = h->pool_cls_n[0]; c.pool_cls_n[1] = h->pool_cls_n[1];
     c.cur_pool = h->cur_pool; c.episode = h->episode; c.redraw_seed = h->redraw_seed;
     c.dlp = h->dlp; c.pool_overflow = h->pool_overflow; c.slot_cls = h->slot_cls;
+    c.fverts = h->fverts; c.fbox = h->fbox; c.eflag = h->eflag;
     if (h->cold_idx >= 0 && memcmp(&c, &h->cold_last, sizeof(c)) == 0) return HOPE_OK;
     const int slot = (h->cold_idx + 1) % hope_env::COLD_RING;
     HIPCHK(hipEventSynchronize(h->cold_ev[slot]));
@@ -860,20 +918,31 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else launch_env_step<0>(of64, af64, grid, block, lds, sc, p);
         if (tm) tm->end(sc);
         if (fork && n_chain == 2 && (split || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // poses final
-        hipStream_t so = split ? h->side[3 + i] : sc;           // two-launch form: everything the search does not wait for
+        // two-launch form: everything the search does not wait for goes to its own stream.  (Experiment knobs: HOPE_OBS_SIDE0 / 1 =
+        // which library stream carries the observation half of chain 0 / 1, HOPE_OBS_WPC0 / 1 = its waves per CU, enforced
+        // through the LDS request.)
+        static const int obs_side[2] = {getenv("HOPE_OBS_SIDE0") ? atoi(getenv("HOPE_OBS_SIDE0")) : 3, getenv("HOPE_OBS_SIDE1") ? atoi(getenv("HOPE_OBS_SIDE1")) : 4};
+        static const int obs_wpc[2] = {getenv("HOPE_OBS_WPC0") ? atoi(getenv("HOPE_OBS_WPC0")) : 0, getenv("HOPE_OBS_WPC1") ? atoi(getenv("HOPE_OBS_WPC1")) : 0};
+        hipStream_t so = split ? h->side[std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
         if (split) HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
-        {                                                       // scalar outputs, reward / target arithmetic: one lane per scene
+        // k_post BEHIND the observation half on that stream: nothing waits for its outputs before the join, the observation is the
+        // long launch (0.675 -> 0.669 ms; HOPE_POST_LAST=0: the round-3 order)
+        static const bool post_last = !(getenv("HOPE_POST_LAST") && atoi(getenv("HOPE_POST_LAST")) == 0);
+        auto launch_post = [&]() {                              // scalar outputs, reward / target arithmetic: one lane per scene
             dim3 pg((p.n_list + WAVE - 1) / WAVE);
             if (tm) tm->begin(HOPE_K_POST, so);
             if (of64) hipLaunchKernelGGL((k_post<double>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, *out);
             else hipLaunchKernelGGL((k_post<float>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, *out);
             if (tm) tm->end(so);
-        }
+        };
+        if (!(split && post_last)) launch_post();
         if (split) {
             if (tm) tm->begin(HOPE_K_STEP, so);
-            launch_env_step<2>(of64, af64, grid, block, lds, so, p);
+            const size_t lds_obs = obs_wpc[i & 1] > 0 ? std::max(lds, (size_t)((158 * 1024 / obs_wpc[i & 1]) & ~255)) : lds;
+            launch_env_step<2>(of64, af64, grid, block, lds_obs, so, p);
             if (tm) tm->end(so);
-            HIPCHK(hipEventRecord(h->ev_join[3 + i], so));
+            if (post_last) launch_post();
+            HIPCHK(hipEventRecord(h->ev_join[3 + i], so));                // (the event index stays 3 + i whatever stream carries the launch)
         }
         if (!want_rs) continue;
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
@@ -888,11 +957,14 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (tm) tm->end(sc);
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
+        static const int prio_front = getenv("HOPE_PRIO_FRONT") ? atoi(getenv("HOPE_PRIO_FRONT")) : 0;
+        r.prio_front = prio_front;
         r.tile_cap = p.tile_cap;
         r.max_queue = p.n_list;
         r.slot_base = (c == 0) ? ch.a : h->n - 1 - ch.a;    // the two classes fill the record storage from both ends
         r.slot_dir = (c == 0) ? 1 : -1;
         r.verts = h->verts; r.obb = h->obb; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
+        r.fverts = h->fverts; r.fbox = h->fbox; r.eflag = h->eflag;
         r.rs_count = counter; r.rs_list = qlist;
         r.rs_rec = h->rs_rec;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
@@ -1054,7 +1126,8 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
                        (const int32_t*)(sp + o_nob), d_scene_c, d_state, d_t, d_nobst, d_traj, d_traj_len, d_traj_valid, d_layer_valid);
     if (verts)
         hipLaunchKernelGGL(k_set_scene_tiles, dim3(n), dim3(128), 0, 0, (const int32_t*)(sp + o_ids),
-                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), d_verts, d_obb, h->max_obst);
+                           (const int32_t*)(sp + o_nob), (const double*)(sp + o_verts), (const double*)(sp + o_bbox), d_verts, d_obb,
+                           h->fverts, h->fbox, h->eflag, h->max_obst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return HOPE_OK;
@@ -1347,7 +1420,7 @@ int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* str
     hipLaunchKernelGGL(k_redraw, dim3(h->n), dim3(WAVE), 0, (hipStream_t)stream, h->max_obst, mask, seed, h->pool_cls[0],
                        h->pool_cls_n[0], h->pool_cls[1], h->pool_cls_n[1], h->pool_verts, h->pool_c, h->pool_nobst, h->verts,
                        h->scene_c, h->n_obst, h->state, h->tstep, h->traj, h->traj_len, h->traj_valid, h->cur_pool, h->episode, h->obb,
-                       h->dlp, h->pool_overflow, h->slot_cls, h->layer_valid);
+                       h->dlp, h->pool_overflow, h->slot_cls, h->layer_valid, h->fverts, h->fbox, h->eflag);
     HIPCHK(hipGetLastError());
     if (h->pactive >= 0 && h->ev_last_step) HIPCHK(hipEventRecord(h->ev_last_step, (hipStream_t)stream));
     return HOPE_OK;

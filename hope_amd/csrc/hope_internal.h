@@ -25,7 +25,7 @@ constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generat
 //       (origin x, y, heading, cos, sin of the heading, type, length, [seg 0 only] int2 (type code, segment count));
 //       table 0 also carries cos / sin(-pose heading) in the spare words [15], [23];
 //       then 5 x 2 doubles = 5 x 4 floats for the float32 filter of k_rs_validate: per segment the origin in the frame
-//       "world minus the search's start position" [m] and cos / sin of the WORLD heading at the origin
+//       "world minus (map box xmin, ymin)" [m] (the frame of the scene's float32 obstacle view) and cos / sin of the WORLD heading at the origin
 constexpr int RS_REC_HDR = 16;
 constexpr int RS_REC_ORDER = 10;
 constexpr int RS_REC_KEYS = RS_REC_HDR;
@@ -40,7 +40,11 @@ struct RsParams {
     int max_queue;            // upper bound of *rs_count (= scenes in the class): grid size
     int slot_base, slot_dir;  // word storage slot of queue entry q = slot_base + slot_dir * q (classes fill from both ends)
     int obs_f64;
+    int prio_front;           // wave priority (s_setprio) of k_rs_words / k_rs_segs: the latency-bound front of the launch chain
     const float4* obb;        // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
+    const float4* fverts;     // [n][max_obst][2] float32 view of the obstacles in the scene's frame (origin = map box xmin, ymin): hope_dev.h obstacle_f32
+    const float4* fbox;       // [n][max_obst] their boxes in that frame
+    const uint8_t* eflag;     // [n][eflag_stride(max_obst)] per edge: robust for the reference's tolerance-free box test
     const double* verts;      // [n][max_obst][4][2] world frame
     const int32_t* n_obst;    // [n]
     const double* scene_c;    // [n][SC_WORDS]

@@ -383,7 +383,14 @@ __device__ __forceinline__ bool rs_dup(int n, double o0, double o1, double o2, d
 constexpr int RSA_GROUPS = 4;
 __device__ __constant__ const int rsa_group_begin[RSA_GROUPS + 1] = {0, 3, 7, 9, 12};
 
+__device__ __forceinline__ void set_wave_prio(int pr) {        // (s_setprio takes an immediate)
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
+    set_wave_prio(p.prio_front);
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
     const int qi = blockIdx.x * RSA_SCENES + ls;
     const int count = *p.rs_count;
@@ -505,6 +512,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
 // per word (two sincos and two divisions per segment); inside the validation kernel, one wave per search, it cost the
 // whole wave ~400 instructions per tested word -- a quarter of that kernel's cycles.
 __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
+    set_wave_prio(p.prio_front);
     __shared__ double keyl[8][RS_WORDS_PER_SCENE];            // candidate keys in path order
     __shared__ double prl[8][RS_WORDS_PER_SCENE];             // heap priorities per search
     __shared__ unsigned char hidl[8][RS_WORDS_PER_SCENE];     // heap ids (candidate slot)
@@ -585,6 +593,8 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     const double q0w = st[2];
     double sq0, cq0;                                      // world heading of the start pose: rotation local course -> world
     hm_sincos(q0w, &sq0, &cq0);
+    // start position in the frame of the scene's float32 obstacle view (origin = map box xmin, ymin: integers)
+    const double fq0x = st[0] - p.scene_c[(size_t)scene * SC_WORDS + SC_BBOX], fq0y = st[1] - p.scene_c[(size_t)scene * SC_WORDS + SC_BBOX + 2];
     for (int k = k0; k < n_test; k += 8) {
         const double* W = rec + RS_REC_WORDS + 8 * (int)order[k];
         double len[5];
@@ -604,9 +614,9 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
                 double* sp_ = tb + RS_SEGW * i;
                 sp_[0] = ox; sp_[1] = oy; sp_[2] = hy; sp_[3] = c_oy; sp_[4] = s_oy; sp_[5] = (double)m; sp_[6] = l;
                 if (i == 0) sp_[7] = w6;
-                {   // float32 filter row: origin rotated into the world axes (still relative to the start position), and the
-                    // world heading at the origin by angle addition (only ever used with error margins)
-                    const float fox = (float)(cq0 * ox - sq0 * oy), foy = (float)(sq0 * ox + cq0 * oy);
+                {   // float32 filter row: origin rotated into the world axes, in the frame of the scene's float32 obstacle view, and
+                    // the world heading at the origin by angle addition (only ever used with error margins)
+                    const float fox = (float)(fq0x + (cq0 * ox - sq0 * oy)), foy = (float)(fq0y + (sq0 * ox + cq0 * oy));
                     const float fc = (float)(c_oy * cq0 - s_oy * sq0), fs = (float)(s_oy * cq0 + c_oy * sq0);
                     tb[RS_SEG_F32 + 2 * i] = __hiloint2double(__float_as_int(foy), __float_as_int(fox));
                     tb[RS_SEG_F32 + 2 * i + 1] = __hiloint2double(__float_as_int(fs), __float_as_int(fc));
@@ -877,10 +887,11 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate(RsParams p, int obs_f64
 // A pass with a `hit` sample condemns the word at once; a pass with undecided samples and no hit re-evaluates just those
 // samples in float64; a pass whose samples are all clear is clear.  Identical results to k_rs_validate by construction
 // (the tests run both kernels on the same queues: tests/test_gpu_parity.py); HOPE_RS_EXACT=1 selects the kernel above.
-constexpr float FEPS = 1e-3f, FKAPPA = 2e-2f, FETA_EDGE = 1e-2f, FETA_HULL = 2e-3f;
+constexpr float FEPS = 1e-3f, FKAPPA = 2e-2f, FETA_HULL = 2e-3f;      // (FETA_EDGE: hope_dev.h, obstacle_f32)
 constexpr float F_INV_MAXC = (float)(1.0 / MAXC);
 constexpr float F_HL = (float)(0.5 * (CAR_XF - CAR_XR)), F_HW = (float)CAR_YH, F_MID = (float)(0.5 * (CAR_XF + CAR_XR));
 constexpr int RS_TAB = 256;
+constexpr int RSB_TABF = RSB_BAD + 8, RSB_WORDS_F = RSB_TABF + RS_TAB;   // k_rs_validate_f: + the first-segment sample table
 constexpr int RSF_OCC = 4;                 // waves per SIMD the register allocation of k_rs_validate_f aims at
 __device__ double g_rs_steps[RS_TAB];     // first-segment samples: T[k] = step added k + 1 times in sequence (every word's
                                           // first segment starts with pd = d and walks pd += d: the same chain for all)
@@ -915,15 +926,24 @@ __device__ __noinline__ bool exact_pass(int idx, const double* segp, const doubl
 }
 
 // The reference arithmetic for the samples the float32 filter left undecided, and only for the edges it left open (ua / ub:
-// obstacle | edge mask << 8): every other edge of these samples is certainly clear.  Same expressions as pose_hits.  Out of
-// line: it runs in a few per cent of the passes and must not cost the common path registers.
-__device__ __noinline__ bool exact_edges(bool unc, int sidx, int ua, int ub, const double* segp, const double* qpd,
-                                         const unsigned char* qseg, const double* tile64, double c_q, double s_q, double q0x,
-                                         double q0y, double q0w, double xmin, double xmax, double ymin, double ymax) {
+// obstacle | edge mask << 8): every other edge of these samples is certainly clear.  A sample with open edges on more than two
+// obstacles (uover: rare) takes every edge of every candidate obstacle of the pass (cand[0 .. nc)) instead -- the exact test of an
+// edge the filter found clear says clear, so looking at more edges cannot change the verdict.  Same expressions as pose_hits.
+// INLINE with rolled loops and the hull corners recomputed where they are used (round 4; it was an out-of-line function with
+// corner arrays: its callee-saved registers went to scratch memory on every call -- 13 x the kernel's output bytes in HBM writes --
+// and a kernel with a call cannot be free of scratch at all).
+__device__ __forceinline__ void hull_corner(int k, double ct, double st, double wx, double wy, double& cx, double& cy) {
+    cx = ct * car_x(k) - st * car_y(k) + wx;                                     // :468-471
+    cy = st * car_x(k) + ct * car_y(k) + wy;
+}
+__device__ __forceinline__ bool exact_edges(bool unc, int sidx, int ua, int ub, bool uover, const int* cand, int nc, const double* segp,
+                                            const double* qpd, const unsigned char* qseg, const double* tile64, const double* rec) {
     bool bad = false;
-    // The reference arithmetic, for the undecided samples and only for the edges the filter left open: every
-    // other edge of these samples is certainly clear.  Same expressions as pose_hits (k_rs_validate's).
     if (unc) {
+        // start pose, map box and the rotation of calc_all_paths: from the search record (global memory, the same address on every
+        // lane) -- kept in registers across the whole kernel they were 18 SGPRs of a register file that was already spilling
+        const double q0x = rec[2], q0y = rec[3], q0w = rec[4], xmin = rec[5], xmax = rec[6], ymin = rec[7], ymax = rec[8];
+        const double c_q = rec[RS_REC_SEGS + RS_SEGW + 7], s_q = rec[RS_REC_SEGS + 2 * RS_SEGW + 7];     // cos / sin(-q0 yaw) (k_rs_segs)
         double px = 0, py = 0, pyaw = 0;
         {
             const double spd = qpd[sidx];
@@ -936,17 +956,18 @@ __device__ __noinline__ bool exact_edges(bool unc, int sidx, int ua, int ub, con
         bad = wx < xmin || wx > xmax || wy < ymin || wy > ymax;             // :462-464
         double st_, ct_;
         hm_sincos(wyaw, &st_, &ct_);
-        double vx[4], vy[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            vx[k] = ct_ * car_x(k) - st_ * car_y(k) + wx;                   // :468-471
-            vy[k] = st_ * car_x(k) + ct_ * car_y(k) + wy;
+        double hminx, hmaxx, hminy, hmaxy;
+        {
+            double cx0, cy0, cx1, cy1, cx2, cy2, cx3, cy3;
+            hull_corner(0, ct_, st_, wx, wy, cx0, cy0); hull_corner(1, ct_, st_, wx, wy, cx1, cy1);
+            hull_corner(2, ct_, st_, wx, wy, cx2, cy2); hull_corner(3, ct_, st_, wx, wy, cx3, cy3);
+            hminx = fmin(fmin(cx0, cx1), fmin(cx2, cx3)); hmaxx = fmax(fmax(cx0, cx1), fmax(cx2, cx3));
+            hminy = fmin(fmin(cy0, cy1), fmin(cy2, cy3)); hmaxy = fmax(fmax(cy0, cy1), fmax(cy2, cy3));
         }
-        const double hminx = fmin(fmin(vx[0], vx[1]), fmin(vx[2], vx[3])), hmaxx = fmax(fmax(vx[0], vx[1]), fmax(vx[2], vx[3]));
-        const double hminy = fmin(fmin(vy[0], vy[1]), fmin(vy[2], vy[3])), hmaxy = fmax(fmax(vy[0], vy[1]), fmax(vy[2], vy[3]));
+        const int n_slot = uover ? nc : 2;
 #pragma unroll 1
-        for (int slot = 0; slot < 2; slot++) {
-            const int rec_ = slot ? ub : ua;
+        for (int slot = 0; slot < n_slot; slot++) {
+            const int rec_ = uover ? (cand[slot] | 0xF00) : (slot ? ub : ua);
             if (rec_ < 0) continue;
             const double* o = tile64 + 8 * (rec_ & 0xff);
 #pragma unroll 1
@@ -956,10 +977,11 @@ __device__ __noinline__ bool exact_edges(bool unc, int sidx, int ua, int ub, con
                 const double exmin = fmin(x1, x2), exmax = fmax(x1, x2), eymin = fmin(y1, y2), eymax = fmax(y1, y2);
                 if (exmin > hmaxx || exmax < hminx || eymin > hmaxy || eymax < hminy) continue;
                 const double d_ = y2 - y1, e_ = x1 - x2, f_ = y1 * x2 - x1 * y2;                  // :504-506
-#pragma unroll
+#pragma unroll 1
                 for (int k = 0; k < 4; k++) {
-                    const int k2 = (k + 1) & 3;
-                    const double ax1 = vx[k], ay1 = vy[k], ax2 = vx[k2], ay2 = vy[k2];
+                    double ax1, ay1, ax2, ay2;
+                    hull_corner(k, ct_, st_, wx, wy, ax1, ay1);
+                    hull_corner((k + 1) & 3, ct_, st_, wx, wy, ax2, ay2);
                     const double vminx = fmin(ax1, ax2), vmaxx = fmax(ax1, ax2), vminy = fmin(ay1, ay2), vmaxy = fmax(ay1, ay2);
                     if (vminx > exmax || vmaxx < exmin || vminy > eymax || vmaxy < eymin) continue;
                     const double a_ = ay2 - ay1, b_ = ax1 - ax2, c_ = ay1 * ax2 - ax1 * ay2;      // :477-479
@@ -975,6 +997,12 @@ __device__ __noinline__ bool exact_edges(bool unc, int sidx, int ua, int ub, con
         }
     }
     return bad;
+}
+
+// a wave-uniform double moved to scalar registers (the generator's per-segment state: five doubles that the compiler, which cannot
+// see that LDS reads of a uniform address are uniform, kept in vector registers for the whole kernel)
+__device__ __forceinline__ double uni_d(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
 template <int OCC, bool TIMING, bool STATS>
@@ -1000,7 +1028,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     double* scr = lds + 6 * p.tile_cap;            // (the float64 re-evaluation reads its few obstacle edges from global memory)
     double* segp = scr + RSB_SEG;
     double* qpd = scr + RSB_QPD;
-    int* cand = (int*)(scr + RSB_WORDS);
+    int* cand = (int*)(scr + RSB_WORDS_F);
+    double* tabl = scr + RSB_TABF;                 // first-segment samples T[0 .. 256) (a copy per wave: four registers per lane were
+                                                   // the difference between 128 VGPRs and spilling)
     unsigned char* qseg = (unsigned char*)(cand + ((p.tile_cap + 3) & ~3));
     unsigned char* eflag = qseg + RSB_QCAP;
 
@@ -1012,57 +1042,42 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     if (n_paths == 0) return;
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
     const int n_obst = __builtin_amdgcn_readlane(__double2hiint(r0), 0);
-    const double q0x = readlane_d(r0, 2), q0y = readlane_d(r0, 3), q0w = readlane_d(r0, 4);
-    const double xmin = readlane_d(r0, 5), xmax = readlane_d(r0, 6), ymin = readlane_d(r0, 7), ymax = readlane_d(r0, 8);
     const double* verts_g = p.verts + (size_t)scene * p.max_obst * 8;
-    const float4* obb_g = p.obb + (size_t)scene * p.max_obst;
-    // first-segment samples: lane holds T[lane], T[64 + lane], ... (in flight during the staging)
-    const double T0 = g_rs_steps[lane], T1 = g_rs_steps[WAVE + lane], T2 = g_rs_steps[2 * WAVE + lane], T3 = g_rs_steps[3 * WAVE + lane];
-    // map box relative to the start position: the rear axle must stay inside (:462-464)
-    const float fxmin = (float)(xmin - q0x), fxmax = (float)(xmax - q0x), fymin = (float)(ymin - q0y), fymax = (float)(ymax - q0y);
+    {   // first-segment samples into LDS (in flight during the staging)
+        const double T0 = g_rs_steps[lane], T1 = g_rs_steps[WAVE + lane], T2 = g_rs_steps[2 * WAVE + lane], T3 = g_rs_steps[3 * WAVE + lane];
+        tabl[lane] = T0; tabl[WAVE + lane] = T1; tabl[2 * WAVE + lane] = T2; tabl[3 * WAVE + lane] = T3;
+    }
+    // map box in the frame of the scene's float32 obstacle view (origin = its lower left corner): the rear axle must stay inside (:462-464)
+    const float fxmin = 0.0f, fxmax = (float)(readlane_d(r0, 6) - readlane_d(r0, 5)), fymin = 0.0f, fymax = (float)(readlane_d(r0, 8) - readlane_d(r0, 7));
     const double step = RS_STEP * MAXC;
-    // Obstacle vertices relative to the start position, float32 (subtraction in float64: one rounding, <= 4e-6 m); lane = vertex,
-    // so a quad of lanes holds one obstacle: its box and its edges' flags come from quad DPP, no second pass over the tile.
-    for (int base0 = 0; base0 < 4 * n_obst; base0 += 4 * WAVE) {
-        // (four loads in flight per round: a large tile is 8 chunks of 64 vertices, one exposed latency each when taken one by one)
-        double2 qq[4];
+    // The float32 view of the obstacles -- vertices in that frame, their boxes, the edges' robustness flags -- was made when the
+    // scene got its map (obstacle_f32, hope_dev.h): a copy.  (Rounds 2-3 converted the float64 tile here, once per SEARCH: 26 % of
+    // the kernel's cycles, 500 wave instructions for a Dragon-Lake lot.)
+    {
+        const float4* gfv = p.fverts + (size_t)scene * p.max_obst * 2;
+        const float4* gfb = p.fbox + (size_t)scene * p.max_obst;
+        const uint32_t* gfl = (const uint32_t*)(p.eflag + (size_t)scene * eflag_stride(p.max_obst));
+        float4* lfv = (float4*)fv;
+        for (int base = 0; base < 2 * n_obst; base += 4 * WAVE) {           // four loads in flight per round
+            float4 qq[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = base0 + u * WAVE + lane;
-            qq[u] = v < 4 * n_obst ? ((const double2*)verts_g)[v] : make_double2(0.0, 0.0);
-        }
+            for (int u = 0; u < 4; u++) { const int i = base + u * WAVE + lane; qq[u] = i < 2 * n_obst ? gfv[i] : make_float4(0, 0, 0, 0); }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-        const int base = base0 + u * WAVE;
-        if (base >= 4 * n_obst) break;
-        const int v = base + lane;
-        const bool in = v < 4 * n_obst;
-        const double2 q = qq[u];
-        const float fx = (float)(q.x - q0x), fy = (float)(q.y - q0y);
-        if (in) fv[v] = make_float2(fx, fy);
-        // An edge's coordinate box must not be degenerate: both extents >= FETA_EDGE.  One degenerate case IS robust: an edge that
-        // lies exactly on the world line y = 0 (or x = 0): then f = y1 x2 - x1 y2 and d = y2 - y1 are exact zeros, raw_y = -a f / det
-        // is an exact (signed) zero and passes the box test y_min = y_max = 0 whatever the rounding -- the back wall of every
-        // generated lot (parking_map_normal.py:70-78) has its top edge there.
-        const double x2 = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(q.x), 0x39, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(q.x), 0x39, 0xf, 0xf, true));
-        const double y2 = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(q.y), 0x39, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(q.y), 0x39, 0xf, 0xf, true));   // quad_perm [1,2,3,0]: the ring's next vertex
-        const bool wide_x = fabs(x2 - q.x) >= (double)FETA_EDGE, wide_y = fabs(y2 - q.y) >= (double)FETA_EDGE;
-        const bool zero_line = (q.y == 0.0 && y2 == 0.0 && wide_x) || (q.x == 0.0 && x2 == 0.0 && wide_y);
-        const unsigned long long rb = __ballot(in && ((wide_x && wide_y) || zero_line));
-        float mnx = fminf(fx, dpp_f<0xB1>(fx)), mxx = fmaxf(fx, dpp_f<0xB1>(fx)), mny = fminf(fy, dpp_f<0xB1>(fy)), mxy = fmaxf(fy, dpp_f<0xB1>(fy));
-        mnx = fminf(mnx, dpp_f<0x4E>(mnx)); mxx = fmaxf(mxx, dpp_f<0x4E>(mxx)); mny = fminf(mny, dpp_f<0x4E>(mny)); mxy = fmaxf(mxy, dpp_f<0x4E>(mxy));
-        if (in && (lane & 3) == 0) {
-            fbox[v >> 2] = make_float4(mnx, mxx, mny, mxy);
-            eflag[v >> 2] = (unsigned char)((rb >> lane) & 0xF);
+            for (int u = 0; u < 4; u++) { const int i = base + u * WAVE + lane; if (i < 2 * n_obst) lfv[i] = qq[u]; }
         }
+        for (int base = 0; base < n_obst; base += 2 * WAVE) {
+            const int i0 = base + lane, i1 = base + WAVE + lane;
+            const float4 b0 = i0 < n_obst ? gfb[i0] : make_float4(0, 0, 0, 0), b1 = i1 < n_obst ? gfb[i1] : make_float4(0, 0, 0, 0);
+            if (i0 < n_obst) fbox[i0] = b0;
+            if (i1 < n_obst) fbox[i1] = b1;
         }
+        for (int i = lane; 4 * i < n_obst; i += WAVE) ((uint32_t*)eflag)[i] = gfl[i];
     }
     int found = -1;
     double* bad1 = scr + RSB_BAD;
     if (lane < 6) bad1[lane] = INFINITY;
     wsync();
     RS_T(0);
-    const double c_q = readlane_d(tb, RS_SEGW + 7), s_q = readlane_d(tb, 2 * RS_SEGW + 7);   // cos / sin(-q0 yaw) (k_rs_segs)
     const bool paranoid = (obs_f64 & 0x2000) != 0;        // self-check: float64 for every sample, disagreements counted
     unsigned long long st_pass = 0, st_hit = 0, st_exact = 0, st_unc = 0, st_bad_hit = 0, st_bad_clear = 0, st_samples = 0;
     unsigned long long st_why[5] = {};
@@ -1092,9 +1107,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
             while (!finished && nq + WAVE + 1 <= win) {
                 if (TIMING) tsec[10] += 1;
                 if (!seg_open) {
-                    l = segp[RSB_SEGW * i + 6];
-                    d = l > 0.0 ? step : -step;
-                    if (i >= 1 && (lprev * l) > 0) pd = -d - ll; else pd = d - ll;
+                    l = uni_d(segp[RSB_SEGW * i + 6]);
+                    d = uni_d(l > 0.0 ? step : -step);
+                    pd = uni_d((i >= 1 && (lprev * l) > 0) ? -d - ll : d - ll);
                     lprev = l;
                     seg_open = true;
                 }
@@ -1102,12 +1117,12 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 int ncap;
                 if (i == 0 && t_off + WAVE <= RS_TAB) {
                     // first segment: pd = d, d + d, ... is the same chain for every word of every search -> table
-                    const double v = t_off == 0 ? T0 : (t_off == WAVE ? T1 : (t_off == 2 * WAVE ? T2 : T3));
+                    const double v = tabl[t_off + lane];
                     mine = d > 0.0 ? v : -v;
                     ncap = WAVE;
                     t_off += WAVE;
-                    if (t_off < RS_TAB) {                         // the chain's next value: lane 0 of the next chunk
-                        const double nx = readlane_d(t_off == WAVE ? T1 : (t_off == 2 * WAVE ? T2 : T3), 0);
+                    if (t_off < RS_TAB) {                         // the chain's next value: the first entry of the next chunk
+                        const double nx = tabl[t_off];
                         t = d > 0.0 ? nx : -nx;
                     } else t = readlane_d(mine, WAVE - 1) + d;
                 } else {
@@ -1135,8 +1150,8 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 if (lane < cnt) { qpd[nq + lane] = mine; qseg[nq + lane] = (unsigned char)i; }
                 nq += cnt;
                 if (fail) {
-                    pd = __shfl(mine, cnt);
-                    ll = l - pd - d;
+                    pd = readlane_d(mine, cnt);
+                    ll = uni_d(l - pd - d);
                     seg_open = false;
                     if (i == nseg - 1) {
                         if (lane == 0) { qpd[nq] = l; qseg[nq] = (unsigned char)i; }
@@ -1144,7 +1159,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                         finished = true;
                     }
                     i++;
-                } else pd = t;
+                } else pd = uni_d(t);
             }
             wsync();
             RS_T(2);
@@ -1302,7 +1317,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                     }
                 }
                 if (STATS && paranoid) {                         // float64 for every sample; compare with the float32 verdicts
-                    const bool ex = exact_pass<true>(active ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, verts_g, obb_g, cand, n_obst, xmin, xmax, ymin, ymax, lane);
+                    const double q0x = rec[2], q0y = rec[3], q0w = rec[4], xmin = rec[5], xmax = rec[6], ymin = rec[7], ymax = rec[8];
+                    const double c_q = rec[RS_REC_SEGS + RS_SEGW + 7], s_q = rec[RS_REC_SEGS + 2 * RS_SEGW + 7];
+                    const bool ex = exact_pass<true>(active ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, verts_g, p.obb + (size_t)scene * p.max_obst, cand, n_obst, xmin, xmax, ymin, ymax, lane);
                     st_samples += __popcll(__ballot(active));
                     st_bad_hit += __popcll(__ballot(active && hit && !ex));
                     if (active && ((hit && !ex) || (!any_hit && !hit && !unc && ex))) {
@@ -1324,9 +1341,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                     bad = ex;
                 } else if (!any_hit && __any(unc)) {
                     if (STATS) { st_exact += 1; st_unc += __popcll(__ballot(unc)); }
-                    bad = exact_edges(unc, sidx, ua, ub, segp, qpd, qseg, verts_g, c_q, s_q, q0x, q0y, q0w, xmin, xmax, ymin, ymax);
-                    if (__any(uover))                            // (a sample with open edges on more than two obstacles: rare)
-                        bad = exact_pass<false>(uover ? sidx : -1, segp, qpd, qseg, c_q, s_q, q0x, q0y, q0w, verts_g, obb_g, cand, n_obst, xmin, xmax, ymin, ymax, lane) || bad;
+                    bad = exact_edges(unc, sidx, ua, ub, uover, cand, nc, segp, qpd, qseg, verts_g, rec);
                 }
                 if (TIMING) t0_ = __builtin_readcyclecounter();
                 if (__any(bad)) {
@@ -1387,7 +1402,7 @@ static size_t rs_lds_bytes_exact(int max_obst) {
     return (size_t)(10 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP;
 }
 static size_t rs_lds_bytes_filter(int max_obst) {
-    return (size_t)(6 * max_obst + RSB_WORDS) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP + (size_t)((max_obst + 3) & ~3);
+    return (size_t)(6 * max_obst + RSB_WORDS_F) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP + (size_t)((max_obst + 3) & ~3);
 }
 size_t rs_lds_bytes(int max_obst) { return std::max(rs_lds_bytes_exact(max_obst), rs_lds_bytes_filter(max_obst)); }
 size_t rs_rec_bytes_per_scene() { return sizeof(double) * RS_REC_DOUBLES; }

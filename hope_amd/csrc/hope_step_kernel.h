@@ -59,8 +59,10 @@ __device__ __forceinline__ double draw_uniform(uint64_t key, int i) {
 // N(0, 0.02^2) rad jitter (:60-65), the map box floor / ceil(min / max(start, dest) -/+ 20) (:70-73), the case's obstacles
 // culled by that box in their order (filter_obstacles :88-101), then independent 50 % flips of dest and start about their box
 // centres (:80-83, _flip_box_orientation :117-123).  Writes the scene's tile (and its LDS copy when ltile != null), obstacle
-// boxes and the constant record `c24` (24 doubles, LDS or global, written by lane 0); returns the obstacle count.
+// boxes, the float32 view of the obstacles (obstacle_f32) and the constant record `c24` (24 doubles, LDS or global, written by
+// lane 0); returns the obstacle count.
 __device__ __forceinline__ int draw_dlp_case(const DlpCases& D, int cs, uint64_t key, int max_obst, double* gverts, float4* gobb,
+                                             float4* gfv, float4* gfbox, uint8_t* geflag,
                                              double* c24, double* ltile, int32_t* overflow, int lane) {
     const int c0 = D.cand_off[cs], n_c = D.cand_off[cs + 1] - c0;
     int ci = (int)(draw_uniform(key, 0) * n_c);
@@ -105,6 +107,7 @@ __device__ __forceinline__ int draw_dlp_case(const DlpCases& D, int cs, uint64_t
                 for (int k = 0; k < 8; k++) ltile[8 * pos + k] = v[k];
             }
             gobb[pos] = obstacle_box(v);
+            obstacle_f32(v, bb[0], bb[2], gfv + 2 * pos, gfbox + pos, geflag + pos);     // frame origin = (map box xmin, ymin)
         }
         cnt += __popcll(m);
     }
@@ -140,6 +143,9 @@ struct StepCold {
     DlpCases dlp;             // HOPE_AUTO_REDRAW: Dragon-Lake-Parking cases drawn on the device (hope_env_set_dlp_cases), or n_cases = 0
     int32_t* pool_overflow;   // [1] draws whose culled obstacle set exceeded max_obst (truncated): must stay 0
     const uint8_t* slot_cls;  // [n] draw class of every scene slot (0: lots of <= 32 obstacles, 1: larger)
+    float4* fverts;           // [n][max_obst][2] float32 view of the obstacles (obstacle_f32), rewritten with every new map
+    float4* fbox;             // [n][max_obst]
+    uint8_t* eflag;           // [n][eflag_stride(max_obst)]
 };
 
 constexpr uint32_t STEP_HF_TRAJ = 1;   // StepParams::hflags: the handle keeps vehicle.trajectory (HOPE_F_IMAGE)
@@ -847,14 +853,24 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                     const double2* psrc = (const double2*)pv;
                     double2* ldst = (double2*)tile;
                     for (int v = lane; v < 4 * nob; v += WAVE) { const double2 q2 = psrc[v]; gdst[v] = q2; ldst[v] = q2; }
-                    for (int o = lane; o < nob; o += WAVE) gobb[o] = obstacle_box(pv + (size_t)o * 8);
                     const double* pc = cp->pool_c + (size_t)j * SC_WORDS;
+                    {
+                        const double fox = pc[SC_BBOX], foy = pc[SC_BBOX + 2];
+                        float4* gfv = cp->fverts + (size_t)scene * p.max_obst * 2;
+                        float4* gfb = cp->fbox + (size_t)scene * p.max_obst;
+                        uint8_t* gfl = cp->eflag + (size_t)scene * eflag_stride(p.max_obst);
+                        for (int o = lane; o < nob; o += WAVE) {
+                            gobb[o] = obstacle_box(pv + (size_t)o * 8);
+                            obstacle_f32(pv + (size_t)o * 8, fox, foy, gfv + 2 * o, gfb + o, gfl + o);
+                        }
+                    }
                     if (lane < SC_WORDS) gsc[lane] = pc[lane];
                     sc = pc;                                            // the new scene's constants, straight from the pool
                 } else {                                                // a Dragon-Lake-Parking case: drawn here (ParkingMapDLP.reset)
                     double* c24 = scr + LDS_SH + 64;                    // (region A is free between the sub-step loop and the lidar)
-                    nob = draw_dlp_case(cp->dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), p.max_obst, (double*)gdst, gobb, c24, tile,
-                                        cp->pool_overflow, lane);
+                    nob = draw_dlp_case(cp->dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), p.max_obst, (double*)gdst, gobb,
+                                        cp->fverts + (size_t)scene * p.max_obst * 2, cp->fbox + (size_t)scene * p.max_obst,
+                                        cp->eflag + (size_t)scene * eflag_stride(p.max_obst), c24, tile, cp->pool_overflow, lane);
                     wsync();
                     if (lane < SC_WORDS) gsc[lane] = c24[lane];
                     sc = c24;

@@ -22,6 +22,38 @@ def shard_range(n_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def local_world_size():
+    """ranks on THIS node (torch.distributed.run exports LOCAL_WORLD_SIZE; a single process counts as 1)"""
+    return max(1, int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', 1))))
+
+
+def pin_rank_to_cores(local_rank=None, local_world=None):
+    """Give this rank ITS share of the host: with one process per GPU every rank runs host-side helpers -- the native scene
+    generator (hope_scenegen_generate), the pool refresher's thread, the OpenMP oracle of the CPU baseline -- whose default
+    fan-out is "the CPUs I may run on".  Unpinned, 8 ranks x 256 hardware threads oversubscribe a 256-thread host eightfold.
+    The rank's CPU affinity becomes a contiguous block of the CPUs the process may use now (NUMA-friendly for GPUs enumerated in
+    socket order), OMP_NUM_THREADS / torch's intra-op pool follow.  HOPE_NO_PIN=1 disables it.  Returns the number of CPUs."""
+    if local_rank is None:
+        local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if local_world is None:
+        local_world = local_world_size()
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:                      # not Linux
+        return os.cpu_count() or 1
+    if local_world <= 1 or os.environ.get('HOPE_NO_PIN') == '1' or len(cpus) < local_world:
+        return len(cpus)
+    per = len(cpus) // local_world
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    os.environ['OMP_NUM_THREADS'] = str(len(mine))
+    try:
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+    except Exception:
+        pass
+    return len(mine)
+
+
 def init_from_env(backend=None):
     """reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  Returns (rank, world, local_rank)."""
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -37,13 +69,39 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+_AR = {'calls': 0, 'bytes': 0, 'events': [], 'ms': 0.0}
+
+
+def allreduce_stats(reset=False):
+    """fused gradient all-reduces since the last reset: {'calls', 'bytes', 'ms'} -- ms from device events around the collective
+    (CUDA tensors; 0 for gloo / CPU), resolved here, not in the hot loop"""
+    for a, b in _AR['events']:
+        b.synchronize()
+        _AR['ms'] += a.elapsed_time(b)
+    _AR['events'].clear()
+    out = {'calls': _AR['calls'], 'bytes': _AR['bytes'], 'ms': _AR['ms'],
+           'ms_per_call': _AR['ms'] / _AR['calls'] if _AR['calls'] else None, 'bytes_per_call': _AR['bytes'] / _AR['calls'] if _AR['calls'] else None}
+    if reset:
+        _AR.update(calls=0, bytes=0, ms=0.0)
+    return out
+
+
 def allreduce_gradients(params, average=True, group=None):
     """sum (or mean) the .grad of every parameter across ranks through ONE flat buffer."""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
+    ev = None
+    if flat.is_cuda and len(_AR['events']) < 4096:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if ev is not None:
+        ev[1].record()
+        _AR['events'].append(ev)
+    _AR['calls'] += 1
+    _AR['bytes'] += flat.numel() * flat.element_size()
     if average:
         flat /= dist.get_world_size(group)
     off = 0

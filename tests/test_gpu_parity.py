@@ -95,7 +95,7 @@ def rollout(env, orc, rng, steps, tol, with_rs=False, stages=None):
 def test_library_is_native():
     from hope_amd import load_library
     L = load_library()
-    assert L.hope_abi_version() == 6
+    assert L.hope_abi_version() == 7
 
 
 def test_step_parity_f64_dlp():
