@@ -675,6 +675,24 @@ int hope_debug_step_prof(uint64_t* out, int reset) {
     return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_step_prof: ") + hipGetErrorString(e));
 }
 
+int hope_debug_census(uint64_t* out, int reset) {
+    // [1] [3] [7] are minima (bit patterns of non-negative doubles), the rest are counts; 64 shards
+    static unsigned long long buf[64 * 16];
+    if (!out) return fail(HOPE_EINVAL, "hope_debug_census: null argument");
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(buf, HIP_SYMBOL(g_census), sizeof(buf));
+    for (int i = 0; i < 16; i++) {
+        const bool is_min = i == 1 || i == 3 || i == 7;
+        out[i] = is_min ? ~0ull : 0;
+        for (int sh = 0; sh < 64; sh++) out[i] = is_min ? std::min<uint64_t>(out[i], buf[sh * 16 + i]) : out[i] + buf[sh * 16 + i];
+    }
+    if (e == hipSuccess && reset) {
+        for (int sh = 0; sh < 64; sh++) for (int i = 0; i < 16; i++) buf[sh * 16 + i] = (i == 1 || i == 3 || i == 7) ? 0x7ff0000000000000ull : 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_census), buf, sizeof(buf));
+    }
+    return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_census: ") + hipGetErrorString(e));
+}
+
 int hope_debug_rs_prof(uint64_t* out, int reset) {
     hipError_t e = rs_prof_read((unsigned long long*)out, reset);
     return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_prof: ") + hipGetErrorString(e));

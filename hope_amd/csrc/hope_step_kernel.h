@@ -397,7 +397,7 @@ __device__ __forceinline__ int stage_near(const float4* obb, const double2* src,
 // orientation filter (segments_intersect_fast); a lane whose pair it leaves undecided -- and only if no lane has a certain hit --
 // takes the robust path, one lane at a time, with the LDS work area xl[ROBUST_LDS_WORDS].
 __device__ __forceinline__ bool detect_collision(double px, double py, double ct, double st, const double* tile, const int* list,
-                                                 int n_list, double* xl, int lane) {
+                                                 int n_list, double* xl, int lane, unsigned* n_undecided = nullptr) {
     const int n_slots = 4 * n_list;
     const Box b = make_box(px, py, ct, st);
     double hminx = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3]));
@@ -427,6 +427,7 @@ __device__ __forceinline__ bool detect_collision(double px, double py, double ct
         if (__any(hit)) return true;
         unsigned long long um = __ballot(und);
         if (um) {
+            if (n_undecided) *n_undecided += __popcll(um);
             bool hit2 = false;
             while (um) {
                 const int l = __ffsll((long long)um) - 1;
@@ -616,10 +617,25 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
 // [3] lidar: ego transform + ring keep [4] lidar: per-edge beam ranges [5] lidar: enqueue [6] lidar: exact pairs (drain)
 // [7] action mask [8] whole wave [9] waves
 __device__ unsigned long long g_step_prof[64 * 16];
+// Tie census (the same instrumented instantiation; tools/tie_census.py): how close the workload comes to the decisions whose
+// arithmetic the reference delegates to GEOS -- [0] arrival-ratio evaluations [1] min |overlap / dest area - 0.95| (double bits)
+// [2] lidar ring-keep evaluations [3] min |ring distance - 10 m| [4] (hull edge, obstacle edge) pairs an orientation filter
+// left undecided (the exact path decided them) [6] action-mask table compares [7] min NON-ZERO |table entry - scan value| [8] scene-steps
+// whose mask took the exact 1200-beam evaluation (a table entry within 1e-9 of the scan) [9] scene-steps [10] compares with entry == scan
+// bit for bit (the structural tie: a touching obstacle clips the scan to the hull range the table was built from)
+__device__ unsigned long long g_census[64 * 16];
+#define CEN_ARR(ua_) do { if (TIMING) { cen_arr_n += 1; cen_arr = fmin(cen_arr, fabs((ua_) / dest_area - 0.95)); } } while (0)
 #define ST_T0() unsigned long long t0_ = TIMING ? __builtin_readcyclecounter() : 0
 #define ST_T(i) do { if (TIMING) { const unsigned long long t1_ = __builtin_readcyclecounter(); tsec[i] += t1_ - t0_; t0_ = t1_; } } while (0)
 #define ST_FLUSH() do { if (TIMING) { tsec[8] = __builtin_readcyclecounter() - tstart_; tsec[9] = 1; \
-        if (lane == 0) for (int i_ = 0; i_ < 16; i_++) if (tsec[i_]) atomicAdd(&g_step_prof[(blockIdx.x & 63) * 16 + i_], tsec[i_]); } } while (0)
+        if (lane == 0) for (int i_ = 0; i_ < 16; i_++) if (tsec[i_]) atomicAdd(&g_step_prof[(blockIdx.x & 63) * 16 + i_], tsec[i_]); \
+        double cr_ = cen_ring, cm_ = cen_mask; unsigned nr_ = cen_ring_n, nm_ = cen_mask_n, ne_ = cen_eq; \
+        for (int o_ = 32; o_ > 0; o_ >>= 1) { cr_ = fmin(cr_, __shfl_xor(cr_, o_)); cm_ = fmin(cm_, __shfl_xor(cm_, o_)); nr_ += __shfl_xor(nr_, o_); nm_ += __shfl_xor(nm_, o_); ne_ += __shfl_xor(ne_, o_); } \
+        if (lane == 0) { unsigned long long* c_ = g_census + (blockIdx.x & 63) * 16; \
+            atomicAdd(&c_[0], (unsigned long long)cen_arr_n); atomicMin(&c_[1], (unsigned long long)__double_as_longlong(cen_arr)); \
+            atomicAdd(&c_[2], (unsigned long long)nr_); atomicMin(&c_[3], (unsigned long long)__double_as_longlong(cr_)); \
+            atomicAdd(&c_[4], (unsigned long long)cen_und); atomicAdd(&c_[6], (unsigned long long)nm_); \
+            atomicMin(&c_[7], (unsigned long long)__double_as_longlong(cm_)); atomicAdd(&c_[8], (unsigned long long)cen_tie); atomicAdd(&c_[9], 1ull); atomicAdd(&c_[10], (unsigned long long)ne_); } } } while (0)
 
 // PART: 0 = the whole scene-step; 1 = motion, status, turnover and state only (everything the Reeds-Shepp chain and k_post
 // wait for); 2 = the observation only (lidar + action mask) of the pose PART 1 left in `state`.  With HOPE_F_OVERLAP the
@@ -632,6 +648,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if ((int)blockIdx.x >= p.n_list) return;
     unsigned long long tsec[16] = {};
     const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
+    double cen_arr = INFINITY, cen_ring = INFINITY, cen_mask = INFINITY;      // tie census (TIMING builds only; dead code otherwise)
+    unsigned cen_arr_n = 0, cen_ring_n = 0, cen_mask_n = 0, cen_und = 0, cen_tie = 0, cen_eq = 0;
     ST_T0();
     if (PART != 2 && p.rs_count_zero && blockIdx.x == 0 && threadIdx.x == 0) p.rs_count_zero[0] = 0;   // this class's queue length
     const int scene = p.scene_list[scene_of_block(blockIdx.x, p.n_list)];
@@ -747,6 +765,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 }
                 {   // pairs the orientation filter left open (practically never): the robust path, one lane at a time
                     unsigned long long um = __ballot(und && !hit);
+                    if (TIMING) cen_und += __popcll(um);
                     while (um) {
                         const int l = __ffsll((long long)um) - 1;
                         um &= um - 1;
@@ -760,6 +779,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                         const int kq = k0 + gg;
                         if (am & gm) {                                                   // _check_arrived :164-170
                             ua = overlap_area(scr[LDS_PX + kq], scr[LDS_PY + kq], scr[LDS_CB + kq], scr[LDS_SB + kq], dbox, scr + LDS_SH, lane);
+                            CEN_ARR(ua);
                             if (ua / dest_area > 0.95) { ev_k = kq; ev_arrive = true; break; }
                         }
                         if (hm & gm) { ev_k = kq; break; }                               // _detect_collision :264
@@ -771,9 +791,10 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 const double qx = scr[LDS_PX + k], qy = scr[LDS_PY + k], qc = scr[LDS_CB + k], qs = scr[LDS_SB + k];
                 if ((apmask >> k) & 1) {                                                  // _check_arrived :164-170
                     ua = overlap_area(qx, qy, qc, qs, dbox, scr + LDS_SH, lane);
+                    CEN_ARR(ua);
                     if (ua / dest_area > 0.95) { ev_k = k; ev_arrive = true; break; }
                 }
-                if (detect_collision(qx, qy, qc, qs, tile, nlist, n_near, xl, lane)) { ev_k = k; break; }  // _detect_collision :264
+                if (detect_collision(qx, qy, qc, qs, tile, nlist, n_near, xl, lane, TIMING ? &cen_und : nullptr)) { ev_k = k; break; }  // _detect_collision :264
             }
         }
         // final pose of the motion: the arrival pose, the pose BEFORE the colliding sub-step (retreat :264-271), or
@@ -801,7 +822,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         if (arrive) status = HOPE_STATUS_ARRIVED;
         else {
             const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
-            bool coll = known_free ? false : detect_collision(x, y, ct, sn, tile, nlist, n_near, xl, lane);
+            bool coll = known_free ? false : detect_collision(x, y, ct, sn, tile, nlist, n_near, xl, lane, TIMING ? &cen_und : nullptr);
             if (coll) status = HOPE_STATUS_COLLIDED;
             else if (x > xmax || x < xmin || y > ymax || y < ymin) status = HOPE_STATUS_OUTBOUND;
             else {
@@ -809,6 +830,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 if (have_ua) arrived = ua / dest_area > 0.95;
                 else if (kf_pose >= 0 ? ((apmask >> kf_pose) & 1) != 0 : arrival_possible(x, y, ct, sn, dcx, dcy, dcd, dsd)) {
                     ua = overlap_area(x, y, ct, sn, dbox, scr + LDS_SH, lane);
+                    CEN_ARR(ua);
                     have_ua = true;
                     arrived = ua / dest_area > 0.95;
                 }
@@ -896,9 +918,10 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                                                    : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
         wsync();
         const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
-        bool cont = !detect_collision(x, y, ct, sn, tile, nlist, n_near0, xl, lane) && !(x > xmax || x < xmin || y > ymax || y < ymin);
+        bool cont = !detect_collision(x, y, ct, sn, tile, nlist, n_near0, xl, lane, TIMING ? &cen_und : nullptr) && !(x > xmax || x < xmin || y > ymax || y < ymin);
         if (cont) {
             const double ua0 = overlap_area(x, y, ct, sn, dbox, scr + LDS_SH, lane);
+            CEN_ARR(ua0);
             if (!(ua0 / dest_area > 0.95)) {                            // not ARRIVED (and t = 1 is not OUTTIME): CONTINUE
                 const double bur = ua0 / (2 * dest_area - ua0);
                 if (!(bur < accum)) accum = bur;                        // :221-226 with accum = 0
@@ -972,6 +995,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         }
         dd = fmin(dd, dpp_d<0xB1>(dd));                      // quad_perm [1,0,3,2]
         dd = fmin(dd, dpp_d<0x4E>(dd));                      // quad_perm [2,3,0,1]
+        if (TIMING && in && (i & 3) == 0) { cen_ring_n += 1; cen_ring = fmin(cen_ring, fabs(dd - LIDAR_RANGE)); }
         const bool kq = in && (i & 3) == 0 && dd < LIDAR_RANGE;
         const unsigned long long km = __ballot(kq);
         if (kq) llist[n_k + __popcll(km & ((1ull << lane) - 1))] = o;   // in place: writes stay below the next chunk's reads
@@ -1169,6 +1193,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                         if (mstep > 0) {
                             const double xv = xs[ib[g]];
                             double bv = v[g];                     // boundary value: largest examined entry <= x
+                            if (TIMING) { cen_mask_n += 1; const double df_ = fabs(bv - xv); if (df_ > 0) cen_mask = fmin(cen_mask, df_); else cen_eq += 1; }
                             if (bv > xv) {
                                 const double* row = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + lane;
                                 // walk down to the first entry <= x: four rows per trip, loaded together (a dependent
@@ -1192,6 +1217,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                                 }
                                 if (c == 0) bv = -INFINITY;
                                 mstep = c;
+                                if (TIMING && c > 0) { cen_mask_n += 1; const double df_ = fabs(bv - xv); if (df_ > 0) cen_mask = fmin(cen_mask, df_); else cen_eq += 1; }
                             }
                             if (bv > xv - 1e-9) tie = true;
                         }
@@ -1200,6 +1226,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             }
         }
     }
+    if (TIMING && __any(tie)) cen_tie = 1;
     if (__any(tie)) {
         // ---- exact fall-back over all 1200 beams (rare) ---------------------------------------------------
         for (int r = 0; r < (NL + WAVE - 1) / WAVE; r++) {

@@ -313,6 +313,14 @@ int hope_debug_rs_filter_dump(double *out /*[64][16]*/);
 int hope_debug_rs_log(int32_t *out /*[cap][4]*/, int cap, int32_t *n, int reset);
 /* the same for k_env_step (environment variable HOPE_STEP_TIMING; float32 observation / action handles); tools/step_timing.py */
 int hope_debug_step_prof(uint64_t *out /*[16]*/, int reset);
+/* Tie census of the same instrumented build (HOPE_STEP_TIMING): how close the workload comes to the decisions whose arithmetic the
+ * reference delegates to GEOS (rows a-3, a-4, the ring cull of a-8) and to the mask compares.  out: [0] arrival-ratio evaluations,
+ * [1] min |overlap / dest area - 0.95| (bit pattern of a double), [2] lidar ring-keep evaluations, [3] min |ring distance - 10 m|
+ * (double), [4] (hull edge, obstacle edge) pairs the orientation filter left undecided (decided by the exact expansion), [6] mask table
+ * compares, [7] min non-zero |table entry - scan value| (double), [8] scene-steps whose mask took the exact 1200-beam evaluation,
+ * [9] scene-steps, [10] compares whose entry equals the scan value bit for bit.
+ * Call once with reset != 0 before counting (the minima start at +inf then).  tools/tie_census.py. */
+int hope_debug_census(uint64_t *out /*[16]*/, int reset);
 
 /* ---- host-side scene generator (no device involved; any thread) ------------------------------------------------------ */
 /* n scenes of `level` (0 Normal, 1 Complex, 2 Extrem) drawn as ParkingMapNormal.reset does (src/env/parking_map_normal.py:474-494
