@@ -76,11 +76,17 @@ enum { M_DXX, M_DXY, M_DX0, M_DYX, M_DYY, M_DY0, M_ROX, M_ROY, M_VEH_HIDDEN,
 // (code_newest - code) mod DYN_MOD and, if age < min(len, 20), into palette id 24 - age.  Pixels of entries that have left the drawn
 // set are simply older than 20: nothing is ever erased, except that every DYN_REFRESH entries (and at every reset) the painted
 // region is cleared and the <= 20 live boxes are repainted, so that no stale code gets old enough to alias (114 < 192).
+// Round 4: the layer is a 256 x 256 pixel TORUS (64 KiB per scene instead of 256 KiB: 4.3 GB instead of 17 GB at 65 536 scenes).
+// The boxes drawn now span at most 19 steps x 15 px + a 62 px box = 347 px, and usually far less; two of their pixels can only
+// share a byte if the box around them is wider or higher than 256 px -- then the episode switches to the per-tile raster
+// (M_DYN_BAD), which is exact.  Otherwise a byte read for a pixel INSIDE that box holds either a live code painted for this very
+// pixel or a code older than 20 entries (whatever pixel it was painted for), and pixels outside the box are not looked up at all.
 constexpr int DYN_MOD = 192, DYN_REFRESH = 96;
 // box around the <= 20 trajectory boxes that are drawn NOW (the tiles it misses need not look at the layer): spare header words
 constexpr int OFF_LIVE_X = OFF_HDR + 14, OFF_LIVE_Y = OFF_HDR + HDR_INTS + 14;
 __device__ __forceinline__ int dyn_code(int e) { return e % DYN_MOD + 1; }
-__device__ __forceinline__ int dyn_byte(int x, int y) { return ((((y >> 3) << 5) + (x >> 4)) << 7) + ((y & 7) << 4) + (x & 15); }
+// byte of world pixel (x, y) in the 256 x 256 torus (16 x 32 blocks of 16 x 8 pixels)
+__device__ __forceinline__ int dyn_byte(int x, int y) { return (((((y & (BEV_DYN_DIM - 1)) >> 3) << 4) + ((x & (BEV_DYN_DIM - 1)) >> 4)) << 7) + ((y & 7) << 4) + (x & 15); }
 enum { H_MINY, H_NROWS, H_FLAGS, H_MINX, H_MAXX, H_MAXY, H_VX, H_VY = H_VX + 4 };
 constexpr int F_SIMPLE = 1;                    // every row has exactly one span and the border pass adds nothing outside
 constexpr uint32_t SPAN_EMPTY = 2u | (1u << 16);   // a0 = 1 > a1 = 0 (stored + 1)
@@ -273,11 +279,11 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
     const bool dyn_reset = valid == 0;
     const bool dyn_refresh = dyn_reset || (traj_len - 1) / DYN_REFRESH != (valid - 1) / DYN_REFRESH;
     if (dyn_refresh) {
-        if (dirty_x0 <= dirty_x1 && dirty_y0 <= dirty_y1) {
-            const int bx0 = dirty_x0 >> 4, nbx = (dirty_x1 >> 4) - bx0 + 1, by0 = dirty_y0 >> 3, nby = (dirty_y1 >> 3) - by0 + 1;
+        if (dirty_x0 <= dirty_x1 && dirty_y0 <= dirty_y1) {              // the blocks of the painted region, on the torus
+            const int bx0 = dirty_x0 >> 4, nbx = min((dirty_x1 >> 4) - bx0 + 1, BEV_DYN_DIM / 16), by0 = dirty_y0 >> 3, nby = min((dirty_y1 >> 3) - by0 + 1, BEV_DYN_DIM / 8);
             for (int i = lane; i < nbx * nby * 8; i += WAVE) {
                 const int blk = i >> 3, byi = blk / nbx, bxi = blk - byi * nbx;
-                *(uint4*)(dyn + ((((by0 + byi) << 5) + bx0 + bxi) << 7) + ((i & 7) << 4)) = make_uint4(0, 0, 0, 0);
+                *(uint4*)(dyn + (((((by0 + byi) & (BEV_DYN_DIM / 8 - 1)) << 4) + ((bx0 + bxi) & (BEV_DYN_DIM / 16 - 1))) << 7) + ((i & 7) << 4)) = make_uint4(0, 0, 0, 0);
             }
         }
         dirty_x0 = 1; dirty_x1 = 0; dirty_y0 = 1; dirty_y1 = 0;
@@ -288,10 +294,11 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
         const int y = miny + lane;
         const int a = max((int)(sp & 0xffff) - 1, 0), b = min((int)(sp >> 16) - 1, WIN - 1);
         if (lane < nrows && y >= 0 && y < WIN) {
-            uint8_t* row = dyn + (((y >> 3) << 5) << 7) + ((y & 7) << 4);
+            uint8_t* row = dyn + ((((y & (BEV_DYN_DIM - 1)) >> 3) << 4) << 7) + ((y & 7) << 4);
             for (int x = a; x <= b;) {
-                if ((x & 3) == 0 && x + 3 <= b) { *(uint32_t*)(row + ((x >> 4) << 7) + (x & 15)) = 0x01010101u * (uint32_t)code; x += 4; }
-                else { row[((x >> 4) << 7) + (x & 15)] = (uint8_t)code; x += 1; }
+                const int xb = (x & (BEV_DYN_DIM - 1)) >> 4;
+                if ((x & 3) == 0 && x + 3 <= b) { *(uint32_t*)(row + (xb << 7) + (x & 15)) = 0x01010101u * (uint32_t)code; x += 4; }
+                else { row[(xb << 7) + (x & 15)] = (uint8_t)code; x += 1; }
             }
         }
         const int cx0 = max(minx, 0), cx1 = min(maxx, WIN - 1), cy0 = max(miny, 0), cy1 = min(miny + nrows - 1, WIN - 1);
@@ -461,6 +468,8 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
             ly0 = min(ly0, __shfl_xor(ly0, o)); ly1 = max(ly1, __shfl_xor(ly1, o));
         }
         if (lane == 0) { out[OFF_LIVE_X] = lx0; out[OFF_LIVE_X + 1] = lx1; out[OFF_LIVE_Y] = ly0; out[OFF_LIVE_Y + 1] = ly1; }
+        // the torus holds the drawn boxes without aliasing only while the box around them fits into it
+        if (lx0 <= lx1 && (lx1 - lx0 >= BEV_DYN_DIM || ly1 - ly0 >= BEV_DYN_DIM)) dyn_bad = 1;
     }
     if (lane == 0) {
         out[OFF_MAP + M_DIRTY_X0] = dirty_x0; out[OFF_MAP + M_DIRTY_X1] = dirty_x1;
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(BEV_WAVES * 64, LEGACY ? 4 : BEV_OCC) void k_bev_im
             const uint32_t sp = ((unsigned)r < (unsigned)v_nrows) ? tabs[TAB_ROWS + r] : SPAN_EMPTY;
             did = (x + 1 >= (int)(sp & 0xffff) && x + 1 <= (int)(sp >> 16)) ? 4 : 0;
         }
-        if (traj_on) {
+        if (traj_on && x >= dirty_x0 && x <= dirty_x1 && y >= dirty_y0 && y <= dirty_y1) {      // inside the box around the drawn boxes
             const int c = dynl[dyn_byte(x, y)];
             int age = code_new - c;
             age += age < 0 ? DYN_MOD : 0;

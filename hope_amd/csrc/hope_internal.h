@@ -60,7 +60,8 @@ struct RsParams {
 constexpr int BEV_IMG = HOPE_IMG_SIZE;
 constexpr int BEV_TRAJ_LEN = HOPE_TRAJ_RENDER_LEN;
 constexpr int BEV_LAYER_ROWS = 512, BEV_LAYER_STRIDE = 128;   // 500 x 500 world pixels, 4 per byte, tiled in 32 x 16 pixel blocks of 128 bytes: 16 x 32 blocks = 64 KiB per scene
-constexpr size_t BEV_DYN_BYTES = 256 * 1024;   // trajectory layer: 500 x 500 world pixels, one byte each, tiled in 16 x 8 pixel blocks of 128 bytes (32 x 64 blocks)
+constexpr int BEV_DYN_DIM = 256;               // trajectory layer: a TORUS of 256 x 256 world pixels (pixel (x, y) lives at (x mod 256, y mod 256)), one byte each,
+constexpr size_t BEV_DYN_BYTES = (size_t)BEV_DYN_DIM * BEV_DYN_DIM;   // tiled in 16 x 8 pixel blocks of 128 bytes (16 x 32 blocks): 64 KiB per scene (round 3: the whole 500 x 500 surface, 256 KiB)
 constexpr int BEV_SCENE_INTS = 16 + (3 + BEV_TRAJ_LEN) * 16 + (2 + BEV_TRAJ_LEN) * 64;   // k_bev_prep's per-scene scratch
 struct BevParams {
     int n, max_obst;

@@ -270,3 +270,82 @@ def test_image_trajectory_layer_over_a_long_episode():
             checked += 1
     assert pushes.max() > 200 and checked > 60, (pushes.max(), checked)
     env.close()
+
+
+def test_image_trajectory_torus_falls_back_when_the_drawn_boxes_span_more_than_256_px():
+    """The trajectory layer is a 256 x 256 px torus (hope_bev.hip): twenty consecutive boxes of a car that drives straight at full
+    speed span 19 x 15 px + a box = up to ~345 px, more than the torus can hold without aliasing -- the episode must then switch to
+    the exact per-tile raster.  Empty 80 m lots, cars driving straight (and diagonally, both axes) for 40 steps at +-2.5 m/s from
+    poses all over the surface, plus slow ones that stay on the layer: every uint8 equal to the oracle's on every step."""
+    from hope_amd.scenes import Scene
+    rng = np.random.default_rng(5)
+    scenes = []
+    heads = [0.0, np.pi / 2, np.pi / 4, -3 * np.pi / 4, np.pi, 0.3, -1.2, 2.5]
+    for k in range(32):
+        h = heads[k % len(heads)]
+        # the map box decides the surface's offset; start in the middle so that 40 steps of 1.25 m stay inside the 41.6 m surface
+        c = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5)])
+        start = np.array([c[0] - 18 * np.cos(h), c[1] - 18 * np.sin(h), h])
+        dest = np.array([c[0] + 19 * np.cos(h + 1.3), c[1] + 19 * np.sin(h + 1.3), h + 0.7])
+        far = np.array([[[60.0, 60.0], [61.0, 60.0], [61.0, 61.0], [60.0, 61.0]]])                    # one obstacle out of the way
+        bbox = np.array([min(start[0], dest[0]) - 25, max(start[0], dest[0]) + 25, min(start[1], dest[1]) - 25, max(start[1], dest[1]) + 25])
+        scenes.append(Scene(start=start, dest=dest, bbox=np.round(bbox), verts=far, nvert=np.array([4], np.int32), level='Normal'))
+    env, orc = make_img_pair(scenes, max_obst=32)
+    env.reset_obs(); orc.reset_obs()
+    n = len(scenes)
+    fast = np.arange(n) % 4 != 3                     # three of four cars at full speed, the fourth crawls (stays on the layer)
+    span = 0.0
+    p0 = orc.pose.copy()
+    for it in range(40):
+        act = np.stack([np.zeros(n), np.where(fast, 1.0, 0.15) * np.where((np.arange(n) // 8) % 2 == 0, 1.0, -1.0)], 1)
+        env.step(torch.from_numpy(act).to(env.device))
+        orc.step(act)
+        assert_images_equal(env, orc, f'step {it}')
+        span = max(span, float(np.abs(orc.pose[:, :2] - p0[:, :2]).max()))
+    assert span * 12 > 300, span                      # some car did move more than the torus is wide
+    env.close()
+
+
+def test_gpu_image_obeys_the_analytic_invariants_of_the_reference_geometry():
+    """Row f-1: the HIP image itself -- not only its equality with the restated renderer -- is anchored to what the
+    reference's code prescribes: over 3 x 256 random scenes the vehicle / dest / obstacle pixels sit within 1 px of
+    31.5 + R(heading) K (P - C) / 4, keep their area at 3 px/m, colours are convex combinations of the palette and the
+    background is exactly (0, 0, 0); after driving, the centre shows the newest trajectory colour.  tests/image_invariants.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import image_invariants as I
+    from hope_amd import ParkingBatch
+    rng = np.random.default_rng(12)
+    n = 256
+    seen = {'dest': 0, 'obstacle': 0}
+    for kind in ('vehicle', 'dest', 'obstacle'):
+        made = [I.make_scene(rng, kind) for _ in range(n)]
+        env = ParkingBatch(n, 32, obs_dtype=torch.float64, action_dtype=torch.float64, image=True)
+        env.set_scenes(np.arange(n), [m[0] for m in made])
+        env.reset_obs()
+        torch.cuda.synchronize()
+        imgs = env.img.cpu().numpy()
+        for k, (sc, info) in enumerate(made):
+            what = f'{kind} {k}'
+            if kind == 'vehicle':
+                I.check_vehicle_only(imgs[k], what)
+            elif kind == 'dest':
+                seen['dest'] += I.check_dest(imgs[k], sc.start, info, what) is not None
+            else:
+                seen['obstacle'] += I.check_obstacle(imgs[k], sc.start, info, what) is not None
+        if kind == 'vehicle':
+            # three steps straight ahead: the vehicle box is the newest trajectory box -> TRAJ_COLORS[-1] at the centre, and the
+            # trail lies BEHIND the car (towards - col), nothing ahead of the nose
+            for _ in range(3):
+                env.step(torch.tensor([[0.0, 0.6]] * n, dtype=torch.float64, device=env.device))
+            torch.cuda.synchronize()
+            imgs = env.img.cpu().numpy()
+            moved = (env.pose.cpu().numpy()[:, :2] != np.array([m[0].start[:2] for m in made])).any(axis=1)
+            assert moved.all()
+            for k in range(n):
+                assert tuple(imgs[k][:, 31, 31]) == I.TRAJ_NEWEST and tuple(imgs[k][:, 32, 32]) == I.TRAJ_NEWEST, k
+                assert not imgs[k][:, 22:42, 42:54].any(), k                # right ahead of the nose (7 px + borders): empty
+                assert imgs[k][:, 29:35, 14:24].any(), k                    # behind: the older boxes / the start outline
+        env.close()
+    assert seen['dest'] > 200 and seen['obstacle'] > 200, seen

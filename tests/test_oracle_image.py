@@ -268,3 +268,25 @@ def test_image_oracle_regression_hashes():
     assert got == ['878a38e87d132f13373469c5b16a352e264e6d4eb888a5210b0cfa508aa9a728',
                    '65a611dc552bdb5983c4a2be71000d95f24acb3c5848894a31d4b891a1cc04e1',
                    'e55e0297f0dcf6c578c36af1335e12f65f406d1e09bcebafb7e065ca6ea58a7c']
+
+
+def test_oracle_image_obeys_the_analytic_invariants_of_the_reference_geometry():
+    """Row f-1's statistical anchor: 3 x 200 random scenes (vehicle alone / dest box in view / one obstacle in view); the rendered
+    shapes sit where car_parking_base.py:139-147, :322-346 put them (centroid within 1 px of 31.5 + R(heading) K (P - C) / 4), keep
+    their area at 3 px/m (- 5 % .. + 16 %: filled polygons include their border pixels), the vehicle is centred with its nose to
+    + col, pixels are convex combinations of the palette, the background is exactly (0, 0, 0).  tests/image_invariants.py."""
+    import image_invariants as I
+    rng = np.random.default_rng(11)
+    seen = {'dest': 0, 'obstacle': 0}
+    for kind in ('vehicle', 'dest', 'obstacle'):
+        for k in range(200):
+            sc, info = I.make_scene(rng, kind)
+            img = O.bev_image(sc.verts, sc.nvert, sc.start, sc.dest, sc.bbox, sc.start, sc.start[None])
+            what = f'{kind} {k}'
+            if kind == 'vehicle':
+                I.check_vehicle_only(img, what)
+            elif kind == 'dest':
+                seen['dest'] += I.check_dest(img, sc.start, info, what) is not None
+            else:
+                seen['obstacle'] += I.check_obstacle(img, sc.start, info, what) is not None
+    assert seen['dest'] > 150 and seen['obstacle'] > 150, seen
