@@ -435,9 +435,12 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
         sp_out = sp; o_miny = miny; o_nrows = min(nrows, TAB_ROWS); o_minx = minx; o_maxx = maxx; o_simple = simple;
     };
     const unsigned long long needm = __ballot(need);
+    bool veh_simple = true;
     for (unsigned long long mask = needm & 7ull; mask; mask &= mask - 1) {   // start, dest, vehicle
         uint32_t sp; int a_, b_, c_, d_; bool e_;
-        do_box(__builtin_ctzll(mask), sp, a_, b_, c_, d_, e_);
+        const int l_ = __builtin_ctzll(mask);
+        do_box(l_, sp, a_, b_, c_, d_, e_);
+        if (l_ == 2) veh_simple = e_;
     }
     // trajectory entries, oldest first: the live ones that already have their tables when the layer was cleared, then the new ones
     const int e_first = max(traj_len - BEV_TRAJ_LEN, 0);
@@ -477,6 +480,10 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
         out[OFF_MAP + M_DYN_BAD] = dyn_bad; out[OFF_MAP + M_DYN_CODE] = dyn_code(max(traj_len - 1, 0));
     }
     if (lane == 0) {
+        // scenes the raster-free launch of k_bev_image cannot render (its `legacy` test, same inputs): queued for the other launch,
+        // which strides over this list instead of starting a workgroup per scene only to find nothing to do
+        const bool legacy = dyn_bad || (!(p.debug & 4) && !veh_hidden && !veh_simple) || (p.debug & 32);
+        if (legacy) p.legacy_list[1 + atomicAdd(&p.legacy_list[0], 1)] = scene;
         p.traj_valid[scene] = traj_len;
         if (p.layer_valid[scene] == 0) {                      // a new map since the layer was built: queue the scene for k_bev_static
             p.layer_valid[scene] = 1;
@@ -600,18 +607,14 @@ __device__ __forceinline__ int tile_of(int wave, int it) {
 #endif
 constexpr int CACHE_SLOT = 28 * 128;           // layer blocks of one tile's window (4 x 7 at most)
 template <bool LEGACY>
-__global__ __launch_bounds__(BEV_WAVES * 64, LEGACY ? 4 : BEV_OCC) void k_bev_image(BevParams p) {
+__device__ __forceinline__ void bev_render_scene(const BevParams& p, const int scene, uint8_t* lds_raw) {
     // LDS: palette (128 B) | span tables shared by the workgroup's waves (LEGACY: all, 5.6 KB; else dest + vehicle) | per wave:
     // LEGACY the window (8.3 KB + 72), else the block cache
-    extern __shared__ __align__(16) uint8_t lds_raw[];
     uint32_t* pal = (uint32_t*)lds_raw;
     uint32_t* tabs = pal + 32;                                               // [N_TAB][TAB_ROWS]
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     constexpr int SLOT = LEGACY ? FB_SLOT : CACHE_SLOT, SLOT_BYTES = LEGACY ? FB_BYTES : CACHE_SLOT;
     uint8_t* fb = lds_raw + 32 * sizeof(uint32_t) + (LEGACY ? N_TAB : 2) * TAB_ROWS * sizeof(uint32_t) + wave * SLOT;   // (LEGACY: + 64 dummy bytes, fill_span)
-    const int scene = scene_of_block(blockIdx.x, p.n);
-    // k_bev_static (the launch before this one) has consumed the list of stale layers: it starts empty for the next image
-    if (blockIdx.x == 0 && threadIdx.x == 0) p.rebuild[0] = 0;
     if (scene >= p.n) return;
     if (p.active && !p.active[scene]) return;
     const int* scr = p.scratch + (size_t)scene * BEV_SCENE_INTS;
@@ -887,6 +890,25 @@ __global__ __launch_bounds__(BEV_WAVES * 64, LEGACY ? 4 : BEV_OCC) void k_bev_im
     }
 }
 
+template <bool LEGACY>
+__global__ __launch_bounds__(BEV_WAVES * 64, LEGACY ? 4 : BEV_OCC) void k_bev_image(BevParams p) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    if (!LEGACY) {
+        // k_bev_static and the per-tile-raster launch (the launches before this one) have consumed their lists: both start empty
+        // for the next image
+        if (blockIdx.x == 0 && threadIdx.x == 0) { p.rebuild[0] = 0; p.legacy_list[0] = 0; }
+        bev_render_scene<false>(p, scene_of_block(blockIdx.x, p.n), lds_raw);
+    } else {
+        // the scenes k_bev_prep queued for the per-tile raster (normally none): a small grid strides over the list
+        const int32_t* ll = p.legacy_list;
+        const int count = ll[0];
+        for (int i = blockIdx.x; i < count; i += gridDim.x) {
+            bev_render_scene<true>(p, ll[1 + i], lds_raw);
+            __syncthreads();                                                  // (the next scene reuses the LDS)
+        }
+    }
+}
+
 }  // namespace
 
 size_t bev_lds_bytes(bool legacy) {
@@ -912,8 +934,10 @@ hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer*
     if (timer) timer->end(stream);
     const dim3 grid(p.n), block(BEV_WAVES * WAVE);
     if (timer) timer->begin(HOPE_K_IMAGE, stream);
+    // (scenes with a box that is not a plain car box, or whose drawn boxes outgrew the trajectory torus: none in practice; first,
+    // because the other launch empties the list)
+    hipLaunchKernelGGL(k_bev_image<true>, dim3(std::min(p.n, 1024)), block, bev_lds_bytes(true), stream, p);
     hipLaunchKernelGGL(k_bev_image<false>, grid, block, bev_lds_bytes(false), stream, p);
-    hipLaunchKernelGGL(k_bev_image<true>, grid, block, bev_lds_bytes(true), stream, p);      // (scenes with a box that is not a plain car box: none in practice)
     if (timer) timer->end(stream);
     return hipGetLastError();
 }

@@ -57,6 +57,7 @@ struct hope_env {
     uint8_t* bev_layer = nullptr;   // HOPE_F_IMAGE: [n][64 KiB] the static layer, 2 bits per pixel, tiled
     uint8_t* bev_dyn = nullptr;     // HOPE_F_IMAGE: [n][256 KiB] the trajectory layer, one byte per pixel, tiled
     int32_t* bev_list = nullptr;    // HOPE_F_IMAGE: [1 + n] count + scenes whose layer must be rebuilt this step
+    int32_t* bev_legacy = nullptr;  // HOPE_F_IMAGE: [1 + n] count + scenes for the per-tile raster launch of k_bev_image
     int* bev_scratch = nullptr;    // HOPE_F_IMAGE: [n][BEV_SCENE_INTS]
     // per tile class (0: n_obst <= SMALL_TILE, 1: larger) dense scene lists; classes are static between set_scenes calls
     int32_t* cls_list[2] = {nullptr, nullptr};
@@ -529,6 +530,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         ALLOC(h->bev_layer, N * (size_t)BEV_LAYER_ROWS * BEV_LAYER_STRIDE);
         ALLOC(h->bev_dyn, N * BEV_DYN_BYTES);
         ALLOC(h->bev_list, (N + 1) * sizeof(int32_t));
+        ALLOC(h->bev_legacy, (N + 1) * sizeof(int32_t));
         ALLOC(h->bev_scratch, N * BEV_SCENE_INTS * sizeof(int));
     }
 #undef ALLOC
@@ -539,6 +541,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         HIPCHK(hipMemset(h->layer_valid, 0, N * sizeof(int32_t)));
         HIPCHK(hipMemset(h->bev_dyn, 0, N * BEV_DYN_BYTES));
         HIPCHK(hipMemset(h->bev_list, 0, (N + 1) * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->bev_legacy, 0, (N + 1) * sizeof(int32_t)));
         HIPCHK(hipMemset(h->bev_scratch, 0, N * BEV_SCENE_INTS * sizeof(int)));
     }
     HIPCHK(hipMemset(h->n_obst, 0, N * sizeof(int32_t)));
@@ -656,7 +659,7 @@ int hope_env_destroy(hope_env_t* h) {
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -994,6 +997,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         b.n = h->n; b.max_obst = h->max_obst; b.verts = h->verts; b.n_obst = h->n_obst; b.scene_c = h->scene_c;
         b.state = h->state; b.traj = h->traj; b.traj_len = h->traj_len; b.traj_valid = h->traj_valid; b.scratch = h->bev_scratch; b.img = out->img;
         b.layer = h->bev_layer; b.layer_valid = h->layer_valid; b.rebuild = h->bev_list; b.dyn = h->bev_dyn;
+        b.legacy_list = h->bev_legacy;
         // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
         b.active = active;
         b.debug = (stages >> 12) & 0xF;

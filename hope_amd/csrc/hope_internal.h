@@ -75,6 +75,7 @@ struct BevParams {
     uint8_t* layer;           // [n][BEV_LAYER_ROWS][BEV_LAYER_STRIDE] static layer (obstacles, start outline, dest): 2 bits per pixel
     uint8_t* dyn;             // [n][BEV_DYN_BYTES] trajectory layer: per pixel the code of the NEWEST trajectory box that covers it (0: none)
     int32_t* layer_valid;     // [n] the layer matches the scene's map
+    int32_t* legacy_list;     // [1 + n] count + the scenes k_bev_prep queued for the per-tile raster launch of k_bev_image
     int32_t* rebuild;         // [1 + n] count, then the scenes k_bev_prep found with a stale layer (k_bev_static rebuilds them)
     int* scratch;             // [n][BEV_SCENE_INTS] map + box headers + span tables (k_bev_prep -> k_bev_image)
     const uint8_t* active;    // [n] or null
