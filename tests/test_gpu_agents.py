@@ -262,3 +262,32 @@ def test_rollout_with_deferred_rs_join_takes_the_same_actions():
         assert bool(a[4].any())                        # some scenes were replaying a Reeds-Shepp path
     finally:
         del os.environ['HOPE_SPLIT_MIN']
+
+
+def test_bench_as_eight_ranks_of_8192_scenes_sharing_the_gpu():
+    """the multi-GPU run is the driver's to launch; what can be exercised on a 1-GPU box is everything but RCCL
+    itself -- `bench.py --gpus 8` under torch.distributed.run with the launch line the driver uses, BASELINE config 4's exact shape
+    (65 536 scenes strong-scaled = 8 192 per rank), all ranks on cuda:0 over gloo (HOPE_BENCH_SHARE_GPU=1).  The line must account
+    for every rank (ranks, the all-reduce of ones, per-rank step times, the host-core share each rank pinned itself to)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HOPE_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 36500 + os.getpid() % 2000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--scenes', '65536',
+           '--steps', '10', '--warmup', '3', '--preroll', '20', '--no-cpu-baseline', '--witness', '0', '--repeat-passes', '0']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.strip().split('\n') if ln.startswith('{')][-1]
+    d = json.loads(line)
+    print(json.dumps({k: d[k] for k in ('value', 'ms_per_step', 'n_gpus', 'ranks', 'rccl_check', 'rank_ms_per_step', 'host')}))
+    assert d['n_gpus'] == 8 and d['ranks'] == 8 and d['scaling'] == 'strong'
+    assert d['config']['scenes_per_gpu'] == 8192
+    assert d['rccl_check']['ok'] and d['rccl_check']['allreduce_of_ones'] == 8.0 and d['rccl_check']['backend'] == 'gloo'
+    assert len(d['rank_ms_per_step']['all']) == 8 and d['rank_ms_per_step']['max'] >= d['rank_ms_per_step']['min'] > 0
+    assert abs(d['value'] - 65536 * 10 / (d['ms_per_step'] * 10 * 1e-3)) < 1e-3 * d['value']
+    # every rank pinned itself to its share of the host's cores; the generator's default fan-out is that share
+    assert d['host']['pinned'] and d['host']['cpus_this_rank'] <= max(1, d['host']['cpus_node'] // 8 + 1)
+    assert d['host']['generator_threads'] == d['host']['cpus_this_rank']
