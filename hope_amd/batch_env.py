@@ -49,18 +49,25 @@ class ParkingBatch:
         L.check(self.lib.hope_env_upload_tables(self.h, ds.ctypes.data, hb.ctypes.data, ab.ctypes.data),
                 'hope_env_upload_tables')
         n, dev, od = self.n, self.device, obs_dtype
-        self.lidar = torch.zeros((n, L.LIDAR_NUM), dtype=od, device=dev)
-        self.action_mask = torch.zeros((n, L.N_ACTION), dtype=od, device=dev)
-        self.target = torch.zeros((n, L.TARGET_DIM), dtype=od, device=dev)
-        self.reward = torch.zeros(n, dtype=od, device=dev)
-        self.reward_info = torch.zeros((n, 5), dtype=od, device=dev)
-        self.status = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.pose = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-        self.rs_word = torch.full((n, 8), -1, dtype=torch.int8, device=dev)
-        self.rs_lengths = torch.zeros((n, L.RS_MAX_SEG), dtype=od, device=dev)
-        # obs['img'] * 255 as uint8, channel-first (env_wrapper.py:53-54); the reference's float image is img / 255
-        self.img = torch.zeros((n, L.IMG_CHANNELS, L.IMG_SIZE, L.IMG_SIZE), dtype=torch.uint8, device=dev) if image else None
+        # every output lives in ONE device arena (typed views at 256-byte aligned offsets): `download_outputs()` brings all of a
+        # step's results to the host with a single copy -- what the N = 1 look-alike classes (hope_amd/env.py) need per step
+        spec = [('lidar', (n, L.LIDAR_NUM), od), ('action_mask', (n, L.N_ACTION), od), ('target', (n, L.TARGET_DIM), od),
+                ('reward', (n,), od), ('reward_info', (n, 5), od), ('status', (n,), torch.int32), ('done', (n,), torch.uint8),
+                ('pose', (n, 3), torch.float64), ('rs_word', (n, 8), torch.int8), ('rs_lengths', (n, L.RS_MAX_SEG), od)]
+        if image:       # obs['img'] * 255 as uint8, channel-first (env_wrapper.py:53-54); the reference's float image is img / 255
+            spec.append(('img', (n, L.IMG_CHANNELS, L.IMG_SIZE, L.IMG_SIZE), torch.uint8))
+        off, self._layout = 0, {}
+        for name, shape, dt in spec:
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            self._layout[name] = (off, nbytes, shape, dt)
+            off = (off + nbytes + 255) & ~255
+        self._arena = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self._arena_host = None
+        for name, (o, nbytes, shape, dt) in self._layout.items():
+            setattr(self, name, self._arena[o:o + nbytes].view(dt).view(shape))
+        self.rs_word.fill_(-1)
+        if not image:
+            self.img = None
         self._act_buf = torch.zeros((n, 2), dtype=action_dtype, device=dev) if graph else None
         self._done_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
         # observation-only view for turnover(): the finished step's reward / status / done / RS outputs are kept
@@ -300,6 +307,17 @@ class ParkingBatch:
         you keep before stepping, as hope_amd.rollout does) when both are needed."""
         o = {'img': self.img, 'lidar': self.lidar, 'target': self.target, 'action_mask': self.action_mask}
         return {k: (v.clone() if (clone and v is not None) else v) for k, v in o.items()}
+
+    def download_outputs(self):
+        """every output of the last step on the host, through ONE device-to-host copy of the output arena into pinned memory (and one
+        stream synchronisation): {name: numpy view}.  The views alias the pinned buffer: valid until the next call."""
+        if self._arena_host is None:
+            self._arena_host = torch.empty(self._arena.shape, dtype=torch.uint8, pin_memory=True)
+        self._arena_host.copy_(self._arena, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        hb = self._arena_host.numpy()
+        np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.uint8: np.uint8, torch.int8: np.int8}
+        return {name: hb[o:o + nbytes].view(np_dt[dt]).reshape(shape) for name, (o, nbytes, shape, dt) in self._layout.items()}
 
     # -- state -------------------------------------------------------------------------------------
     def download_state(self):

@@ -198,19 +198,22 @@ class CarParking:
         self._batch.set_scenes([0], [scene])
         return self.step()[0]
 
+    def _obs_from(self, o, img_chw):
+        """the observation dict from one `ParkingBatch.download_outputs()` snapshot (copies: the snapshot is reused)"""
+        obs = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
+        if self.use_img_observation:                       # processed_img / 255.0, (W, H, C)  observation_processor.py:14
+            im = o['img'][0] if img_chw else o['img'][0].transpose(1, 2, 0)
+            obs['img'] = im.astype(np.float64) / 255.0
+        if self.use_lidar_observation:
+            obs['lidar'] = o['lidar'][0].copy()
+        if self.use_action_mask:
+            obs['action_mask'] = o['action_mask'][0].copy()
+        obs['target'] = o['target'][0].copy()
+        return obs
+
     def _last_reset_obs(self, img_chw):
         """the observation of the reset just done, in the wrapper's layout (buffers still hold it: no second launch)"""
-        b = self._batch
-        obs = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
-        if self.use_img_observation:
-            im = b.img[0] if img_chw else b.img[0].permute(1, 2, 0)
-            obs['img'] = im.cpu().numpy().astype(np.float64) / 255.0
-        if self.use_lidar_observation:
-            obs['lidar'] = b.lidar[0].cpu().numpy()
-        if self.use_action_mask:
-            obs['action_mask'] = b.action_mask[0].cpu().numpy()
-        obs['target'] = b.target[0].cpu().numpy()
-        return obs
+        return self._obs_from(self._batch.download_outputs(), img_chw)
 
     # -- the step ---------------------------------------------------------------------------------------
     def step(self, action=None):
@@ -232,8 +235,8 @@ class CarParking:
             steer, speed = float(np.clip(act[0], *VALID_STEER)), float(np.clip(act[1], *VALID_SPEED))
         else:
             b.reset_obs()
-        torch.cuda.synchronize(b.device)
-        pose = b.pose[0].cpu().numpy()
+        o = b.download_outputs()                            # ONE packed device-to-host copy + one synchronisation per step
+        pose = o['pose'][0]
         self.t += 1
         prev = self.vehicle.state.get_pos()
         self.vehicle.state = State([pose[0], pose[1], pose[2], speed, steer])
@@ -243,26 +246,17 @@ class CarParking:
         # nothing -- the rule the device-side trajectory ring follows.  (A zero-speed action keeps its sub-steps.)
         if action is not None and (self.vehicle.state.get_pos() != prev or speed == 0):
             self.vehicle.trajectory.append(self.vehicle.state)
-        observation = {'img': None, 'lidar': None, 'target': None, 'action_mask': None}
-        if self.use_img_observation:                       # processed_img / 255.0, (W, H, C)  observation_processor.py:14
-            im = b.img[0] if img_chw else b.img[0].permute(1, 2, 0)
-            observation['img'] = im.cpu().numpy().astype(np.float64) / 255.0
-        if self.use_lidar_observation:
-            observation['lidar'] = b.lidar[0].cpu().numpy()
-        if self.use_action_mask:
-            observation['action_mask'] = b.action_mask[0].cpu().numpy()
-        observation['target'] = b.target[0].cpu().numpy()
-        status = Status(int(b.status[0].item()))
-        ri = b.reward_info[0].cpu().numpy()
-        reward_info = OrderedDict(zip(REWARD_WEIGHT.keys(), (float(v) for v in ri)))
+        observation = self._obs_from(o, img_chw)
+        status = Status(int(o['status'][0]))
+        reward_info = OrderedDict(zip(REWARD_WEIGHT.keys(), (float(v) for v in o['reward_info'][0])))
         info = OrderedDict({'reward_info': reward_info, 'path_to_dest': None})
-        w = b.rs_word[0].cpu().numpy()
+        w = o['rs_word'][0]
         if w[6]:
             n = int(w[5])
-            info['path_to_dest'] = PATH(b.rs_lengths[0, :n].cpu().numpy(), [TYPE_NAMES[int(c)] for c in w[:n]],
+            info['path_to_dest'] = PATH(o['rs_lengths'][0, :n].copy(), [TYPE_NAMES[int(c)] for c in w[:n]],
                                         self.vehicle.state.get_pos())
         # what the wrapper adds on top (env_wrapper.py:10-35,80) leaves the kernels ready-made: k_post's shaped reward and done
-        self._wrapped = (float(b.reward[0].item()), bool(b.done[0].item()))
+        self._wrapped = (float(o['reward'][0]), bool(o['done'][0]))
         return observation, reward_info, status, info
 
     def render(self, mode='human'):
