@@ -62,6 +62,10 @@ def parse():
     ap.add_argument('--policy-amp', action='store_true',
                     help='--policy hope --image: run the image encoders under bf16 autocast + channels_last (stock PyTorch levers; '
                          'changes the policy\'s numerics, reported next to the fp32 default)')
+    ap.add_argument('--policy-fast', default='off', choices=['off', 'graph', 'amp', 'graph+amp'],
+                    help='--policy hope: stock levers on the inference forward of the rollout -- graph: captured device graph '
+                         '(same fp32 results); amp: bf16 autocast on the token mixer and embedding MLPs (changes the policy\'s '
+                         'numerics); reported next to the fp32 eager default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scenes', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=12)
@@ -219,6 +223,8 @@ def main():
             agent = A.BatchedSAC(device=dev, use_img=args.image, batch_size=args.mini_batch)
             trainer = SACTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, learn=args.algo == 'sac',
                                  fresh_scenes=fresh, pool_refresher=refresher, defer_rs=defer)
+        if args.policy_fast != 'off':
+            agent.enable_fast_policy(graph='graph' in args.policy_fast, amp='amp' in args.policy_fast)
         if args.policy_amp:
             from hope_amd.policy import set_img_amp
             for net in (getattr(agent, 'actor', None), getattr(agent, 'critic', None), getattr(agent, 'critic_target', None)):
@@ -458,7 +464,8 @@ def main():
                 {'rollout': ', inference only)', 'sac': ' + SAC updates)', 'ppo': ' + PPO updates)'}[args.algo]
             result['config']['workload'] = result['config']['workload'].replace('random actions U[-1,1]^2', 'actions from the policy / RS replay')
             result['config'].update({'policy': 'HopeNet (MultiObsEmbedding shape), random init', 'algo': args.algo,
-                                     'actor_params': count_parameters(trainer.agent.actor), 'use_img': bool(args.image),
+                                     'actor_params': count_parameters(trainer.agent.actor), 'use_img': bool(args.image), 'policy_fast': args.policy_fast,
+                                     'policy_graph_replays': (getattr(trainer.agent, '_fast', None) or {}).get('replays'),
                                      'horizon': args.horizon, 'mini_batch': args.mini_batch,
                                      'mini_epoch': args.mini_epoch if args.algo == 'ppo' else None,
                                      'updates_in_run': trainer.updates, 'allreduce_bytes_total': trainer.agent.allreduce_bytes,

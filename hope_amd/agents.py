@@ -72,9 +72,47 @@ class _AgentCommon:
         if self.state_norm is not None:
             self.state_norm.update({'lidar': next_obs['lidar'], 'target': next_obs['target']})
 
+    # ---- stock-PyTorch levers for the INFERENCE forward (rollout side; off by default; bench.py --policy-fast) -------------
+    def enable_fast_policy(self, graph=True, amp=False):
+        """graph: replay the actor's inference forward as one captured device graph (static batch: launch overhead of its ~100
+        small kernels disappears; same fp32 arithmetic, same results).  amp: run the token mixer and the embedding MLPs under
+        bf16 autocast (the image encoder's convolutions stay fp32: `policy.set_img_amp` is the separate lever) -- changes the
+        policy's numerics, never the env's.  Updates keep the plain fp32 path."""
+        self._fast = {'graph': bool(graph), 'amp': bool(amp), 'g': None, 'in': None, 'out': None, 'replays': 0, 'captures': 0}
+
+    def _actor_infer(self, nobs):
+        f = getattr(self, '_fast', None)
+        if f is not None and f['amp'] and next(self.actor.parameters()).is_cuda:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                return self.actor(nobs).float()
+        return self.actor(nobs)
+
     @torch.no_grad()
     def policy_mean(self, nobs):
-        return torch.clamp(self.actor(nobs), -1, 1)                              # ppo_agent.py:137
+        f = getattr(self, '_fast', None)
+        if f is None or not f['graph'] or not nobs['lidar'].is_cuda:
+            return torch.clamp(self._actor_infer(nobs), -1, 1)                   # ppo_agent.py:137
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in nobs.items())
+        if f['g'] is None or f['sig'] != sig:                                    # (re)capture for this batch shape
+            f['in'] = {k: torch.empty_like(v) for k, v in nobs.items()}
+            for k, v in nobs.items():
+                f['in'][k].copy_(v)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                                               # warm-up outside the capture (lazy inits)
+                    torch.clamp(self._actor_infer(f['in']), -1, 1)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                f['out'] = torch.clamp(self._actor_infer(f['in']), -1, 1)
+            f['g'], f['sig'] = g, sig
+            f['captures'] += 1
+        for k, v in nobs.items():
+            f['in'][k].copy_(v)
+        f['g'].replay()
+        f['replays'] += 1
+        return f['out'].clone()
 
     @torch.no_grad()
     def act(self, obs, use_mask=True, generator=None, planned=None, executing=None, plan_fn=None):

@@ -291,3 +291,25 @@ def test_bench_as_eight_ranks_of_8192_scenes_sharing_the_gpu():
     # every rank pinned itself to its share of the host's cores; the generator's default fan-out is that share
     assert d['host']['pinned'] and d['host']['cpus_this_rank'] <= max(1, d['host']['cpus_node'] // 8 + 1)
     assert d['host']['generator_threads'] == d['host']['cpus_this_rank']
+
+
+def test_graph_captured_policy_forward_equals_the_eager_one():
+    """the rollout's inference forward replayed as one captured device graph (agents.enable_fast_policy)
+    is the same fp32 arithmetic -- identical means for changing inputs, recapture on a new batch shape; the bf16-autocast variant
+    stays within bf16's resolution of the fp32 mean (it is reported by bench.py --policy-fast, never the default)."""
+    from hope_amd import agents as A
+    torch.manual_seed(1)
+    ag = A.BatchedPPO(device='cuda', use_img=False)
+    ref = A.BatchedPPO(device='cuda', use_img=False)
+    ref.actor.load_state_dict(ag.actor.state_dict())
+    ag.enable_fast_policy(graph=True, amp=False)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    for n in (512, 512, 512, 96):
+        nobs = {'lidar': torch.rand((n, 120), device='cuda', generator=g), 'target': torch.rand((n, 5), device='cuda', generator=g),
+                'action_mask': torch.rand((n, 42), device='cuda', generator=g)}
+        a, b = ag.policy_mean(nobs), ref.policy_mean(nobs)
+        assert torch.equal(a, b), n
+    assert ag._fast['captures'] == 2 and ag._fast['replays'] == 4
+    ag.enable_fast_policy(graph=True, amp=True)
+    a = ag.policy_mean(nobs)
+    assert float((a - b).abs().max()) < 0.05 and not torch.equal(a, b)
