@@ -123,7 +123,8 @@ struct hope_env {
     static constexpr int MAX_CHAINS = 8;                    // launch chains in flight: tile classes x HOPE_CHAINS sub-lists
     int sub_chains = 1;
     hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {}, ev_segs[2] = {}, ev_post[2] = {};
+    int rs_parity = 0;                                      // which of the two queue counters of a chain this step uses (pipelined steps)
     // HOPE_DEFER_RS: the chains of the last step have not been joined into the caller's stream (events ev_join[1], ev_join[RS_SIDE])
     static constexpr int RS_SIDE = 5;                       // the stream of the first chain when it may not run on the caller's
     bool rs_pending = false;
@@ -584,7 +585,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_segs[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming)); }
         // HOPE_PRIO=1 (experiment, rejected): highest stream priority for the launch chains (the critical path), lowest for
         // the observation / image streams [2], [3], [4].  Measured 0.80 -> 1.08 ms per step at 65 536 scenes: the second
         // chain's kernels then wait hundreds of microseconds between launches behind the first chain's.
@@ -646,7 +647,7 @@ int hope_env_destroy(hope_env_t* h) {
     drain_events(h);
     hipDeviceSynchronize();
     drop_graphs(h);
-    for (hipEvent_t e : {h->ev_fork, h->ev_in, h->ev_out, h->ev_step[0], h->ev_step[1]}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_fork, h->ev_in, h->ev_out, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
     for (int i = 0; i < hope_env::MAX_CHAINS; i++) {
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
         if (h->side[i]) hipStreamDestroy(h->side[i]);
@@ -848,7 +849,8 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
                         hipStream_t s, bool overlap, int has_action, LaunchTimer* tm) {
     StepParams p;
     memset(&p, 0, sizeof(p));
-    p.n = h->n; p.max_obst = h->max_obst; p.stages = stages; p.has_action = has_action;
+    static const uint32_t dbg_stages = getenv("HOPE_DEBUG_STAGES") ? (uint32_t)strtol(getenv("HOPE_DEBUG_STAGES"), nullptr, 0) : 0;   // profiling switches 0x1000 / 0x2000 (results invalid)
+    p.n = h->n; p.max_obst = h->max_obst; p.stages = stages | dbg_stages; p.has_action = has_action;
     p.hflags = h->traj ? STEP_HF_TRAJ : 0;
     p.verts = h->verts; p.obb = h->obb; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
     p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.post = h->post;
@@ -908,16 +910,50 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     const bool defer = split && (stages & HOPE_DEFER_RS) && !(h->flags & HOPE_F_GRAPH) &&
                        h->n >= (defer_min ? atoi(defer_min) : split_min ? atoi(split_min) : 32768);
     if (!defer) { int rcj = join_rs(h, s); if (rcj != HOPE_OK) return rcj; }    // (a deferred step's launches follow the unjoined ones on the same streams)
+    // PIPELINED steps (round 4; with HOPE_DEFER_RS, HOPE_PIPE=0 switches it off): each tile class runs on TWO library streams --
+    //   env stream  : k_kinematics -> k_env_step<motion> -> k_env_step<observation> -> k_post     (what the caller's stream joins)
+    //   search stream: [motion done] k_rs_compact -> k_rs_words -> k_rs_segs -> k_rs_validate      (hope_env_wait_rs / never)
+    // so that step k + 1's kinematics and motion launch do not queue behind step k's validation kernel, the longest launch of the
+    // step: they only wait for step k's k_rs_segs (the last reader of `state` / `post` on the search stream) and -- through the
+    // caller's stream -- for its observation.  The search of step k may then read obstacle tiles that step k + 1's episode
+    // turnover is rewriting: only for scenes whose episode ended in step k + 1, whose search result nobody can read any more
+    // (k_rs_compact of step k + 1 clears it, after the validation kernel, on the same stream), and all reads stay inside the
+    // scene's own tile slots.  The queue counter alternates between two words per chain (the motion launch of step k + 1 zeroes
+    // the one step k + 1 uses while step k's validation blocks are still reading theirs).
+    static const bool pipe_env = !(getenv("HOPE_PIPE") && atoi(getenv("HOPE_PIPE")) == 0);
+    const bool pipe = defer && pipe_env && n_chain == 2;
+    if (want_rs && !(h->flags & HOPE_F_GRAPH)) h->rs_parity ^= 1;
     if (fork) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         for (int i = 1; i < n_streams; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
         if (defer) HIPCHK(hipStreamWaitEvent(h->side[hope_env::RS_SIDE], h->ev_fork, 0));
     }
+    bool joined_on_caller[2] = {false, false}, post_on_rs[2] = {false, false};
     for (int i = 0; i < n_chain; i++) {
         const Chain& ch = chains[i];
         const int c = ch.c;
         hipStream_t sc = (fork && ch.st > 0) ? h->side[ch.st] : defer ? h->side[hope_env::RS_SIDE] : s;
-        int32_t* counter = h->rs_count + i;
+        int32_t* counter = h->rs_count + i + hope_env::MAX_CHAINS * h->rs_parity;
+        // two-launch form: everything the search does not wait for goes to its own stream.  (Experiment knobs: HOPE_OBS_SIDE0 / 1 =
+        // which library stream carries the observation half of chain 0 / 1, HOPE_OBS_WPC0 / 1 = its waves per CU, enforced
+        // through the LDS request.)
+        static const int obs_side[2] = {getenv("HOPE_OBS_SIDE0") ? atoi(getenv("HOPE_OBS_SIDE0")) : 3, getenv("HOPE_OBS_SIDE1") ? atoi(getenv("HOPE_OBS_SIDE1")) : 4};
+        static const int obs_wpc[2] = {getenv("HOPE_OBS_WPC0") ? atoi(getenv("HOPE_OBS_WPC0")) : 0, getenv("HOPE_OBS_WPC1") ? atoi(getenv("HOPE_OBS_WPC1")) : 0};
+        hipStream_t so = split ? h->side[std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
+        // pipelined: the env stream of the class with MORE scenes is the caller's stream itself -- its kernels are the step's critical
+        // cycle (kinematics -> motion -> observation -> the caller's next actions -> kinematics ...), and every hop between a library
+        // stream and the caller's costs that cycle 20-30 us (two hops per step: 0.648 -> 0.60 ms).  Not with the image, which
+        // runs on the caller's stream next to the observation launches.
+        static const bool pipe_on_caller = !(getenv("HOPE_PIPE_CALLER") && atoi(getenv("HOPE_PIPE_CALLER")) == 0);
+        const bool on_caller = pipe && pipe_on_caller && !(stages & HOPE_STAGE_IMG) && h->cls_count[c] >= h->cls_count[1 - c];
+        if (on_caller) so = s;
+        // ... and k_post, whose outputs the caller's stream joins too, runs at the head of the search stream instead of behind the
+        // observation launch (the search stream has slack, the env stream is the critical one)
+        static const bool post_on_search = !(getenv("HOPE_POST_SEARCH") && atoi(getenv("HOPE_POST_SEARCH")) == 0);
+        const bool post_rs = pipe && want_rs && post_on_search;
+        if (i < 2) { joined_on_caller[i] = on_caller; post_on_rs[i] = post_rs; }
+        hipStream_t sk = pipe ? so : sc;                        // the stream of the kinematics and the motion launch
+        if (pipe && !on_caller) HIPCHK(hipStreamWaitEvent(sk, h->ev_fork, 0));
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
         p.scene_list = h->cls_list[c] + ch.a;
         p.n_list = ch.b - ch.a;
@@ -926,26 +962,23 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             HIPCHK(hipStreamWaitEvent(sc, h->ev_step[0], 0));   // staggered: behind the first chain's motion launch
         if ((stages & HOPE_STAGE_MOTION) && has_action) {       // this class's sub-step poses head its chain
             dim3 kg((p.n_list + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
-            if (tm) tm->begin(HOPE_K_KINEMATICS, sc);
-            if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
-            else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, sc, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
-            if (tm) tm->end(sc);
+            if (tm) tm->begin(HOPE_K_KINEMATICS, sk);
+            if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, sk, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
+            else hipLaunchKernelGGL((k_kinematics<float>), kg, block, 0, sk, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
+            if (tm) tm->end(sk);
         }
         const dim3 grid(p.n_list);
         size_t lds = step_lds_bytes(p.tile_cap);
-        if (tm) tm->begin(HOPE_K_STEP, sc);
-        if (split) launch_env_step<1>(of64, af64, grid, block, lds, sc, p);
-        else if (step_timing && !of64 && !af64) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sc, p);
-        else launch_env_step<0>(of64, af64, grid, block, lds, sc, p);
-        if (tm) tm->end(sc);
-        if (fork && n_chain == 2 && (split || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sc));   // poses final
-        // two-launch form: everything the search does not wait for goes to its own stream.  (Experiment knobs: HOPE_OBS_SIDE0 / 1 =
-        // which library stream carries the observation half of chain 0 / 1, HOPE_OBS_WPC0 / 1 = its waves per CU, enforced
-        // through the LDS request.)
-        static const int obs_side[2] = {getenv("HOPE_OBS_SIDE0") ? atoi(getenv("HOPE_OBS_SIDE0")) : 3, getenv("HOPE_OBS_SIDE1") ? atoi(getenv("HOPE_OBS_SIDE1")) : 4};
-        static const int obs_wpc[2] = {getenv("HOPE_OBS_WPC0") ? atoi(getenv("HOPE_OBS_WPC0")) : 0, getenv("HOPE_OBS_WPC1") ? atoi(getenv("HOPE_OBS_WPC1")) : 0};
-        hipStream_t so = split ? h->side[std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
-        if (split) HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
+        // pipelined: the last step's k_rs_compact / k_rs_words / k_rs_segs (search stream) read `post` and `state`, which the motion
+        // launch rewrites
+        if (pipe) HIPCHK(hipStreamWaitEvent(sk, h->ev_segs[i], 0));
+        if (tm) tm->begin(HOPE_K_STEP, sk);
+        if (split) launch_env_step<1>(of64, af64, grid, block, lds, sk, p);
+        else if (step_timing && !of64 && !af64) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sk, p);
+        else launch_env_step<0>(of64, af64, grid, block, lds, sk, p);
+        if (tm) tm->end(sk);
+        if (fork && n_chain == 2 && (split || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sk));   // poses final
+        if (split && !pipe) HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
         // k_post BEHIND the observation half on that stream: nothing waits for its outputs before the join, the observation is the
         // long launch (0.675 -> 0.669 ms; HOPE_POST_LAST=0: the round-3 order)
         static const bool post_last = !(getenv("HOPE_POST_LAST") && atoi(getenv("HOPE_POST_LAST")) == 0);
@@ -956,16 +989,24 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             else hipLaunchKernelGGL((k_post<float>), pg, block, 0, so, p.n_list, p.scene_list, active, stages, h->scene_c, h->state, h->post, h->rs_flag, *out);
             if (tm) tm->end(so);
         };
-        if (!(split && post_last)) launch_post();
+        if (!(split && post_last) && !post_rs) launch_post();
         if (split) {
             if (tm) tm->begin(HOPE_K_STEP, so);
             const size_t lds_obs = obs_wpc[i & 1] > 0 ? std::max(lds, (size_t)((158 * 1024 / obs_wpc[i & 1]) & ~255)) : lds;
             launch_env_step<2>(of64, af64, grid, block, lds_obs, so, p);
             if (tm) tm->end(so);
-            if (post_last) launch_post();
-            HIPCHK(hipEventRecord(h->ev_join[3 + i], so));                // (the event index stays 3 + i whatever stream carries the launch)
+            if (post_last && !post_rs) launch_post();
+            if (!on_caller) HIPCHK(hipEventRecord(h->ev_join[3 + i], so));   // (the event index stays 3 + i whatever stream carries the launch)
         }
         if (!want_rs) continue;
+        if (pipe) HIPCHK(hipStreamWaitEvent(sc, h->ev_step[i], 0));  // the search stream starts behind this step's motion launch
+        if (post_rs) {
+            hipStream_t keep = so;
+            so = sc;                                                  // (launch_post launches on `so`)
+            launch_post();
+            so = keep;
+            HIPCHK(hipEventRecord(h->ev_post[i], sc));
+        }
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
         {
@@ -989,7 +1030,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         r.rs_count = counter; r.rs_list = qlist;
         r.rs_rec = h->rs_rec;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
-        HIPCHK(launch_rs_search(r, sc, tm));
+        HIPCHK(launch_rs_search(r, sc, tm, pipe ? h->ev_segs[i] : nullptr));
     }
     HIPCHK(hipGetLastError());
     if (stages & HOPE_STAGE_IMG) {
@@ -1027,7 +1068,10 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         } else
             for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
         if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
-        if (split) for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
+        if (split) for (int i = 0; i < 2; i++) {
+            if (!joined_on_caller[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
+            if (post_on_rs[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_post[i], 0));
+        }
     }
     return HOPE_OK;
 }

@@ -89,7 +89,7 @@ struct LaunchTimer {
     virtual void end(hipStream_t s) = 0;
 };
 // launches the Reeds-Shepp feasibility kernels over the scenes queued in rs_list (hope_rs.hip)
-hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer);   // one tile class
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer, hipEvent_t after_segs = nullptr);   // one tile class; after_segs: recorded behind k_rs_segs
 hipError_t rs_prof_read(unsigned long long* out /*[16]*/, int reset);   // HOPE_RS_TIMING cycle accounting
 hipError_t rs_init_tables();                                              // k_rs_validate_f's sample table, once per device (hope_env_create)
 hipError_t rs_fstat_read(unsigned long long* out /*[16]*/, int reset);    // float32-filter statistics (HOPE_RS_DEBUG & 0x4000)

@@ -1005,6 +1005,14 @@ __device__ __forceinline__ double uni_d(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// LDS ordering inside the ONE wave of a workgroup without draining the vector-memory queue (a __syncthreads() waits for vmcnt(0),
+// which would end the overlap of the tile's global_load_lds with the first word's set-up): LDS operations of a wave complete in
+// order, so the wave only has to have ISSUED its writes before the reads; the clobber keeps the compiler from moving them
+__device__ __forceinline__ void lsync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int OCC, bool TIMING, bool STATS>
 __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1043,7 +1051,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
     const int n_obst = __builtin_amdgcn_readlane(__double2hiint(r0), 0);
     const double* verts_g = p.verts + (size_t)scene * p.max_obst * 8;
-    {   // first-segment samples into LDS (in flight during the staging)
+    {   // first-segment samples into LDS (ordinary loads: requested with the record's header, they arrive together)
         const double T0 = g_rs_steps[lane], T1 = g_rs_steps[WAVE + lane], T2 = g_rs_steps[2 * WAVE + lane], T3 = g_rs_steps[3 * WAVE + lane];
         tabl[lane] = T0; tabl[WAVE + lane] = T1; tabl[2 * WAVE + lane] = T2; tabl[3 * WAVE + lane] = T3;
     }
@@ -1051,32 +1059,28 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     const float fxmin = 0.0f, fxmax = (float)(readlane_d(r0, 6) - readlane_d(r0, 5)), fymin = 0.0f, fymax = (float)(readlane_d(r0, 8) - readlane_d(r0, 7));
     const double step = RS_STEP * MAXC;
     // The float32 view of the obstacles -- vertices in that frame, their boxes, the edges' robustness flags -- was made when the
-    // scene got its map (obstacle_f32, hope_dev.h): a copy.  (Rounds 2-3 converted the float64 tile here, once per SEARCH: 26 % of
-    // the kernel's cycles, 500 wave instructions for a Dragon-Lake lot.)
+    // scene got its map (obstacle_f32, hope_dev.h).  It goes from global memory STRAIGHT INTO LDS (global_load_lds: no staging
+    // registers, and the wave does not wait): the first word's setup and its first samples are generated while the tile is in
+    // flight; `tile_wait()` below is the one place that waits for it.  (Rounds 2-3 converted the float64 tile here, once per SEARCH,
+    // with the wave stalled on the loads: 26 % of the kernel's cycles.)
     {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
         const float4* gfv = p.fverts + (size_t)scene * p.max_obst * 2;
         const float4* gfb = p.fbox + (size_t)scene * p.max_obst;
         const uint32_t* gfl = (const uint32_t*)(p.eflag + (size_t)scene * eflag_stride(p.max_obst));
         float4* lfv = (float4*)fv;
-        for (int base = 0; base < 2 * n_obst; base += 4 * WAVE) {           // four loads in flight per round
-            float4 qq[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = base + u * WAVE + lane; qq[u] = i < 2 * n_obst ? gfv[i] : make_float4(0, 0, 0, 0); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = base + u * WAVE + lane; if (i < 2 * n_obst) lfv[i] = qq[u]; }
-        }
-        for (int base = 0; base < n_obst; base += 2 * WAVE) {
-            const int i0 = base + lane, i1 = base + WAVE + lane;
-            const float4 b0 = i0 < n_obst ? gfb[i0] : make_float4(0, 0, 0, 0), b1 = i1 < n_obst ? gfb[i1] : make_float4(0, 0, 0, 0);
-            if (i0 < n_obst) fbox[i0] = b0;
-            if (i1 < n_obst) fbox[i1] = b1;
-        }
-        for (int i = lane; 4 * i < n_obst; i += WAVE) ((uint32_t*)eflag)[i] = gfl[i];
+        for (int base = 0; base < 2 * n_obst; base += WAVE)
+            if (base + lane < 2 * n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfv + base + lane), (lds_ptr)(lfv + base), 16, 0, 0);
+        for (int base = 0; base < n_obst; base += WAVE)
+            if (base + lane < n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfb + base + lane), (lds_ptr)(fbox + base), 16, 0, 0);
+        for (int base = 0; 4 * base < n_obst; base += WAVE)
+            if (4 * (base + lane) < n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfl + base + lane), (lds_ptr)((uint32_t*)eflag + base), 4, 0, 0);
     }
+    bool tile_pending = true;
     int found = -1;
     double* bad1 = scr + RSB_BAD;
     if (lane < 6) bad1[lane] = INFINITY;
-    wsync();
+    lsync();
     RS_T(0);
     const bool paranoid = (obs_f64 & 0x2000) != 0;        // self-check: float64 for every sample, disagreements counted
     unsigned long long st_pass = 0, st_hit = 0, st_exact = 0, st_unc = 0, st_bad_hit = 0, st_bad_clear = 0, st_samples = 0;
@@ -1097,7 +1101,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
             if (lane == 0) { qpd[0] = zero; qseg[0] = (unsigned char)__double2loint(zero); }
         }
         int nq = 1;
-        wsync();
+        lsync();
         RS_T(1);
         const int win = 128;
         int i = 0, t_off = 0;                              // t_off: first-segment samples taken from the table so far
@@ -1161,7 +1165,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                     i++;
                 } else pd = uni_d(t);
             }
-            wsync();
+            lsync();
             RS_T(2);
             const int n_all = nq;
             const int n = finished ? n_all : (n_all & ~(WAVE - 1));
@@ -1206,6 +1210,10 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 const float lox = cx - ex, hix = cx + ex, loy = cy - ey, hiy = cy + ey;
                 const float ulox = wave_min_f(active ? lox : INFINITY), uhix = wave_max_f(active ? hix : -INFINITY);
                 const float uloy = wave_min_f(active ? loy : INFINITY), uhiy = wave_max_f(active ? hiy : -INFINITY);
+                if (tile_pending) {                                  // first look at the obstacles: the tile's loads must have landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    tile_pending = false;
+                }
                 int nc = 0;
                 for (int base = 0; base < n_obst; base += WAVE) {
                     const int o = base + lane;
@@ -1221,7 +1229,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 RS_T(4);
                 if (nc > 0 && !__any(hit)) {
                     if (TIMING) { tsec[12] += 1; tsec[13] += nc; }
-                    wsync();
+                    lsync();
                     const bool hull_ok = fminf(fabsf(hc), fabsf(hs)) >= FETA_HULL;      // no hull edge axis-parallel in the world
                     for (int ci = 0; ci < nc; ci++) {
                         const int r = cand[ci];
@@ -1297,7 +1305,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                         }
                         if (__any(hit)) break;                   // one certain collision condemns the word
                     }
-                    wsync();
+                    lsync();
                 }
                 RS_T(5);
                 // ---- decision of the pass ----
@@ -1347,7 +1355,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 if (__any(bad)) {
                     const double mine1 = (bad && active && qseg[sidx] == 0) ? fabs(qpd[sidx]) : INFINITY;
                     const double v = fmin(bad1[cls1], wave_min_d(mine1));
-                    wsync();
+                    lsync();
                     if (lane < 6 && (lane == cls1 || v == 0.0)) bad1[lane] = fmin(bad1[lane], v);
                     invalid = true;
                     break;
@@ -1358,11 +1366,11 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
                 double cd = 0;
                 unsigned char cs = 0;
                 if (lane < rem) { cd = qpd[n + lane]; cs = qseg[n + lane]; }
-                wsync();
+                lsync();
                 if (lane < rem) { qpd[lane] = cd; qseg[lane] = cs; }
                 nq = rem;
             }
-            wsync();
+            lsync();
         }
         if (!invalid) { found = idx - 1; break; }
     }
@@ -1464,7 +1472,7 @@ hipError_t rs_init_tables() {
     return e;
 }
 
-hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer) {
+hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* timer, hipEvent_t after_segs) {
     if (p.max_queue <= 0) return hipSuccess;
     // (read per call: the tests switch kernels inside one process)
     static const bool timing = getenv("HOPE_RS_TIMING") != nullptr;      // cycle accounting build (tools/rs_timing.py)
@@ -1498,6 +1506,7 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->begin(HOPE_K_RS_SEGS, stream);
     hipLaunchKernelGGL(k_rs_segs, dim3((p.max_queue + 7) / 8), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
+    if (after_segs) { hipError_t e = hipEventRecord(after_segs, stream); if (e != hipSuccess) return e; }   // (pipelined steps: the next motion launch waits here)
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
     static const bool no_prio = getenv("HOPE_RS_PRIO") && atoi(getenv("HOPE_RS_PRIO")) == 0;
     // only for the launch of the class with more scenes, i.e. the longer chain (both launches: 0.657 ms / steady 0.688; only the

@@ -251,11 +251,16 @@ __device__ __forceinline__ double quad_intersection_area_lane0(const double* B /
 }
 
 // The same clip with one LANE per polygon pair (k_post): the ping-pong buffers are lane-private LDS columns, word i of
-// buffer b of lane l at sh[(8 b + i) * WAVE + l] (b = 0..3: ax, ay, bx, by; a convex quad clipped by a convex quad has
-// at most 8 vertices).  Same expressions in the same order as quad_intersection_area_lane0.
-__device__ __noinline__ double quad_intersection_area_private(const double* B /*8 words x,y, global*/, double* sh /* + lane */) {
-    double* ax = sh;               double* ay = sh + 8 * WAVE;
-    double* bx = sh + 16 * WAVE;   double* by = sh + 24 * WAVE;
+// buffer b of column l at sh[(8 b + i) * CLIP_COLS + l] (b = 0..3: ax, ay, bx, by; a convex quad clipped by a convex quad has
+// at most 8 vertices).  Same expressions in the same order as quad_intersection_area_lane0.  CLIP_COLS lanes of a wave clip at a
+// time (k_post walks the few lanes that need it in groups): 1 KB of LDS per block -- with a column per LANE (16 KB per 64-thread
+// block, rounds 2-3) the blocks of this tiny kernel waited for LDS behind the observation launches (5 KB per wave, 30 per CU)
+// and took 130 us.
+constexpr int CLIP_COLS = 4;
+#define WAVE_CLIP CLIP_COLS
+__device__ __noinline__ double quad_intersection_area_private(const double* B /*8 words x,y, global*/, double* sh /* + column */) {
+    double* ax = sh;                    double* ay = sh + 8 * WAVE_CLIP;
+    double* bx = sh + 16 * WAVE_CLIP;   double* by = sh + 24 * WAVE_CLIP;
     int n = 4;
     for (int e = 0; e < 4 && n > 0; e++) {
         const double c1x = B[2 * e], c1y = B[2 * e + 1];
@@ -264,15 +269,15 @@ __device__ __noinline__ double quad_intersection_area_private(const double* B /*
         int m = 0;
         for (int i = 0; i < n; i++) {
             const int i2 = (i + 1 == n) ? 0 : i + 1;
-            const double sx = ax[i * WAVE], sy = ay[i * WAVE], tx = ax[i2 * WAVE], ty = ay[i2 * WAVE];
+            const double sx = ax[i * WAVE_CLIP], sy = ay[i * WAVE_CLIP], tx = ax[i2 * WAVE_CLIP], ty = ay[i2 * WAVE_CLIP];
             const double ds = ex * (sy - c1y) - ey * (sx - c1x);
             const double dt = ex * (ty - c1y) - ey * (tx - c1x);
             const bool sin_ = ds >= 0, tin = dt >= 0;
-            if (sin_) { bx[m * WAVE] = sx; by[m * WAVE] = sy; m++; }
+            if (sin_) { bx[m * WAVE_CLIP] = sx; by[m * WAVE_CLIP] = sy; m++; }
             if (sin_ != tin) {
                 const double r = ds / (ds - dt);
-                bx[m * WAVE] = sx + r * (tx - sx);
-                by[m * WAVE] = sy + r * (ty - sy);
+                bx[m * WAVE_CLIP] = sx + r * (tx - sx);
+                by[m * WAVE_CLIP] = sy + r * (ty - sy);
                 m++;
             }
         }
@@ -285,9 +290,9 @@ __device__ __noinline__ double quad_intersection_area_private(const double* B /*
     double sum = 0.0;                                  // GEOS Area::ofRingSigned (ring_area_signed_lds)
     const double x0 = ax[0];
     for (int i = 1; i < n; i++) {
-        const double x = ax[i * WAVE] - x0;
+        const double x = ax[i * WAVE_CLIP] - x0;
         const int ip = (i + 1 == n) ? 0 : i + 1;
-        sum += x * (ay[(i - 1) * WAVE] - ay[ip * WAVE]);
+        sum += x * (ay[(i - 1) * WAVE_CLIP] - ay[ip * WAVE_CLIP]);
     }
     return fabs(sum / 2.0);
 }
@@ -1287,11 +1292,11 @@ template <typename OT>
 __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_list, const uint8_t* active, uint32_t stages,
                                             const double* scene_c, double* state, const double* post, uint8_t* rs_flag,
                                             hope_step_out out) {
-    __shared__ double clip_lds[32 * WAVE];                    // lane-private polygon buffers of the clip
+    __shared__ double clip_lds[32 * CLIP_COLS];               // polygon buffers of the clip: CLIP_COLS lanes at a time
     const int idx = blockIdx.x * WAVE + threadIdx.x;
-    if (idx >= n_list) return;
-    const int scene = scene_list[idx];
-    if (active && !active[scene]) return;
+    const int scene = idx < n_list ? scene_list[idx] : 0;
+    const bool live = idx < n_list && !(active && !active[scene]);
+    if (!__any(live)) return;
     const double* sc = scene_c + (size_t)scene * SC_WORDS;
     const double* pr = post + (size_t)scene * POST_WORDS;
     double* st = state + (size_t)scene * ST_WORDS;
@@ -1299,42 +1304,70 @@ __global__ __launch_bounds__(64) void k_post(int n_list, const int32_t* scene_li
     const int packed = __double2loint(pr[7]), fl = __double2hiint(pr[7]);
     const int status = packed & 0xff, t = packed >> 8;
     // ---- per-scene scalar outputs ------------------------------------------------------------------------
-    if (out.pose) { out.pose[3 * (size_t)scene] = st[0]; out.pose[3 * (size_t)scene + 1] = st[1]; out.pose[3 * (size_t)scene + 2] = st[2]; }
-    if (stages & HOPE_STAGE_REWARD) {
-        if (out.status) out.status[scene] = status;
-        if (out.done) out.done[scene] = status != HOPE_STATUS_CONTINUE;
-    }
-    if (!(stages & HOPE_STAGE_RS)) {                     // (with the Reeds-Shepp stage k_rs_compact clears them, ahead of the search)
-        if (out.rs_word) {
-            const unsigned long long none = (unsigned char)HOPE_RS_NONE;
-            *(unsigned long long*)(out.rs_word + 8 * (size_t)scene) = none | none << 8 | none << 16 | none << 24 | none << 32;
+    if (live) {
+        if (out.pose) { out.pose[3 * (size_t)scene] = st[0]; out.pose[3 * (size_t)scene + 1] = st[1]; out.pose[3 * (size_t)scene + 2] = st[2]; }
+        if (stages & HOPE_STAGE_REWARD) {
+            if (out.status) out.status[scene] = status;
+            if (out.done) out.done[scene] = status != HOPE_STATUS_CONTINUE;
         }
-        if (out.rs_lengths) {
+        if (!(stages & HOPE_STAGE_RS)) {                     // (with the Reeds-Shepp stage k_rs_compact clears them, ahead of the search)
+            if (out.rs_word) {
+                const unsigned long long none = (unsigned char)HOPE_RS_NONE;
+                *(unsigned long long*)(out.rs_word + 8 * (size_t)scene) = none | none << 8 | none << 16 | none << 24 | none << 32;
+            }
+            if (out.rs_lengths) {
 #pragma unroll
-            for (int i = 0; i < 5; i++) ((OT*)out.rs_lengths)[5 * (size_t)scene + i] = (OT)0;
+                for (int i = 0; i < 5; i++) ((OT*)out.rs_lengths)[5 * (size_t)scene + i] = (OT)0;
+            }
         }
     }
+    // ---- overlap area of the final pose with the dest box, for the scenes whose step did not need it already (most CONTINUE
+    // scenes): exact quick reject first (as overlap_area: disjoint discs -> empty intersection), then the polygon clip for the few
+    // lanes within reach of their slot, CLIP_COLS of them at a time (wave-level loop: every lane of the wave passes here)
+    double ua_ = live ? pr[6] : 0.0;
+    {
+        const bool want = live && (fl & POST_F_REWARD) && (stages & HOPE_STAGE_REWARD) && status == HOPE_STATUS_CONTINUE && (fl & POST_F_NEED_UA);
+        bool clip = false;
+        Box box;
+        if (want) {
+            double sn, ct;
+            hm_sincos(pr[5], &sn, &ct);
+            box = make_box(pr[3], pr[4], ct, sn);
+            const double* dbox = sc + SC_DBOX;
+            const double cx = 0.5 * (box.x[0] + box.x[2]), cy = 0.5 * (box.y[0] + box.y[2]);
+            const double dx = 0.5 * (dbox[0] + dbox[4]) - cx, dy = 0.5 * (dbox[1] + dbox[5]) - cy;
+            const double reach = 5.2;
+            ua_ = 0.0;
+            clip = !(dx * dx + dy * dy > reach * reach);
+        }
+        unsigned long long cm = __ballot(clip);
+        while (cm) {
+            // the next CLIP_COLS lanes that clip: column = rank of the lane among them
+            const int rank = __popcll(cm & ((1ull << (threadIdx.x & 63)) - 1));
+            const bool mine = clip && ((cm >> (threadIdx.x & 63)) & 1) && rank < CLIP_COLS;
+            if (mine) {
+                double* sh = clip_lds + rank;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { sh[i * CLIP_COLS] = box.x[i]; sh[(8 + i) * CLIP_COLS] = box.y[i]; }
+                ua_ = quad_intersection_area_private(sc + SC_DBOX, sh);
+            }
+            // drop the lanes just served
+            unsigned long long served = 0;
+            {
+                unsigned long long t_ = cm;
+                for (int k = 0; k < CLIP_COLS && t_; k++) { served |= t_ & (~t_ + 1); t_ &= t_ - 1; }
+            }
+            cm &= ~served;
+            __syncthreads();
+        }
+    }
+    if (!live) return;
     if ((fl & POST_F_REWARD) && (stages & HOPE_STAGE_REWARD)) {
         double ri0 = 0, ri2 = 0, ri3 = 0, ri4 = 0, reward = 0;
         if (status == HOPE_STATUS_CONTINUE) {
             const double dest_area = sc[SC_DAREA], dnorm = sc[SC_DNORM];
-            double ua = pr[6];
-            if (fl & POST_F_NEED_UA) {                         // overlap_area(box of the final pose, dest box)
-                double sn, ct;
-                hm_sincos(pr[5], &sn, &ct);
-                const Box box = make_box(pr[3], pr[4], ct, sn);
-                const double* dbox = sc + SC_DBOX;
-                const double cx = 0.5 * (box.x[0] + box.x[2]), cy = 0.5 * (box.y[0] + box.y[2]);
-                const double dx = 0.5 * (dbox[0] + dbox[4]) - cx, dy = 0.5 * (dbox[1] + dbox[5]) - cy;
-                const double reach = 5.2;                      // as overlap_area: disjoint discs -> empty intersection
-                ua = 0.0;
-                if (!(dx * dx + dy * dy > reach * reach)) {
-                    double* sh = clip_lds + threadIdx.x;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { sh[i * WAVE] = box.x[i]; sh[(8 + i) * WAVE] = box.y[i]; }
-                    ua = quad_intersection_area_private(dbox, sh);
-                }
-            }
+            double ua;
+            ua = ua_;
             ri0 = -hm_tanh((double)t / (10 * TOLERANT_TIME));
             double dq[2], aq[2];
 #pragma unroll
