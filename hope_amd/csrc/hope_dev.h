@@ -247,6 +247,7 @@ __device__ __forceinline__ float4 obstacle_box(const double* v) {
 // -- both extents of its coordinate box >= FETA_EDGE, or it lies exactly on the world line y = 0 / x = 0 (then the candidate
 // coordinate is an exact zero whatever the rounding; the back wall of every generated lot, parking_map_normal.py:70-78).
 constexpr float FETA_EDGE = 1e-2f;
+constexpr int OBST_F_CONVEX = 0x10, OBST_F_CCW = 0x20;   // per-obstacle shape flags next to the four edge flags (bits 0..3)
 __device__ __forceinline__ void obstacle_f32(const double* v /*[8]*/, double ox, double oy, float4* fv /*[2]*/, float4* fbox, uint8_t* eflag) {
     float fx[4], fy[4];
     int fl = 0;
@@ -258,6 +259,24 @@ __device__ __forceinline__ void obstacle_f32(const double* v /*[8]*/, double ox,
         const bool wide_x = fabs(x2 - x1) >= (double)FETA_EDGE, wide_y = fabs(y2 - y1) >= (double)FETA_EDGE;
         const bool zero_line = (y1 == 0.0 && y2 == 0.0 && wide_x) || (x1 == 0.0 && x2 == 0.0 && wide_y);
         fl |= ((wide_x && wide_y) || zero_line) ? (1 << j) : 0;
+    }
+    {   // shape flags for the lidar's back-face cull (k_env_step): bit 4 = a strictly convex quadrilateral without slivers (every
+        // interior angle between 25 and 155 degrees, every edge >= 5 cm), bit 5 = counter-clockwise
+        double cr[4];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int j1 = (j + 1) & 3, j2 = (j + 2) & 3;
+            const double ax = v[2 * j1] - v[2 * j], ay = v[2 * j1 + 1] - v[2 * j + 1];
+            const double bx = v[2 * j2] - v[2 * j1], by = v[2 * j2 + 1] - v[2 * j1 + 1];
+            cr[j] = ax * by - ay * bx;                                    // turn at vertex j + 1
+            const double la = ax * ax + ay * ay, lb = bx * bx + by * by;
+            ok = ok && la >= 0.0025 && lb >= 0.0025 && cr[j] * cr[j] >= 0.1786 * la * lb;      // sin^2(25 deg) = 0.1786
+        }
+        const bool ccw = cr[0] > 0;
+        ok = ok && ((cr[0] > 0) == (cr[1] > 0)) && ((cr[1] > 0) == (cr[2] > 0)) && ((cr[2] > 0) == (cr[3] > 0));
+        fl |= ok ? OBST_F_CONVEX : 0;
+        fl |= ccw ? OBST_F_CCW : 0;
     }
     fv[0] = make_float4(fx[0], fy[0], fx[1], fy[1]);
     fv[1] = make_float4(fx[2], fy[2], fx[3], fy[3]);

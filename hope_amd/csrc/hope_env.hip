@@ -852,7 +852,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     static const uint32_t dbg_stages = getenv("HOPE_DEBUG_STAGES") ? (uint32_t)strtol(getenv("HOPE_DEBUG_STAGES"), nullptr, 0) : 0;   // profiling switches 0x1000 / 0x2000 (results invalid)
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages | dbg_stages; p.has_action = has_action;
     p.hflags = h->traj ? STEP_HF_TRAJ : 0;
-    p.verts = h->verts; p.obb = h->obb; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
+    p.verts = h->verts; p.obb = h->obb; p.eflag = h->eflag; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
     p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.post = h->post;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.lidar = out->lidar; p.action_mask = out->action_mask;

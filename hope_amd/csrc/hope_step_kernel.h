@@ -160,6 +160,7 @@ struct StepParams {
     uint32_t hflags;          // STEP_HF_*
     const double* verts;      // [n][max_obst][4][2]
     const float4* obb;        // [n][max_obst] obstacle boxes (xmin, xmax, ymin, ymax), float32 rounded outwards
+    const uint8_t* eflag;     // [n][eflag_stride(max_obst)] per-obstacle flags (obstacle_f32): bits 4, 5 = shape flags of the lidar's back-face cull
     const int32_t* n_obst;    // [n]
     const double* scene_c;    // [n][SC_WORDS]
     double* state;            // [n][ST_WORDS]
@@ -193,7 +194,7 @@ constexpr int KIN_WORDS = 56;   // h[10] cos[10] sin[10] x[10] y[10], [50] = int
 constexpr int POST_WORDS = 8;
 constexpr int POST_F_REWARD = 1, POST_F_TURNOVER = 2, POST_F_NEED_UA = 4;   // NEED_UA: k_post computes the overlap area of the final pose
 __host__ __device__ inline size_t step_lds_bytes(int tile_cap) {
-    return (size_t)(8 * tile_cap + LDS_SCRATCH_WORDS) * 8 + (size_t)((tile_cap + 3) & ~3) * 4;
+    return (size_t)(8 * tile_cap + LDS_SCRATCH_WORDS) * 8 + (size_t)((tile_cap + 3) & ~3) * 4 + (size_t)((tile_cap + 3) & ~3);   // + near / keep list + shape flags
 }
 constexpr int SMALL_TILE = 32;   // scenes with <= 32 obstacles run in a launch with a 2 KB tile (higher occupancy)
 
@@ -376,7 +377,8 @@ __device__ __forceinline__ int build_near_list_box(const double* tile, int n_obs
 // outwards: a superset) meets [bx0, bx1] x [by0, by1] are found from 16 bytes per obstacle, and only THEIR vertices are
 // copied to LDS, compacted: tile slot i = i-th such obstacle, list[i] = i.  Returns their number.
 __device__ __forceinline__ int stage_near(const float4* obb, const double2* src, int n_obst, double bx0, double bx1,
-                                          double by0, double by1, double* tile, int* list, int lane) {
+                                          double by0, double by1, double* tile, int* list, int lane,
+                                          const uint8_t* gflags = nullptr, uint8_t* lflags = nullptr) {
     int cnt = 0;
     for (int base = 0; base < n_obst; base += WAVE) {
         const int o = base + lane;
@@ -391,7 +393,10 @@ __device__ __forceinline__ int stage_near(const float4* obb, const double2* src,
     }
     wsync();
     double2* dst = (double2*)tile;
-    for (int i = lane; i < 4 * cnt; i += WAVE) dst[i] = src[4 * list[i >> 2] + (i & 3)];
+    for (int i = lane; i < 4 * cnt; i += WAVE) {
+        dst[i] = src[4 * list[i >> 2] + (i & 3)];
+        if (gflags && (i & 3) == 0) lflags[i >> 2] = gflags[list[i >> 2]];       // the staged obstacles' shape flags (lidar cull)
+    }
     wsync();
     for (int i = lane; i < cnt; i += WAVE) list[i] = i;
     return cnt;
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     double* tile = lds;
     double* scr = lds + 8 * p.tile_cap;
     int* keep = (int*)(scr + LDS_KEEP);
+    uint8_t* cfl = (uint8_t*)(keep + ((p.tile_cap + 3) & ~3));     // shape flags of the staged obstacles (lidar)
 
     // ---- stage the scene: constants (192 B), state (32 B), obstacle tile (64 B x n_obst) ---------
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
@@ -972,7 +978,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     int* llist = keep;
     wsync();                                                  // the near list (same words) is dead
     const double lr = LIDAR_RANGE + 1e-6;
-    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane)
+    const uint8_t* eflag_s = p.eflag + (size_t)scene * eflag_stride(p.max_obst);
+    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane, eflag_s, cfl)
                               : build_near_list(tile, n_obst, x, y, lr, llist, lane);
     wsync();
     {
@@ -1058,10 +1065,12 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             const int i = base + lane;
             const int e = i < n_kslots ? 4 * llist[i >> 2] + (i & 3) : 0;
             int lo = 0, cnt = 0;
+            bool front = false, back = false, risky = true;     // back-face cull (below): this edge's facing; "the ring cannot be culled"
             if (i < n_kslots) {
                 const int e2 = (e & ~3) | ((e + 1) & 3);
-                const float x1 = (float)tile[2 * e], y1 = (float)tile[2 * e + 1];
-                const float x2 = (float)tile[2 * e2], y2 = (float)tile[2 * e2 + 1];
+                const double dx1 = tile[2 * e], dy1 = tile[2 * e + 1], dx2 = tile[2 * e2], dy2 = tile[2 * e2 + 1];
+                const float x1 = (float)dx1, y1 = (float)dy1;
+                const float x2 = (float)dx2, y2 = (float)dy2;
                 const float t1 = atan2f(y1, x1), t2 = atan2f(y2, x2);
                 float dth = t2 - t1;
                 if (dth > 3.14159265f) dth -= 6.28318531f;
@@ -1069,7 +1078,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 const float span = fabsf(dth);
                 // all beams: span ill-defined, or an end point so close to the sensor (< 0.1 m: far inside the hull) that the
                 // float32 rounding of its coordinates could move its direction by more than the margin
-                if (span > 3.13f || !(span == span) || fminf(x1 * x1 + y1 * y1, x2 * x2 + y2 * y2) < 0.01f) { lo = 0; cnt = NBEAM; }
+                const bool wild = span > 3.13f || !(span == span) || fminf(x1 * x1 + y1 * y1, x2 * x2 + y2 * y2) < 0.01f;
+                if (wild) { lo = 0; cnt = NBEAM; }
                 else {
                     float ts = dth >= 0 ? t1 : t2;                  // start of the arc, counter-clockwise
                     if (ts < 0) ts += 6.28318531f;
@@ -1082,6 +1092,32 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                     if (cnt > NBEAM) cnt = NBEAM;
                     lo = ((ilo % NBEAM) + NBEAM) % NBEAM;
                 }
+                // ---- back-face cull.  A beam that crosses a BACK edge of a convex ring seen from outside has entered the ring
+                // through a front edge first, nearer to the sensor: if that nearer hit is certain to pass the reference's tests
+                // (lidar_simulator.py:116-129), the back edge can never be the beam's minimum (:131) and its pairs are dropped.
+                // Certain means: the ring is a convex quadrilateral without slivers (shape flag, made with the tile), the sensor is
+                // clearly outside (every edge decisively front or back, both kinds present), NO vertex of the ring lies within
+                // 2e-4 rad of a beam direction (so the entry point is >= 2e-5 m inside a front edge -- its coordinate-box tests hold
+                // with 1000 x the rounding error -- and the ring is >= 1e-5 m thick along the beam), and no front edge is
+                // within 1e-4 m of axis-parallel (a degenerate coordinate box is met by bit-equality only).  Anything else: the
+                // ring keeps all its pairs, as before.
+                const int fl = (int)(PART == 2 ? cfl[e >> 2] : eflag_s[e >> 2]);
+                const double cr = dx1 * dy2 - dx2 * dy1;            // > 0: the sensor is on the left of the directed edge
+                const double sc2 = (dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2);
+                const bool decisive = cr * cr > 1e-12 * sc2;       // |sin(angle subtended)| > 1e-6
+                const bool left = cr > 0;
+                front = decisive && (left != ((fl & OBST_F_CCW) != 0));          // CCW ring: the inside is on the left
+                back = decisive && !front;
+                const float q1 = t1 * (1.0f / PITCH);
+                const bool near_beam = fabsf(q1 - rintf(q1)) * PITCH <= 2.0e-4f + 4e-6f;     // this edge's first vertex vs the beam directions
+                const bool thin = front && (fabs(dx2 - dx1) < 1e-4 || fabs(dy2 - dy1) < 1e-4);
+                risky = wild || !decisive || near_beam || thin || !(fl & OBST_F_CONVEX);
+            }
+            {   // ring = 4 consecutive lanes: cull the back edges iff nothing about the ring is risky and it has both kinds of edges
+                const unsigned long long rb = __ballot(risky), fb = __ballot(front), bb = __ballot(back);
+                const int sh = lane & ~3;
+                const bool ring_ok = ((rb >> sh) & 0xF) == 0 && ((fb >> sh) & 0xF) != 0 && ((bb >> sh) & 0xF) != 0;
+                if (ring_ok && back && !(p.stages & 0x4000)) cnt = 0;          // (0x4000: profiling / A-B switch, no cull)
             }
             // Append the pairs to the queue EDGE BY EDGE: for every edge with beams (a scalar walk over the ballot) its range
             // [lo, lo + cnt) is written by the lanes 0 .. cnt-1 in one store -- no per-beam ballots / prefix counts at all

@@ -1220,3 +1220,36 @@ def test_tie_census_no_decision_of_the_geos_slice_comes_near_a_tie():
     # mask: the structural ties exist (a touching obstacle clips the scan to the hull range the table was built from) and are
     # IEEE arithmetic on both sides, not GEOS; they must stay a vanishing part of the workload
     assert c['mask_scene_steps_exact_path'] < 1e-5 * c['scene_steps']
+
+
+def test_lidar_back_face_cull_changes_no_bit():
+    """Round 4: the lidar drops the (beam, edge) pairs of the BACK edges of convex obstacles seen from outside (hope_step_kernel.h:
+    the nearer front-edge hit is certain to pass the reference's tests, so the back edge can never be the beam's minimum,
+    lidar_simulator.py:116-131).  With the cull switched off (stage bit 0x4000) every lidar value and every mask entry must be the
+    same bit, in both launch forms, over mixed and Dragon-Lake scenes with turnover (besides the oracle comparisons of this file,
+    which all run with the cull on)."""
+    import os
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scene_gen import mixed_arrays
+    for split in (False, True):
+        if split:
+            os.environ['HOPE_SPLIT_MIN'] = '1'
+        try:
+            n = 8192
+            arrs = mixed_arrays(n, seed=91 + split, max_obst=128)
+            envs = [ParkingBatch(n, 128, obs_dtype=torch.float64, overlap=True) for _ in range(2)]
+            for e in envs:
+                e.set_scene_arrays(np.arange(n), *arrs[:5])
+                e.reset_obs()
+            g = torch.Generator(device='cuda').manual_seed(17)
+            for it in range(40):
+                a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+                envs[0].step(a, auto_reset=True)
+                envs[1].step(a, stages=L.STAGE_ALL | 0x4000, auto_reset=True)
+                torch.cuda.synchronize()
+                for k in ('lidar', 'action_mask', 'status', 'pose', 'reward', 'rs_word'):
+                    assert torch.equal(getattr(envs[0], k), getattr(envs[1], k)), (split, it, k)
+            for e in envs:
+                e.close()
+        finally:
+            os.environ.pop('HOPE_SPLIT_MIN', None)
