@@ -32,7 +32,8 @@ def build_extension(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
         hipcc = 'hipcc'
-    cmd = [hipcc] + FLAGS + ['-I' + os.path.join(_ROOT, 'include'), '-I' + _CSRC] + \
+    extra = os.environ.get('HOPE_BUILD_DEFS', '').split()          # A/B builds: HOPE_BUILD_DEFS="-DHOPE_MASK_MG=8" HOPE_AMD_LIB=...
+    cmd = [hipcc] + FLAGS + extra + ['-I' + os.path.join(_ROOT, 'include'), '-I' + _CSRC] + \
           [os.path.join(_CSRC, s) for s in SOURCES] + ['-o', out]
     if verbose:
         print(' '.join(cmd))

@@ -15,6 +15,9 @@
 // L2/MALL resident.  No MFMA: this is geometry, not a contraction.
 #pragma once
 #include "hope_dev.h"
+#ifndef HOPE_MASK_MG
+#define HOPE_MASK_MG 4      // action-mask rows probed together (A/B builds: -DHOPE_MASK_MG=8 measured 1.3 % slower)
+#endif
 #include "hope_env.h"
 
 namespace hope {
@@ -1216,7 +1219,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         for (int half = 0; half < 2; half++) {
             unsigned long long m = am[half];
             while (m) {
-                constexpr int MG = 4;                              // rows probed together: their loads are in flight at once
+                constexpr int MG = HOPE_MASK_MG;                              // rows probed together: their loads are in flight at once
                 int ib[MG];
 #pragma unroll
                 for (int g = 0; g < MG; g++) {
