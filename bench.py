@@ -355,7 +355,7 @@ def main():
         # labelled as such.  They describe the default workload only.
         default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and fresh)
         traffic = traffic_source = None
-        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_image.json' if args.image else 'r03_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic_image.json' if args.image else 'r04_pmc_traffic.json')
         if os.path.exists(pmc) and default_workload and not args.graph:
             try:
                 traffic = json.load(open(pmc))['kernels'][dom]['hbm_bytes']
@@ -369,7 +369,7 @@ def main():
         # rocprofv3 --pmc pass of this command (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64).  floor = sum over classes
         # of count / rate; frac = floor / measured time.  Counts are static (labelled), the step time is this run's.
         valu = None
-        sq = os.path.join(ROOT, 'profiles', 'r03_sq_counters.json')
+        sq = os.path.join(ROOT, 'profiles', 'r04_sq_counters.json')
         vr = os.path.join(ROOT, 'profiles', 'r03_valu_rates.json')
         if os.path.exists(sq) and os.path.exists(vr) and default_workload and not args.image:
             try:
@@ -392,7 +392,7 @@ def main():
                 valu = {'valu_insts_per_bench_step': insts, 'mix_weighted_floor_ms_per_step': floor_s * 1e3,
                         'frac': floor_s / (elapsed / args.steps), 'rates_wave_insts_per_s': {'f64_arith': r64, 'f64_trans': rtr, 'other': r32},
                         'per_kernel': per_kernel,
-                        'source': 'static instruction counts by class: profiles/r03_sq_counters.json (rocprofv3 --pmc passes of this command); '
+                        'source': 'static instruction counts by class: profiles/r04_sq_counters.json (rocprofv3 --pmc passes of this command); '
                                   'issue rates: profiles/r03_valu_rates.json (tools/valu_rate.py on the same GPU type); step and kernel times: this run. '
                                   'A single wave issues at most one instruction per ~8-10 cycles, so a kernel needs >= 4 waves per SIMD to reach these rates.'}
             except Exception:

@@ -1,25 +1,30 @@
 #!/bin/bash
 # Regenerates every file under profiles/ on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
 # Outputs land in gpurun_out/final/ (merged back by gpurun); copy them into profiles/ afterwards.
-# PMC counters are collected in their own passes, without any trace domain.
+# PMC counters are collected in their own passes, without any trace domain.  Every command runs under `timeout`.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r04}
 R=$PWD
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-py() { python "$@" 2>$O/stderr.log; }
+T="timeout 400"
+py() { $T python "$@" 2>>$O/stderr.log; }
+PRE="--preroll 100"     # profiled runs: a shorter pre-roll to the stationary episode population (the default run uses 300)
 
 py $R/bench.py | tail -1 > $O/${TAG}_bench_default.json
+py $R/bench.py | tail -1 > $O/${TAG}_bench_default_2.json
 py $R/bench.py --image --no-cpu-baseline | tail -1 > $O/${TAG}_bench_image.json
+py $R/bench.py --rs-join joined --no-cpu-baseline | tail -1 > $O/${TAG}_bench_joined.json
+py $R/bench.py --preroll 0 --no-cpu-baseline --witness 0 | tail -1 > $O/${TAG}_bench_fresh_episodes.json     # the round-3 form of the number
 
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_img -- python $R/bench.py --image --steps 10 --warmup 3 --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1 > $O/${TAG}_bench_image_under_rocprof.json
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -- python $R/bench.py --steps 10 --warmup 3 $PRE --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1 > $O/${TAG}_bench_under_rocprof.json
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_img -- python $R/bench.py --image --steps 10 --warmup 3 $PRE --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1 > $O/${TAG}_bench_image_under_rocprof.json
 for V in "" "_image"; do
   FLAG=""; [ -n "$V" ] && FLAG="--image"
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+    $T rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --preroll 60 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
   done
 done
 # derived busy / utilisation metrics (list VALU-busy and LDS-bank-conflict next to the HBM fraction)
@@ -28,40 +33,47 @@ for V in "" "_image"; do
   I=0
   for C in "VALUBusy SALUBusy" "LDSBankConflict MemUnitBusy" "OccupancyPercent VALUUtilization"; do
     I=$((I+1))
-    rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+    $T rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --preroll 60 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
   done
 done
 python $R/tools/reduce_profiles.py $O $TAG
 # raw SQ counters (instruction mix, wait / active quad-cycles) -> VALU-issue roofline of bench.py
-(cd $R && bash tools/pmc_sq.sh final/sq > /dev/null 2>&1)
+(cd $R && timeout 900 bash tools/pmc_sq.sh final/sq > /dev/null 2>&1)
 cp $O/sq/sq_summary.txt $O/${TAG}_sq_summary.txt; cp $O/sq/sq_counters.json $O/${TAG}_sq_counters.json; rm -rf $O/sq
 py $R/tools/stage_times.py --scenes 32768 > $O/${TAG}_stage_times.txt
 py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
-# batch-size sweep, launch modes, new-map turnover, BASELINE configs 4 / 5 on one GPU, 2 ranks sharing the GPU
+# batch-size sweep, launch modes, new-map turnover, BASELINE configs 4 / 5 on one GPU, ranks sharing the GPU
 {
-  for NS in 4096 8192 16384 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 0 --steps 40 --warmup 10 | tail -1; done
-  echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 | tail -1
-  echo "== --scenes 8192 --graph"; py $R/bench.py --scenes 8192 --graph --no-cpu-baseline --steps 40 --warmup 10 | tail -1
-  echo "== --same-map"; py $R/bench.py --same-map --no-cpu-baseline --steps 40 --warmup 10 | tail -1
+  for NS in 4096 8192 16384 32768 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 2 --steps 40 --warmup 10 | tail -1; done
+  echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
+  echo "== --scenes 8192 --graph"; py $R/bench.py --scenes 8192 --graph --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
+  echo "== --same-map"; py $R/bench.py --same-map --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 | tail -1
+  echo "== HOPE_PIPE=0 (steps not pipelined: the round-3 launch structure with this round's kernels)"; HOPE_PIPE=0 $T python $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
+  echo "== config 2: --stages motion --scenes 4096"; py $R/bench.py --scenes 4096 --stages motion --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
+  echo "== config 3: --scenes 16384 (full step)"; py $R/bench.py --scenes 16384 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 | tail -1
   echo "== config 4 share: --policy hope --algo rollout --scenes 8192 --image"; py $R/bench.py --policy hope --algo rollout --scenes 8192 --image --no-cpu-baseline | tail -1
   echo "== --policy hope --algo rollout (65536 scenes, no image)"; py $R/bench.py --policy hope --algo rollout --no-cpu-baseline | tail -1
   echo "== config 5 share: --policy hope --algo ppo --scenes 16384"; py $R/bench.py --policy hope --algo ppo --scenes 16384 --no-cpu-baseline --steps 32 --warmup 16 | tail -1
   echo "== 2 ranks sharing the GPU (gloo): weak scaling 16384 scenes/rank"
-  HOPE_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --scenes 16384 --steps 20 --warmup 5 2>/dev/null | tail -1
+  HOPE_BENCH_SHARE_GPU=1 $T python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 --scenes 16384 --steps 20 --warmup 5 --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1
+  echo "== 8 ranks sharing the GPU (gloo): config 4's shape, 65536 scenes strong-scaled = 8192 per rank"
+  HOPE_BENCH_SHARE_GPU=1 $T python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29518 $R/bench.py --gpus 8 --scaling strong --scenes 65536 --steps 20 --warmup 5 --preroll 60 --no-cpu-baseline --witness 0 --repeat-passes 0 2>/dev/null | tail -1
   echo "== 2 ranks sharing the GPU (gloo): strong scaling 16384 scenes total, PPO with gradient all-reduce"
-  HOPE_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 $R/bench.py --gpus 2 --scaling strong --scenes 16384 --policy hope --algo ppo --steps 16 --warmup 8 2>/dev/null | tail -1
+  HOPE_BENCH_SHARE_GPU=1 $T python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 $R/bench.py --gpus 2 --scaling strong --scenes 16384 --policy hope --algo ppo --steps 16 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1
 } > $O/${TAG}_bench_modes.txt
-# the caller's stream joined with every output before the next step is enqueued (the default defers the Reeds-Shepp join)
-py $R/bench.py --rs-join joined --no-cpu-baseline | tail -1 > $O/${TAG}_bench_joined.json
-# timeline of one step (joined form: consecutive steps do not overlap, so one step can be cut out of the trace)
-rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/bench.py --rs-join joined --steps 8 --warmup 8 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+# timeline of one step: joined form (one step can be cut out of the trace) and the last 60 launches of the pipelined form
+$T rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/bench.py --rs-join joined --steps 8 --warmup 8 $PRE --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
 { python $R/tools/timeline.py $O/tl 3; python $R/tools/timeline.py $O/tl 2; } > $O/${TAG}_step_timeline.txt 2>&1
 rm -rf $O/tl
-# cycle accounting (instrumented builds), float32-filter statistics + self-check, randomised equality soak
-HOPE_STEP_TIMING=1 python $R/tools/step_timing.py > $O/${TAG}_env_step_cycles.txt 2>/dev/null
-HOPE_RS_TIMING=1 python $R/tools/rs_timing.py > $O/${TAG}_rs_validate_cycles.txt 2>/dev/null
-python $R/tools/rs_filter_stats.py --check > $O/${TAG}_rs_filter_stats.txt 2>/dev/null
-python $R/tools/rs_bench.py > $O/${TAG}_rs_bench.txt 2>/dev/null
-python $R/tools/soak.py --seeds 10 --scenes 4096 --steps 12 > $O/${TAG}_soak.txt 2>/dev/null
+$T rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/bench.py --steps 8 --warmup 8 $PRE --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+python $R/tools/timeline.py $O/tl --tail 60 > $O/${TAG}_step_timeline_pipelined.txt 2>&1
+rm -rf $O/tl
+# cycle accounting (instrumented builds), float32-filter statistics + self-check, randomised equality soak, tie census
+HOPE_STEP_TIMING=1 $T python $R/tools/step_timing.py > $O/${TAG}_env_step_cycles.txt 2>/dev/null
+HOPE_RS_TIMING=1 $T python $R/tools/rs_timing.py > $O/${TAG}_rs_validate_cycles.txt 2>/dev/null
+$T python $R/tools/rs_filter_stats.py --check > $O/${TAG}_rs_filter_stats.txt 2>/dev/null
+$T python $R/tools/rs_bench.py > $O/${TAG}_rs_bench.txt 2>/dev/null
+timeout 900 python $R/tools/soak.py --seeds 10 --scenes 4096 --steps 12 > $O/${TAG}_soak.txt 2>/dev/null
+$T python $R/tools/tie_census.py --scene-steps 2e8 > $O/${TAG}_tie_census.txt 2>/dev/null
 rm -rf $O/kstats $O/kstats_img $O/pmc_* $O/pmc*_FETCH_SIZE $O/pmc*_WRITE_SIZE $O/busy*
 ls -la $O

@@ -41,8 +41,8 @@ for k, cs in acc.items():
                 print(f'   frac of wave cycles {c:20s} {vals[c] / wc:8.3f}')
 
 summary = {'unit': 'per launch, average over the second half of the launches in the profiled run', 'kernels': {}}
-# tools/pmc_sq.sh profiles `bench.py --steps 4 --warmup 8`: 8 + 4 timed + 4 breakdown = 16 env steps with an action (plus one
-# action-less reset_obs, which also launches the class kernels once)
+# tools/pmc_sq.sh profiles `bench.py --steps 4 --warmup 8 --preroll 60`: 60 + 8 + 4 timed + 4 breakdown = 76 env steps with an action
+# (plus one action-less reset_obs, which also launches the class kernels once); the count is the second argument
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 tot_valu = tot_salu = 0.0
 for k, cs in acc.items():

@@ -9,8 +9,24 @@ import re
 import sys
 
 
+def tail(d, n):
+    """the last n launches of the trace, as they are (pipelined steps overlap: no step can be cut out)"""
+    f = sorted(glob.glob(d + '/**/*kernel_trace.csv', recursive=True))[0]
+    rows = [r for r in csv.DictReader(open(f)) if 'k_' in r['Kernel_Name'] and ('hope' in r['Kernel_Name'] or 'k_rs_compact' in r['Kernel_Name'])]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    rows = rows[-n:]
+    t0 = int(rows[0]['Start_Timestamp'])
+    for r in rows:
+        m = re.search(r'(k_[a-z_]+)(<[^>]*>)?', r['Kernel_Name'])
+        name = m.group(1) + (m.group(2) or '')
+        s, e = (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - t0) / 1e3
+        print(f"  q{r.get('Queue_Id', '?'):>3} {s:8.1f} -> {e:8.1f} us  ({e - s:6.1f})  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>8}  {name}")
+
+
 def main():
     d = sys.argv[1]
+    if len(sys.argv) > 3 and sys.argv[2] == '--tail':
+        return tail(d, int(sys.argv[3]))
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     f = sorted(glob.glob(d + '/**/*kernel_trace.csv', recursive=True))[0]
     rows = [r for r in csv.DictReader(open(f)) if 'hope' in r['Kernel_Name']]
