@@ -257,10 +257,10 @@ __device__ __forceinline__ double quad_intersection_area_lane0(const double* B /
 // The same clip with one LANE per polygon pair (k_post): the ping-pong buffers are lane-private LDS columns, word i of
 // buffer b of column l at sh[(8 b + i) * CLIP_COLS + l] (b = 0..3: ax, ay, bx, by; a convex quad clipped by a convex quad has
 // at most 8 vertices).  Same expressions in the same order as quad_intersection_area_lane0.  CLIP_COLS lanes of a wave clip at a
-// time (k_post walks the few lanes that need it in groups): 1 KB of LDS per block -- with a column per LANE (16 KB per 64-thread
+// time (k_post walks the lanes that need it in groups of 16 -- in steady state a third of the scenes are within reach of their slot): 4 KB of LDS per block -- with a column per LANE (16 KB per 64-thread
 // block, rounds 2-3) the blocks of this tiny kernel waited for LDS behind the observation launches (5 KB per wave, 30 per CU)
 // and took 130 us.
-constexpr int CLIP_COLS = 4;
+constexpr int CLIP_COLS = 16;
 #define WAVE_CLIP CLIP_COLS
 __device__ __noinline__ double quad_intersection_area_private(const double* B /*8 words x,y, global*/, double* sh /* + column */) {
     double* ax = sh;                    double* ay = sh + 8 * WAVE_CLIP;
@@ -690,6 +690,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (PART == 0) {
         double2* dst = (double2*)tile;
         for (int v = lane; v < n_slots; v += WAVE) dst[v] = src[v];   // 16 B/lane, coalesced
+        // (the obstacles' shape flags for the lidar's back-face cull, with the tile: not a dependent load in the middle of the lidar)
+        const uint32_t* gf = (const uint32_t*)(p.eflag + (size_t)scene * eflag_stride(p.max_obst));
+        for (int i = lane; 4 * i < n_obst; i += WAVE) ((uint32_t*)cfl)[i] = gf[i];
     }
     double* dbox = scr + LDS_DBOX;
     double* xl = scr + LDS_ROBUST;                       // work area of the robust collision path (one lane at a time)
@@ -919,6 +922,9 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 dest_area = sc[SC_DAREA];
                 n_obst = nob;
                 redrawn = true;
+                // (one-launch form: the staged shape flags belong to the old map; without them the new episode's first lidar scan
+                // simply runs without the back-face cull)
+                if (PART == 0) for (int i_ = lane; 4 * i_ < nob; i_ += WAVE) ((uint32_t*)cfl)[i_] = 0;
                 wsync();
             }
         }
@@ -1104,7 +1110,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 // with 1000 x the rounding error -- and the ring is >= 1e-5 m thick along the beam), and no front edge is
                 // within 1e-4 m of axis-parallel (a degenerate coordinate box is met by bit-equality only).  Anything else: the
                 // ring keeps all its pairs, as before.
-                const int fl = (int)(PART == 2 ? cfl[e >> 2] : eflag_s[e >> 2]);
+                const int fl = (int)cfl[e >> 2];
                 const double cr = dx1 * dy2 - dx2 * dy1;            // > 0: the sensor is on the left of the directed edge
                 const double sc2 = (dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2);
                 const bool decisive = cr * cr > 1e-12 * sc2;       // |sin(angle subtended)| > 1e-6
