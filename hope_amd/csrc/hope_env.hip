@@ -362,7 +362,10 @@ __global__ __launch_bounds__(64) void k_redraw(int max_obst, const uint8_t* mask
 // contiguous range of the queue with a single atomicAdd.
 // Small workgroups on purpose: the kernel runs while other streams keep every CU busy with one-wave workgroups, and a
 // 1024-thread workgroup then waits for 16 free wave slots on ONE CU (measured: up to 0.4 ms of queueing).
-constexpr int COMPACT_THREADS = 256;
+#ifndef HOPE_COMPACT_THREADS
+#define HOPE_COMPACT_THREADS 256
+#endif
+constexpr int COMPACT_THREADS = HOPE_COMPACT_THREADS;
 // The gate itself (car_parking_base.py:293-294: t > 1, status CONTINUE, closer than RS_MAX_DIST to the dest -- of the
 // finished step, from k_env_step's hand-over record) is evaluated here, and the Reeds-Shepp outputs of every scene of the
 // class are cleared here, so that the chain motion -> compact -> words -> segs -> validate does not wait for k_post.

@@ -29,7 +29,7 @@ def local_world_size():
 
 def pin_rank_to_cores(local_rank=None, local_world=None):
     """Give this rank ITS share of the host: with one process per GPU every rank runs host-side helpers -- the native scene
-    generator (hope_scenegen_generate), the pool refresher's thread, the OpenMP oracle of the CPU baseline -- whose default
+    generator (hope_scenegen_generate), the pool refresher's thread, the OpenMP CPU baseline of bench.py -- whose default
     fan-out is "the CPUs I may run on".  Unpinned, 8 ranks x 256 hardware threads oversubscribe a 256-thread host eightfold.
     The rank's CPU affinity becomes a contiguous block of the CPUs the process may use now (NUMA-friendly for GPUs enumerated in
     socket order), OMP_NUM_THREADS / torch's intra-op pool follow.  HOPE_NO_PIN=1 disables it.  Returns the number of CPUs."""
