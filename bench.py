@@ -50,8 +50,6 @@ def parse():
                          'device-resident pool of --pool generated scenes inside the step kernel (HOPE_AUTO_REDRAW)')
     ap.add_argument('--fresh-scenes', action='store_true', help='(the default now; kept for old command lines)')
     ap.add_argument('--pool', type=int, default=8192)
-    ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (small batches: launch latency); '
-                    'per-kernel HIP events are unavailable then, the roofline is stated on the whole step')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
                     help='launch chains of the two tile classes on two streams (auto = on)')
     ap.add_argument('--max-obst', type=int, default=128)
@@ -156,7 +154,7 @@ def main():
 
     overlap = {'auto': None, 'on': True, 'off': False}[args.overlap]
     env = ParkingBatch(N, args.max_obst, device=str(dev), obs_dtype=torch.float32, action_dtype=torch.float32,
-                       profile=not args.graph, image=args.image, overlap=overlap, graph=args.graph)
+                       profile=True, image=args.image, overlap=overlap)
     chunk = 8192
     for a in range(0, N, chunk):
         b = min(N, a + chunk)
@@ -236,8 +234,7 @@ def main():
     # launch costs ~4 % of the step in launch latency (16 event records per step), so the other kernels are timed in a
     # short separate pass after it (ms_per_bench_step_by_kernel)
     dom = 'k_bev_image' if args.image else 'k_env_step'
-    if not args.graph:
-        env.profile_kernels([dom])
+    env.profile_kernels([dom])
     if trainer is None:
         env.reset_obs(stages=stages)
         if args.preroll > 0:
@@ -249,9 +246,8 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(dev)
-    if not args.graph:
-        env.kernel_union_ms(reset=True)
-        env.kernel_ms(reset=True)
+    env.kernel_union_ms(reset=True)
+    env.kernel_ms(reset=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -264,28 +260,21 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     n_break = min(args.steps, 10)
-    if args.graph:
-        # graph replay: no per-launch events; the roofline below is stated on the whole step
-        dom_stats = (elapsed * 1e3, args.steps)
-        dom_union = dom_stats
-        kstats = {}
-    else:
-        dom_union = env.kernel_union_ms(reset=True)[dom]
-        dom_stats = env.kernel_ms(reset=True)[dom]
-        env.profile_kernels(None)
-        for i in range(n_break):
-            one_step(args.warmup + args.steps + i)
-        torch.cuda.synchronize(dev)
-        env.kernel_union_ms(reset=True)
-        kstats = env.kernel_ms(reset=True)
+    dom_union = env.kernel_union_ms(reset=True)[dom]
+    dom_stats = env.kernel_ms(reset=True)[dom]
+    env.profile_kernels(None)
+    for i in range(n_break):
+        one_step(args.warmup + args.steps + i)
+    torch.cuda.synchronize(dev)
+    env.kernel_union_ms(reset=True)
+    kstats = env.kernel_ms(reset=True)
     done_frac = float(env.done.float().mean().item())
     rs_found = float((env.rs_word[:, 6] > 0).float().mean().item())
     # ---- outside the driver-timed K steps: run-to-run spread over longer passes (SURVEY.md §8(d) asks for >= 200 timed steps,
     # median of 5; the driver's command fixes K), at the episode population those passes converge to (OUTTIME needs t > 200)
     repeat = None
     if args.repeat_passes > 0 and trainer is None:
-        if not args.graph:
-            env.profile_kernels([dom])                       # the configuration of the timed region
+        env.profile_kernels([dom])                           # the configuration of the timed region
         ms = []
         dsum = 0.0
         for r in range(args.repeat_passes):
@@ -296,9 +285,8 @@ def main():
             torch.cuda.synchronize(dev)
             ms.append((time.perf_counter() - tr) / args.repeat_steps * 1e3)
             dsum += float(env.done.float().mean().item())
-            if not args.graph:
-                env.kernel_union_ms(reset=True)
-                env.kernel_ms(reset=True)
+            env.kernel_union_ms(reset=True)
+            env.kernel_ms(reset=True)
         sm = sorted(ms)
         repeat = {'passes': args.repeat_passes, 'steps_per_pass': args.repeat_steps, 'ms_per_step': ms, 'min': sm[0],
                   'median': sm[len(sm) // 2], 'max': sm[-1], 'spread': (sm[-1] - sm[0]) / sm[len(sm) // 2],
@@ -344,8 +332,6 @@ def main():
         # takes about the same time but only re-reads obstacle tiles); with --image it is k_bev_image, which is then
         # also the largest by time.  `largest_by_time` is reported next to it.
         largest = max(per_step, key=per_step.get) if per_step else None
-        if args.graph:
-            dom = 'whole step (hipGraph replay)'
         dom_total_ms, dom_launches = dom_stats
         dom_ms = dom_total_ms / max(dom_launches, 1)
         bytes_avg_launch = bytes_per_launch * args.steps / max(dom_launches, 1)
@@ -356,7 +342,7 @@ def main():
         default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and fresh)
         traffic = traffic_source = None
         pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic_image.json' if args.image else 'r04_pmc_traffic.json')
-        if os.path.exists(pmc) and default_workload and not args.graph:
+        if os.path.exists(pmc) and default_workload:
             try:
                 traffic = json.load(open(pmc))['kernels'][dom]['hbm_bytes']
                 traffic_source = 'static: ' + os.path.relpath(pmc, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch)'
@@ -424,7 +410,7 @@ def main():
             'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'preroll_steps': args.preroll if trainer is None else 0, 'mean_edges': float(edges.mean()),
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
-                       'overlap_tile_classes': bool(env.overlap), 'hip_graph': bool(env.graph),
+                       'overlap_tile_classes': bool(env.overlap),
                        'rs_join': ('deferred: the caller\'s stream is ordered after each step\'s observation / reward / status outputs, its '
                                    'Reeds-Shepp outputs by the next step on the library\'s streams (HOPE_DEFER_RS); all work of the K steps '
                                    'is complete at the closing synchronize') if defer else 'joined',

@@ -6,7 +6,7 @@ from .build import lib_path
 
 # mirror of include/hope_env.h
 LIDAR_NUM, N_ACTION, N_ITER, UPSAMPLE, TARGET_DIM, RS_MAX_SEG = 120, 42, 10, 10, 5, 5
-F_OBS_F64, F_ACTION_F64, F_PROFILE, F_IMAGE, F_OVERLAP, F_GRAPH = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+F_OBS_F64, F_ACTION_F64, F_PROFILE, F_IMAGE, F_OVERLAP = 0x1, 0x2, 0x4, 0x8, 0x10
 STAGE_MOTION, STAGE_OBS, STAGE_REWARD, STAGE_RS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 ACTION_PHYSICAL = 0x10
 ACTION_RESCALE_F32 = 0x80

@@ -15,12 +15,10 @@ from .scenes import pack_scenes
 
 class ParkingBatch:
     def __init__(self, n_scenes, max_obstacles=128, device='cuda:0', obs_dtype=torch.float32,
-                 action_dtype=torch.float32, tables=None, profile=False, image=False, overlap=None, graph=False,
+                 action_dtype=torch.float32, tables=None, profile=False, image=False, overlap=None,
                  rescale_f32=False):
         """overlap: run the launch chains of the two obstacle-tile classes on two streams (default on: +15 % at 65 536
-        scenes, +45 % at 4 096-8 192, measured).  graph: replay the step's launches as one hipGraph (the actions are copied
-        into a persistent buffer so that the captured pointers repeat); not combinable with profile.  rescale_f32: with
-        float32 actions, evaluate action_rescale in float32 as the reference does with gym's float32 Box
+        scenes, +45 % at 4 096-8 192, measured).  rescale_f32: with float32 actions, evaluate action_rescale in float32 as the reference does with gym's float32 Box
         (env_wrapper.py:46-47); default: float64 arithmetic whatever the action dtype."""
         if not torch.cuda.is_available():
             raise L.HopeError('ParkingBatch needs a HIP device (torch.cuda.is_available() is False); no CPU fallback')
@@ -33,8 +31,8 @@ class ParkingBatch:
         self.obs_dtype, self.action_dtype = obs_dtype, action_dtype
         if overlap is None:
             overlap = True
-        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0) | (L.F_PROFILE if profile else 0) | (L.F_IMAGE if image else 0) | (L.F_OVERLAP if overlap else 0) | (L.F_GRAPH if graph else 0)
-        self.graph, self.overlap = bool(graph), bool(overlap)
+        flags = (L.F_OBS_F64 if obs_dtype == torch.float64 else 0) | (L.F_ACTION_F64 if action_dtype == torch.float64 else 0) | (L.F_PROFILE if profile else 0) | (L.F_IMAGE if image else 0) | (L.F_OVERLAP if overlap else 0)
+        self.overlap = bool(overlap)
         self.image = bool(image)
         self._action_bits = L.ACTION_RESCALE_F32 if (rescale_f32 and action_dtype == torch.float32) else 0
         h = C.c_void_p()
@@ -68,7 +66,6 @@ class ParkingBatch:
         self.rs_word.fill_(-1)
         if not image:
             self.img = None
-        self._act_buf = torch.zeros((n, 2), dtype=action_dtype, device=dev) if graph else None
         self._done_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
         # observation-only view for turnover(): the finished step's reward / status / done / RS outputs are kept
         self._out_obs = L.StepOut(self.lidar.data_ptr(), self.action_mask.data_ptr(), self.target.data_ptr(), None, None, None,
@@ -261,9 +258,6 @@ class ParkingBatch:
         stages |= self._action_bits
         assert actions.shape == (self.n, 2) and actions.dtype == self.action_dtype and actions.is_contiguous()
         assert actions.device == self.device
-        if self._act_buf is not None and actions.data_ptr() != self._act_buf.data_ptr():
-            self._act_buf.copy_(actions)                  # stable pointer: the captured graph is replayed
-            actions = self._act_buf
         ap = C.c_void_p(active.data_ptr()) if active is not None else None
         L.check(self.lib.hope_env_step(self.h, C.c_void_p(actions.data_ptr()), ap, stages, C.byref(self._out),
                                        self._stream()), 'hope_env_step')

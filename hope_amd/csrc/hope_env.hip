@@ -128,25 +128,8 @@ struct hope_env {
     // HOPE_DEFER_RS: the chains of the last step have not been joined into the caller's stream (events ev_join[1], ev_join[RS_SIDE])
     static constexpr int RS_SIDE = 5;                       // the stream of the first chain when it may not run on the caller's
     bool rs_pending = false;
-    // HOPE_F_GRAPH: the launches of one step, captured on a library stream and replayed while the arguments repeat
-    hipStream_t gstream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    struct GraphKey {
-        const void* actions; const uint8_t* active; uint32_t stages; int has_action; hope_step_out out; const StepCold* cold;
-        bool operator==(const GraphKey& o) const {
-            return actions == o.actions && active == o.active && stages == o.stages && has_action == o.has_action && cold == o.cold &&
-                   memcmp(&out, &o.out, sizeof(out)) == 0;
-        }
-    };
-    struct GraphEntry { GraphKey key; hipGraphExec_t exec; uint64_t used; };
-    std::vector<GraphEntry> graphs;
-    uint64_t graph_clock = 0;
 };
 
-static void drop_graphs(hope_env* h) {
-    for (auto& g : h->graphs) hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
-}
 
 // every entry point runs on the handle's device and puts the caller's current device back (a process that drives
 // several GPUs keeps PyTorch's notion of the current device)
@@ -468,8 +451,8 @@ int hope_abi_version(void) { return HOPE_ABI_VERSION; }
 
 int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int device_id, uint32_t flags) {
     if (!out || n_scenes <= 0 || max_obstacles <= 0) return fail(HOPE_EINVAL, "hope_env_create: bad argument");
-    if ((flags & HOPE_F_GRAPH) && (flags & HOPE_F_PROFILE))
-        return fail(HOPE_EINVAL, "hope_env_create: HOPE_F_GRAPH cannot be combined with HOPE_F_PROFILE (event timing inside a captured graph)");
+    if (flags & 0x20)
+        return fail(HOPE_EINVAL, "hope_env_create: flag 0x20 (hipGraph replay of the step, ABI <= 6) was removed in ABI 7: it was slower than plain launches at every batch size");
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -584,7 +567,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
                               (const void*)k_env_step<double, float, false, 2>, (const void*)k_env_step<double, double, false, 2>})
             HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (flags & (HOPE_F_OVERLAP | HOPE_F_GRAPH)) {
+    if (flags & HOPE_F_OVERLAP) {
         const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -633,11 +616,6 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         }
         for (int r = 1; r < hope_env::MAX_CHAINS; r++) h->side[r] = created[perm[r]];
     }
-    if (flags & HOPE_F_GRAPH) {
-        HIPCHK(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
-    }
     HIPCHK(hipDeviceSynchronize());
     *out = h;
     return HOPE_OK;
@@ -649,13 +627,11 @@ int hope_env_destroy(hope_env_t* h) {
     DeviceGuard guard(h->device);
     drain_events(h);
     hipDeviceSynchronize();
-    drop_graphs(h);
-    for (hipEvent_t e : {h->ev_fork, h->ev_in, h->ev_out, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_fork, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
     for (int i = 0; i < hope_env::MAX_CHAINS; i++) {
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
         if (h->side[i]) hipStreamDestroy(h->side[i]);
     }
-    if (h->gstream) hipStreamDestroy(h->gstream);
     if (h->pool_stream) hipStreamDestroy(h->pool_stream);
     for (hipEvent_t e : h->cold_ev) if (e) hipEventDestroy(e);
     if (h->cold_host) hipHostFree(h->cold_host);
@@ -816,7 +792,6 @@ int hope_env_set_scenes(hope_env_t* h, const int32_t* scene_ids, int n, const do
     }
     { int rc = rebuild_class_lists(h); if (rc != HOPE_OK) return rc; }
     HIPCHK(hipDeviceSynchronize());
-    drop_graphs(h);                                         // grids depend on the class sizes
     h->have_scenes = true;
     return HOPE_OK;
 }
@@ -910,7 +885,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     // HOPE_DEFER_RS: both chains on library streams, the caller's stream joins the observation half only (hope_env.h)
     // (measured: 32 768 scenes 0.433 -> 0.426 ms, 65 536 0.681 -> 0.669; 16 384 0.322 -> 0.361: below 32 768 the joined form)
     const char* defer_min = getenv("HOPE_DEFER_MIN");
-    const bool defer = split && (stages & HOPE_DEFER_RS) && !(h->flags & HOPE_F_GRAPH) &&
+    const bool defer = split && (stages & HOPE_DEFER_RS) &&
                        h->n >= (defer_min ? atoi(defer_min) : split_min ? atoi(split_min) : 32768);
     if (!defer) { int rcj = join_rs(h, s); if (rcj != HOPE_OK) return rcj; }    // (a deferred step's launches follow the unjoined ones on the same streams)
     // PIPELINED steps (round 4; with HOPE_DEFER_RS, HOPE_PIPE=0 switches it off): each tile class runs on TWO library streams --
@@ -925,7 +900,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     // the one step k + 1 uses while step k's validation blocks are still reading theirs).
     static const bool pipe_env = !(getenv("HOPE_PIPE") && atoi(getenv("HOPE_PIPE")) == 0);
     const bool pipe = defer && pipe_env && n_chain == 2;
-    if (want_rs && !(h->flags & HOPE_F_GRAPH)) h->rs_parity ^= 1;
+    if (want_rs) h->rs_parity ^= 1;
     if (fork) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         for (int i = 1; i < n_streams; i++) HIPCHK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
@@ -1123,40 +1098,6 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
         hope_env_t* h; hipStream_t s;
         ~LastStep() { if (h->pactive >= 0 && h->ev_last_step) hipEventRecord(h->ev_last_step, s); }
     } last_step{h, s};
-    if (h->flags & HOPE_F_GRAPH) {
-        // The caller's stream may be the null stream, which cannot be captured: the graph lives on a library stream that
-        // is ordered after / before the caller's stream with two events.
-        hope_env::GraphKey key{actions, active, stages, has_action, *out, h->cold_dev + h->cold_idx};
-        hope_env::GraphEntry* hit = nullptr;
-        for (auto& g : h->graphs) if (g.key == key) { hit = &g; break; }
-        if (!hit) {
-            if (h->graphs.size() >= 64) {                    // evict the least recently used
-                size_t o = 0;
-                for (size_t i = 1; i < h->graphs.size(); i++) if (h->graphs[i].used < h->graphs[o].used) o = i;
-                hipGraphExecDestroy(h->graphs[o].exec);
-                h->graphs.erase(h->graphs.begin() + o);
-            }
-            hipGraph_t graph = nullptr;
-            HIPCHK(hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_step(h, actions, active, stages, out, h->gstream, (h->flags & HOPE_F_OVERLAP) != 0, has_action, nullptr);
-            hipError_t e = hipStreamEndCapture(h->gstream, &graph);
-            if (rc != HOPE_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-            if (e != hipSuccess) return fail(HOPE_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            hipGraphExec_t exec = nullptr;
-            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
-            if (e != hipSuccess) return fail(HOPE_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-            h->graphs.push_back({key, exec, 0});
-            hit = &h->graphs.back();
-        }
-        hit->used = ++h->graph_clock;
-        HIPCHK(hipEventRecord(h->ev_in, s));
-        HIPCHK(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
-        HIPCHK(hipGraphLaunch(hit->exec, h->gstream));
-        HIPCHK(hipEventRecord(h->ev_out, h->gstream));
-        HIPCHK(hipStreamWaitEvent(s, h->ev_out, 0));
-        return HOPE_OK;
-    }
     if (prof && h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
     EventTimer timer(h);
     LaunchTimer* tm = prof ? &timer : nullptr;
@@ -1339,7 +1280,6 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     h->pool_wait_pending = true;
     h->pool_generation++;
     (void)stream;
-    drop_graphs(h);                                         // the pool pointers are kernel arguments of the captured launches
     return HOPE_OK;
 }
 
@@ -1379,7 +1319,6 @@ static int refresh_pool_lists_sync(hope_env_t* h) {
     h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
     h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
     h->pool_generation++;
-    drop_graphs(h);
     return HOPE_OK;
 }
 
@@ -1433,7 +1372,6 @@ int hope_env_set_draw_class(hope_env_t* h, const int32_t* scene_ids, int n, cons
     int rc = rebuild_class_lists(h);
     if (rc != HOPE_OK) return rc;
     HIPCHK(hipDeviceSynchronize());
-    drop_graphs(h);
     return HOPE_OK;
 }
 
@@ -1472,7 +1410,6 @@ int hope_env_download_scenes(hope_env_t* h, const int32_t* scene_ids, int n, dou
 int hope_env_set_redraw_seed(hope_env_t* h, uint64_t seed) {
     if (!h) return fail(HOPE_EINVAL, "hope_env_set_redraw_seed: null handle");
     h->redraw_seed = seed;
-    drop_graphs(h);                                         // the seed is a kernel argument of the captured launches
     return HOPE_OK;
 }
 

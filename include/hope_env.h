@@ -73,9 +73,10 @@ extern "C" {
 #define HOPE_F_OVERLAP 0x10     /* launch the two obstacle-tile classes of a step on two streams (fork / join with events),
                                    and from 16 k scenes on the observation half of the step kernel on further streams
                                    next to the Reeds-Shepp kernels: one chain alone leaves issue slots idle */
-#define HOPE_F_GRAPH 0x20       /* capture the launches of a step into a hipGraph on a library stream (ordered against the
-                                   caller's stream with two events) and replay it while the arguments repeat: same
-                                   actions / active / out pointers and stages.  Not combinable with HOPE_F_PROFILE */
+/* 0x20 was HOPE_F_GRAPH (hipGraph replay of a step's launches, ABI <= 6).  Removed in ABI 7: measured slower than plain asynchronous
+ * launches at every batch size (4 096 scenes 0.269 vs 0.237 ms, 8 192 0.293 vs 0.263, 16 384 0.511 vs 0.352; profiles/r04_bench_modes.txt
+ * of the commit before the removal) -- the launches are not host-bound, and the runtime runs a captured multi-stream graph on fewer
+ * queues than the streams it was captured from.  hope_env_create rejects the bit. */
 
 /* Environment variables read by the library (tuning / diagnostics only; results never depend on them):
  *   HOPE_SPLIT_MIN   scenes per handle from which HOPE_F_OVERLAP launches k_env_step as a motion and an observation
@@ -125,7 +126,7 @@ extern "C" {
  * rs_lengths are ordered by hope_env_wait_rs(h, stream) (the planner override just before the next step), or by the next
  * hope_env_step itself: its launches follow the unfinished ones on the same library streams, so consecutive steps
  * pipeline.  The outputs are the same bits either way.  The bit takes effect in the two-launch form of the step and from
- * 32 768 scenes on (handles with HOPE_F_OVERLAP, without HOPE_F_GRAPH; below that size the joined form is the faster one);
+ * 32 768 scenes on (handles with HOPE_F_OVERLAP; below that size the joined form is the faster one);
  * elsewhere the step is joined as without it and hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself.
  * Lifetime of the inputs: `actions` and `active` are only read by launches `stream` is ordered after when hope_env_step returns
  * (the Reeds-Shepp chain reads a snapshot of `active` that the motion launch takes into a buffer of the handle), so the caller

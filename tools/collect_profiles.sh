@@ -46,7 +46,6 @@ py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
 {
   for NS in 4096 8192 16384 32768 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 2 --steps 40 --warmup 10 | tail -1; done
   echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
-  echo "== --scenes 8192 --graph"; py $R/bench.py --scenes 8192 --graph --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
   echo "== --same-map"; py $R/bench.py --same-map --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 | tail -1
   echo "== HOPE_PIPE=0 (steps not pipelined: the round-3 launch structure with this round's kernels)"; HOPE_PIPE=0 $T python $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   echo "== config 2: --stages motion --scenes 4096"; py $R/bench.py --scenes 4096 --stages motion --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
