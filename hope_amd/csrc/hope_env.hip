@@ -884,9 +884,16 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
                        h->n >= (split_min ? atoi(split_min) : 16384);
     // HOPE_DEFER_RS: both chains on library streams, the caller's stream joins the observation half only (hope_env.h)
     // (measured: 32 768 scenes 0.433 -> 0.426 ms, 65 536 0.681 -> 0.669; 16 384 0.322 -> 0.361: below 32 768 the joined form)
+    // Round 4: with pipelined steps (below) the bit pays at every batch size, in the one-launch form of the step kernel too (pipe1:
+    // env stream = k_kinematics -> k_env_step, search stream = k_post -> k_rs_compact -> ... -> k_rs_validate_f): a small batch is
+    // launch-latency bound, seven dependent launches per class, and overlapping the search of step k with the env launches of step
+    // k + 1 hides most of that chain (8 192 scenes 0.266 -> see RESULTS.md).  HOPE_DEFER_MIN restores a threshold.
+    static const bool pipe_env = !(getenv("HOPE_PIPE") && atoi(getenv("HOPE_PIPE")) == 0);
     const char* defer_min = getenv("HOPE_DEFER_MIN");
-    const bool defer = split && (stages & HOPE_DEFER_RS) &&
-                       h->n >= (defer_min ? atoi(defer_min) : split_min ? atoi(split_min) : 32768);
+    const bool defer_ok = fork && n_chain == 2 && want_rs && (stages & HOPE_STAGE_OBS) && !step_timing && (stages & HOPE_DEFER_RS) &&
+                          h->n >= (defer_min ? atoi(defer_min) : pipe_env ? 0 : 32768);
+    const bool pipe1 = defer_ok && !split && pipe_env;      // pipelined steps with the one-launch step kernel
+    const bool defer = (split && defer_ok) || pipe1;
     if (!defer) { int rcj = join_rs(h, s); if (rcj != HOPE_OK) return rcj; }    // (a deferred step's launches follow the unjoined ones on the same streams)
     // PIPELINED steps (round 4; with HOPE_DEFER_RS, HOPE_PIPE=0 switches it off): each tile class runs on TWO library streams --
     //   env stream  : k_kinematics -> k_env_step<motion> -> k_env_step<observation> -> k_post     (what the caller's stream joins)
@@ -898,7 +905,6 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     // (k_rs_compact of step k + 1 clears it, after the validation kernel, on the same stream), and all reads stay inside the
     // scene's own tile slots.  The queue counter alternates between two words per chain (the motion launch of step k + 1 zeroes
     // the one step k + 1 uses while step k's validation blocks are still reading theirs).
-    static const bool pipe_env = !(getenv("HOPE_PIPE") && atoi(getenv("HOPE_PIPE")) == 0);
     const bool pipe = defer && pipe_env && n_chain == 2;
     if (want_rs) h->rs_parity ^= 1;
     if (fork) {
@@ -917,7 +923,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // through the LDS request.)
         static const int obs_side[2] = {getenv("HOPE_OBS_SIDE0") ? atoi(getenv("HOPE_OBS_SIDE0")) : 3, getenv("HOPE_OBS_SIDE1") ? atoi(getenv("HOPE_OBS_SIDE1")) : 4};
         static const int obs_wpc[2] = {getenv("HOPE_OBS_WPC0") ? atoi(getenv("HOPE_OBS_WPC0")) : 0, getenv("HOPE_OBS_WPC1") ? atoi(getenv("HOPE_OBS_WPC1")) : 0};
-        hipStream_t so = split ? h->side[std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
+        hipStream_t so = (split || pipe1) ? h->side[std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
         // pipelined: the env stream of the class with MORE scenes is the caller's stream itself -- its kernels are the step's critical
         // cycle (kinematics -> motion -> observation -> the caller's next actions -> kinematics ...), and every hop between a library
         // stream and the caller's costs that cycle 20-30 us (two hops per step: 0.648 -> 0.60 ms).  Not with the image, which
@@ -955,7 +961,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else if (step_timing && !of64 && !af64) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sk, p);
         else launch_env_step<0>(of64, af64, grid, block, lds, sk, p);
         if (tm) tm->end(sk);
-        if (fork && n_chain == 2 && (split || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sk));   // poses final
+        if (fork && n_chain == 2 && (split || pipe || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sk));   // poses final
         if (split && !pipe) HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
         // k_post BEHIND the observation half on that stream: nothing waits for its outputs before the join, the observation is the
         // long launch (0.675 -> 0.669 ms; HOPE_POST_LAST=0: the round-3 order)
@@ -975,7 +981,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             if (tm) tm->end(so);
             if (post_last && !post_rs) launch_post();
             if (!on_caller) HIPCHK(hipEventRecord(h->ev_join[3 + i], so));   // (the event index stays 3 + i whatever stream carries the launch)
-        }
+        } else if (pipe1 && !on_caller) HIPCHK(hipEventRecord(h->ev_join[3 + i], so));     // one-launch form: the observation is part of it
         if (!want_rs) continue;
         if (pipe) HIPCHK(hipStreamWaitEvent(sc, h->ev_step[i], 0));  // the search stream starts behind this step's motion launch
         if (post_rs) {
@@ -1046,7 +1052,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         } else
             for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
         if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
-        if (split) for (int i = 0; i < 2; i++) {
+        if (split || pipe1) for (int i = 0; i < 2; i++) {
             if (!joined_on_caller[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
             if (post_on_rs[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_post[i], 0));
         }

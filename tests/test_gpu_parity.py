@@ -472,15 +472,18 @@ def _overlap_modes_body(ParkingBatch, SceneSource):
         e.close()
 
 
-def test_deferred_rs_join_equals_the_joined_step():
+@pytest.mark.parametrize('two_launch', [True, False])
+def test_deferred_rs_join_equals_the_joined_step(two_launch):
     """HOPE_DEFER_RS (two completion points per step: the caller's stream is ordered after the observation half, the
-    Reeds-Shepp outputs by hope_env_wait_rs or by the next step on the library's streams) must produce the same bits as the
-    joined step: every output, every step, with auto-reset on new maps; entry points that read the state while the search of
-    the last step is still unjoined (download_state, restart) join by themselves."""
+    Reeds-Shepp outputs by hope_env_wait_rs; consecutive steps PIPELINE across the library's env and search streams) must produce
+    the same bits as the joined step: every output, every step, with auto-reset on new maps; entry points that read the state
+    while the search of the last step is still unjoined (download_state, restart) join by themselves.  Both forms of the step
+    kernel: two launches (motion / observation; forced at this size with HOPE_SPLIT_MIN) and one launch (small batches)."""
     import os
     from hope_amd import ParkingBatch
     from hope_amd.scene_gen import mixed_arrays, generate_arrays
-    os.environ['HOPE_SPLIT_MIN'] = '1'
+    if two_launch:
+        os.environ['HOPE_SPLIT_MIN'] = '1'
     try:
         n = 6144
         arrs = mixed_arrays(n, seed=77, max_obst=128)
@@ -540,7 +543,7 @@ def test_deferred_rs_join_equals_the_joined_step():
         for e in envs:
             e.close()
     finally:
-        del os.environ['HOPE_SPLIT_MIN']
+        os.environ.pop('HOPE_SPLIT_MIN', None)
 
 
 def test_config3_exact_size_16384_scenes():
