@@ -880,8 +880,11 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     static const bool no_split = getenv("HOPE_NO_SPLIT") != nullptr;
     // (measured: +4.5 % at 65 536 scenes, +3.7 % at 131 072, 0 at 16 384, -3 % at 8 192 and below: two more launches per class)
     const char* split_min = getenv("HOPE_SPLIT_MIN");      // (read per call: the tests force the split at small sizes)
+    // (with pipelined steps -- HOPE_DEFER_RS, below -- the one-launch form stays the faster one up to 32 768 scenes: 16 384 scenes
+    // 0.249 vs 0.266 ms)
+    static const bool pipe_env0 = !(getenv("HOPE_PIPE") && atoi(getenv("HOPE_PIPE")) == 0);
     const bool split = fork && n_chain == 2 && want_rs && (stages & HOPE_STAGE_OBS) && !step_timing && !no_split &&
-                       h->n >= (split_min ? atoi(split_min) : 16384);
+                       h->n >= (split_min ? atoi(split_min) : ((stages & HOPE_DEFER_RS) && pipe_env0) ? 32768 : 16384);
     // HOPE_DEFER_RS: both chains on library streams, the caller's stream joins the observation half only (hope_env.h)
     // (measured: 32 768 scenes 0.433 -> 0.426 ms, 65 536 0.681 -> 0.669; 16 384 0.322 -> 0.361: below 32 768 the joined form)
     // Round 4: with pipelined steps (below) the bit pays at every batch size, in the one-launch form of the step kernel too (pipe1:
@@ -933,8 +936,10 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (on_caller) so = s;
         // ... and k_post, whose outputs the caller's stream joins too, runs at the head of the search stream instead of behind the
         // observation launch (the search stream has slack, the env stream is the critical one)
-        static const bool post_on_search = !(getenv("HOPE_POST_SEARCH") && atoi(getenv("HOPE_POST_SEARCH")) == 0);
-        const bool post_rs = pipe && want_rs && post_on_search;
+        // (two-launch form only: in the one-launch form of small batches k_post stays behind the step kernel on the env stream --
+        // 8 192 scenes 0.205 vs 0.188 ms -- the search chain is the longer one there; HOPE_POST_SEARCH=0 / 1 forces either)
+        static const int post_on_search = getenv("HOPE_POST_SEARCH") ? atoi(getenv("HOPE_POST_SEARCH")) : -1;
+        const bool post_rs = pipe && want_rs && (post_on_search < 0 ? split : post_on_search != 0);
         if (i < 2) { joined_on_caller[i] = on_caller; post_on_rs[i] = post_rs; }
         hipStream_t sk = pipe ? so : sc;                        // the stream of the kinematics and the motion launch
         if (pipe && !on_caller) HIPCHK(hipStreamWaitEvent(sk, h->ev_fork, 0));
