@@ -566,8 +566,15 @@ def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's
     rng = np.random.default_rng(args.seed)
     acts = [rng.uniform(-1, 1, (n, 2)) for _ in range(args.cpu_steps)]
     res = {}
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    omp_default = O.lib(True).orc_num_threads()      # what OpenMP picks by itself (OMP_NUM_THREADS / its own CPU count)
+    if hasattr(O.lib(True), 'orc_set_num_threads'):
+        O.lib(True).orc_set_num_threads(int(usable)) # the all-core figure uses every CPU this process may run on
     for omp in (False, True):
-        rep = 8 if omp else 1                        # the all-core run gets 8x the scenes to keep threads busy
+        rep = 16 if omp else 1                       # the all-core run gets 16x the scenes to keep the threads busy
         nn = n * rep
         orc = O.BatchOracle(nn, args.max_obst, omp=omp)
         tl = lambda x: np.concatenate([x] * rep, axis=0)  # noqa: E731
@@ -585,17 +592,13 @@ def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's
         dt = time.perf_counter() - t0
         res[omp] = nn * args.cpu_steps / dt
     cores = os.cpu_count() or 1
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = cores
     return {'value': res[False], 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
             'sample': f'first {n} scenes of the bench scene set x {args.cpu_steps} steps, same stages/actions, '
                       'oracle/hope_oracle.c (gcc -O2), 1 thread',
             'allcore_value': res[True], 'allcore_threads': O.lib(True).orc_num_threads(), 'host_cores': cores,
-            'host_cpus_usable': usable,
-            'allcore_note': 'OpenMP over scenes with omp_get_max_threads() threads = the CPUs this process may run on (affinity / '
-                            'cgroup), which can be fewer than the hardware threads os.cpu_count() reports (host_cores)'}
+            'host_cpus_usable': usable, 'openmp_default_threads': omp_default,
+            'allcore_note': 'OpenMP over scenes (16x the sample) with one thread per CPU this process may run on (sched_getaffinity); '
+                            'openmp_default_threads is what libgomp would have picked by itself on this box'}
 
 
 if __name__ == '__main__':

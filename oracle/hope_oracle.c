@@ -1394,6 +1394,16 @@ int orc_num_threads(void) {
 #endif
 }
 
+/* the OpenMP build's team size for the following batch calls (bench.py's all-core baseline: every CPU the process may use) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* elementary-function test hook: fn 0 sin, 1 cos, 2 tan, 3 atan2(a,b), 4 asin, 5 acos, 6 hypot(a,b), 7 fmod(a,b), 8 tanh,
  * 9 exp, 10 sqrt, 11 a/b */
 void orc_math(int fn, int n, const double *a, const double *b, double *out) {
