@@ -126,9 +126,9 @@ extern "C" {
  * rs_lengths are ordered by hope_env_wait_rs(h, stream) (the planner override just before the next step).  A caller that does
  * not read them enqueues the next hope_env_step without waiting: the search of step k then runs on the library's search streams
  * NEXT TO the kinematics / motion / observation launches of step k + 1 (consecutive steps pipeline; ABI 7), and its rs_word /
- * rs_lengths are replaced by step k + 1's -- they can only be read after a hope_env_wait_rs issued BEFORE the next step.  The outputs are the same bits either way.  The bit takes effect in the two-launch form of the step and from
- * 32 768 scenes on (handles with HOPE_F_OVERLAP; below that size the joined form is the faster one);
- * elsewhere the step is joined as without it and hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself.
+ * rs_lengths are replaced by step k + 1's -- they can only be read after a hope_env_wait_rs issued BEFORE the next step.  The outputs are the same bits either way.  The bit takes effect on handles with HOPE_F_OVERLAP whose scenes
+ * span both obstacle-tile classes, at every batch size (the one-launch form of the step kernel below 32 768 scenes, the two-launch
+ * form from there on); elsewhere the step is joined as without it and hope_env_wait_rs is a no-op.  Every other entry point that reads or writes the handle's state joins first by itself.
  * Lifetime of the inputs: `actions` and `active` are only read by launches `stream` is ordered after when hope_env_step returns
  * (the Reeds-Shepp chain reads a snapshot of `active` that the motion launch takes into a buffer of the handle), so the caller
  * may free or overwrite both right after the call, in stream order, as without the bit. */

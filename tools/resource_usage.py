@@ -24,7 +24,7 @@ def main():
     show_all = '--all' in sys.argv
     rows = []
     for src in ('hope_env.hip', 'hope_rs.hip', 'hope_bev.hip'):
-        flags = [f for f in FLAGS if f not in ('-shared', '-pthread')]
+        flags = [f for f in FLAGS if f not in ('-shared', '-pthread')] + os.environ.get('HOPE_BUILD_DEFS', '').split()
         cmd = ['/opt/rocm/bin/hipcc'] + flags + ['-I' + os.path.join(ROOT, 'include'), '-I' + CS, '--cuda-device-only',
                '-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CS, src), '-o', '/dev/null']
         err = subprocess.run(cmd, capture_output=True, text=True).stderr
