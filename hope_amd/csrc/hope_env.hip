@@ -537,6 +537,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_count, 0, 2 * hope_env::MAX_CHAINS * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_flag, 0, N));
+    HIPCHK(hipMemset(h->rs_list, 0, 2 * N * sizeof(int32_t)));      // (k_rs_words / k_rs_segs read queue entries before they know the queue length)
     HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
     HIPCHK(hipMemset(h->pool_overflow, 0, sizeof(int32_t)));

@@ -393,10 +393,12 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     set_wave_prio(p.prio_front);
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
     const int qi = blockIdx.x * RSA_SCENES + ls;
+    // the queue entry is requested BEFORE the queue length is known (one memory round trip less): entries at or beyond the count
+    // are stale or zero (hope_env_create clears the list) -- valid scene numbers either way, and lanes without work store nothing
+    const int scene = p.rs_list[qi < p.max_queue ? qi : p.max_queue - 1];
     const int count = *p.rs_count;
     if ((int)blockIdx.x * RSA_SCENES >= count) return;
     const bool live = qi < count;
-    const int scene = p.rs_list[live ? qi : 0];
     const int slot = p.slot_base + p.slot_dir * (live ? qi : 0);
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double* st = p.state + (size_t)scene * ST_WORDS;
@@ -518,20 +520,32 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     __shared__ unsigned char hidl[8][RS_WORDS_PER_SCENE];     // heap ids (candidate slot)
     __shared__ unsigned char ordl[8][RS_WORDS_PER_SCENE];     // pop order
     __shared__ int ntl[8];
+    __shared__ double hdrl[8][8];                            // per search: start pose x, y, heading, map box xmin, xmax, ymin, ymax
     const int lane = threadIdx.x, ls = lane >> 3, k0 = lane & 7;
+    // queue entry and candidate keys are requested BEFORE the queue length is known (see k_rs_words): a memory round trip less
+    const int qi = blockIdx.x * 8 + ls;
+    const int qs = qi < p.max_queue ? qi : p.max_queue - 1;
+    const int scene = p.rs_list[qs];
+    double* rec = p.rs_rec + (size_t)(p.slot_base + p.slot_dir * qs) * RS_REC_DOUBLES;
+    double keyv[RS_WORDS_PER_SCENE / 8];
+#pragma unroll
+    for (int j = 0; j < RS_WORDS_PER_SCENE / 8; j++) keyv[j] = rec[RS_REC_KEYS + 8 * j + k0];
     const int count = *p.rs_count;
     if ((int)blockIdx.x * 8 >= count) return;
-    const int qi = blockIdx.x * 8 + ls;
     const bool live = qi < count;
-    const int slot = p.slot_base + p.slot_dir * (live ? qi : 0);
-    double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
-    const int scene = p.rs_list[live ? qi : 0];
     const double* st = p.state + (size_t)scene * ST_WORDS;
+    // the header's inputs, requested now: they arrive while lane 0 replays the heap
+    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+    double hdr = 0.0;                                       // lanes k0 = 0 .. 6 of a search: pose x, y, heading, map box
+    int hdr_n = 0;
+    if (k0 < 3) hdr = st[k0];
+    else if (k0 < 7) hdr = sc[SC_BBOX + k0 - 3];
+    else hdr_n = p.n_obst[scene];
     // the kept candidates of the search as a bit mask (bit c = candidate slot c): eight lanes x six keys, one ballot per stride
     unsigned long long keptm = 0;
 #pragma unroll
     for (int j = 0; j < RS_WORDS_PER_SCENE / 8; j++) {
-        const double key = live ? rec[RS_REC_KEYS + 8 * j + k0] : -1.0;
+        const double key = live ? keyv[j] : -1.0;
         keyl[ls][8 * j + k0] = key;
         keptm |= ((__ballot(key >= 0.0) >> (8 * ls)) & 0xffull) << (8 * j);
     }
@@ -579,22 +593,24 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
             }
         }
         ntl[ls] = no;
-        // header: everything k_rs_validate needs before it can stage the obstacle tile
-        const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
-        ((int2*)rec)[0] = make_int2(scene, p.n_obst[scene]);
         ((int2*)rec)[1] = make_int2(n_kept, no);
-        rec[2] = st[0]; rec[3] = st[1]; rec[4] = st[2];
-        rec[5] = sc[SC_BBOX]; rec[6] = sc[SC_BBOX + 1]; rec[7] = sc[SC_BBOX + 2]; rec[8] = sc[SC_BBOX + 3];
+    }
+    if (live) {
+        // header: everything k_rs_validate needs before it can stage the obstacle tile -- [0] scene, n_obst [1] candidates kept,
+        // words to test [2..4] start pose [5..8] map box; one field per lane of the search's eight
+        if (k0 < 7) rec[2 + k0] = hdr;
+        else ((int2*)rec)[0] = make_int2(scene, hdr_n);
+        hdrl[ls][k0] = hdr;
     }
     __syncthreads();
     if (!live) return;
     const int n_test = ntl[ls];
     const unsigned char* order = ordl[ls];
-    const double q0w = st[2];
+    const double q0w = hdrl[ls][2];
     double sq0, cq0;                                      // world heading of the start pose: rotation local course -> world
     hm_sincos(q0w, &sq0, &cq0);
     // start position in the frame of the scene's float32 obstacle view (origin = map box xmin, ymin: integers)
-    const double fq0x = st[0] - p.scene_c[(size_t)scene * SC_WORDS + SC_BBOX], fq0y = st[1] - p.scene_c[(size_t)scene * SC_WORDS + SC_BBOX + 2];
+    const double fq0x = hdrl[ls][0] - hdrl[ls][3], fq0y = hdrl[ls][1] - hdrl[ls][5];
     for (int k = k0; k < n_test; k += 8) {
         const double* W = rec + RS_REC_WORDS + 8 * (int)order[k];
         double len[5];
@@ -1024,9 +1040,16 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     unsigned long long tsec[16] = {};
     const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
     RS_T0();
+    // The record is requested BEFORE the queue length is known (one memory round trip less in front of every search): scene_of_block
+    // depends on the count only in the queue's last 64 entries, and any block's guess lies inside this chain's record slots.
+    const int b_ = (int)blockIdx.x;
+    const int q_guess = ((b_ | 63) < p.max_queue) ? (b_ ^ ((b_ >> 3) & 7)) : b_;
+    const double* rec_guess = p.rs_rec + (size_t)(p.slot_base + p.slot_dir * q_guess) * RS_REC_DOUBLES;
+    double r0 = lane < RS_REC_HDR ? rec_guess[lane] : 0.0;
+    double tb = lane < RS_SEG_TABLE ? rec_guess[RS_REC_SEGS + lane] : 0.0;
     const int count = *p.rs_count;
-    if ((int)blockIdx.x >= count) return;
-    const int qidx = scene_of_block(blockIdx.x, count);
+    if (b_ >= count) return;
+    const int qidx = scene_of_block(b_, count);
     const int slot = p.slot_base + p.slot_dir * qidx;
     // LDS: float2 V[4 cap] | float4 box[cap] | float64 tile 8 cap + world boxes float4[cap] (filled when the first pass needs the
     //      float64 arithmetic) | scratch doubles: segment table 50, sample queue pd[256], bad1[8] | int cand[cap] | bytes: qseg[256],
@@ -1043,9 +1066,11 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     unsigned char* eflag = qseg + RSB_QCAP;
 
     const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
-    const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
     const double* tables = rec + RS_REC_SEGS;
-    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
+    if (qidx != q_guess) {                                // (only in the queue's last, partial group of 64)
+        r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
+        tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
+    }
     const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);
     if (n_paths == 0) return;
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
