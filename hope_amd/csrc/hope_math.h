@@ -68,7 +68,7 @@ HM_FN void hm_sincos(double x, double* s, double* c) {
     double r = fma(-kd, 1.5707963267341256, ax);
     r = fma(-kd, 6.077100506303966e-11, r);
     r = fma(-kd, 2.0222662487959506e-21, r);
-    const int q = (int)((long long)kd & 3);
+    const int q = (int)kd & 3;                        /* (|kd| < 2^31: one conversion instruction on the GPU instead of the 64-bit sequence) */
     const double ks = hm_ksin(r), kc = hm_kcos(r);
     double ss = (q & 1) ? kc : ks;
     double cc = (q & 1) ? ks : kc;

@@ -535,6 +535,22 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// x / 20.0 exactly as IEEE division rounds it, in three instructions instead of the ~11 of the general division (two per round of
+// the micro-step loop).  R = RN(1/20) = RN(0.8) 2^-4 has relative error 2^-54 (0.8 = 0x3FE999999999999A, rounded up by 0.4 ulp).
+// q0 = RN(x R) lies within one ulp of x / 20 (0.4 ulp from R + 0.5 ulp rounding for quotients in [1, 1.6) 2^k; 0.5 + 0.5 in
+// [0.8, 1) 2^k), so the remainder r = x - 20 q0 is representable and the fma delivers it exactly; x / 20 = q0 + r / 20, and
+// q0 + r R differs from it by at most 2^-54 ulp.  That cannot move it across a rounding boundary: with x = X 2^e (X a 53-bit
+// integer) the quotient is 4 X / 5 or 8 X / 5 ulps, whose distance to any midpoint m + 1/2 is an odd integer over 10: >= 0.1 ulp.
+// So RN(q0 + r R) = RN(x / 20) for every x without under- / overflow (the terms here are ~1e-3 .. 1e-1).  Pose parity (tolerance
+// 0.0, tests/test_gpu_parity.py) compares the sums of these quotients with the oracle's plain divisions.
+static_assert(MINI_ITER == 20, "div_by_20");
+__device__ __forceinline__ double div_by_20(double x) {
+    const double R = 0.05;
+    const double q0 = x * R;
+    const double r = fma(-q0, 20.0, x);
+    return fma(r, R, q0);
+}
+
 template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_list, const double* state, const void* actions,
                                                   const uint8_t* active, uint32_t stages, const double* scene_c, double* kin) {
@@ -575,8 +591,8 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
             const int k = r / (MINI_ITER / 4) - 1;
             out[k] = h; out[10 + k] = c_; out[20 + k] = s_; out[30 + k] = x; out[40 + k] = y;
         }
-        const double tx = speed * c_ * STEP_LENGTH / MINI_ITER;
-        const double ty = speed * s_ * STEP_LENGTH / MINI_ITER;
+        const double tx = div_by_20(speed * c_ * STEP_LENGTH);      // ... / MINI_ITER, correctly rounded (below)
+        const double ty = div_by_20(speed * s_ * STEP_LENGTH);
         // x += ..., y += ... in micro-step order (vehicle.py:90-91): quad broadcasts through DPP (no LDS round trip)
         x += quad_bcast<0>(tx); y += quad_bcast<0>(ty);
         x += quad_bcast<1>(tx); y += quad_bcast<1>(ty);

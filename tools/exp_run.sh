@@ -1,2 +1,3 @@
-echo "== new chain"; HOPE_RS_TIMING=1 timeout 300 python tools/rs_timing.py 2>/dev/null
-echo "== old chain"; HOPE_AMD_LIB=$PWD/hope_amd/libhope_env_bold.so HOPE_RS_TIMING=1 timeout 300 python tools/rs_timing.py 2>/dev/null
+timeout 600 python -m pytest tests/test_math.py -x -q -m gpu 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dropin.py -x -q 2>&1 | tail -3
+bash tools/exp_ab.sh
