@@ -71,6 +71,7 @@ rm -rf $O/tl
 HOPE_STEP_TIMING=1 $T python $R/tools/step_timing.py > $O/${TAG}_env_step_cycles.txt 2>/dev/null
 HOPE_RS_TIMING=1 $T python $R/tools/rs_timing.py > $O/${TAG}_rs_validate_cycles.txt 2>/dev/null
 $T python $R/tools/rs_filter_stats.py --check > $O/${TAG}_rs_filter_stats.txt 2>/dev/null
+$T python $R/tools/rs_filter_stats.py 2>/dev/null | head -3 > $O/${TAG}_rs_filter_stats_nocheck.txt
 $T python $R/tools/rs_bench.py > $O/${TAG}_rs_bench.txt 2>/dev/null
 timeout 900 python $R/tools/soak.py --seeds 10 --scenes 4096 --steps 12 > $O/${TAG}_soak.txt 2>/dev/null
 $T python $R/tools/tie_census.py --scene-steps 2e8 > $O/${TAG}_tie_census.txt 2>/dev/null
