@@ -259,6 +259,7 @@ __global__ void k_debug_math(int fn, int n, const double* a, const double* b, do
         case 8: r = hm_tanh(x); break;
         case 9: r = hm_exp(x); break;
         case 10: r = sqrt(x); break;
+        case 12: r = div_by_20(x); break;                  // k_kinematics' division by MINI_ITER (hope_step_kernel.h)
         default: r = x / y; break;
     }
     out[i] = r;

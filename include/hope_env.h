@@ -294,7 +294,7 @@ int hope_env_upload_state(hope_env_t *h, const double *pose, const int32_t *t, c
 /* ---- test hook ------------------------------------------------------------------------------------------ */
 /* Evaluates one elementary function of hope_amd/csrc/hope_math.h (plus sqrt and division) on the DEVICE for n
  * float64 inputs: fn 0 sin, 1 cos, 2 tan, 3 atan2(a,b), 4 asin, 5 acos, 6 hypot(a,b), 7 fmod(a,b), 8 tanh, 9 exp,
- * 10 sqrt, 11 a/b.  a, b, out are DEVICE pointers (b may be NULL for unary functions).  The functions are built
+ * 10 sqrt, 11 a/b, 12 the kinematics kernel's three-instruction a/20.  a, b, out are DEVICE pointers (b may be NULL for unary functions).  The functions are built
  * from IEEE-exact operations only, so the results must equal the host evaluation bit for bit. */
 int hope_debug_math(int fn, int n, const double *a, const double *b, double *out, void *stream);
 

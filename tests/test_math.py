@@ -69,3 +69,28 @@ def test_device_equals_host_bit_for_bit():
         dev = out.cpu().numpy()
         same = (dev.view(np.int64) == host.view(np.int64)) | (np.isnan(dev) & np.isnan(host))
         assert same.all(), (name, int((~same).sum()), a[~same][:3], dev[~same][:3], host[~same][:3])
+
+
+@pytest.mark.gpu
+def test_kinematics_division_by_20_is_the_ieee_quotient():
+    """k_kinematics divides its 200 displacement terms per step by MINI_ITER = 20 with q0 = x R, r = fma(-q0, 20, x), q = fma(r, R, q0)
+    (R = RN(1/20); proof of correct rounding in hope_step_kernel.h).  Here: the device sequence against numpy's division on 2e6
+    values -- random mantissas over 40 binades and both signs, integers near multiples of 5, near-midpoint quotients, the step's
+    own magnitudes."""
+    torch = pytest.importorskip('torch')
+    from hope_amd import _lib as L
+    lib = L.load_library()
+    rng = np.random.default_rng(5)
+    mant = rng.integers(1 << 52, 1 << 53, 1_000_000).astype(np.float64)
+    x = np.concatenate([
+        np.ldexp(mant, rng.integers(-80, -40, len(mant))) * rng.choice([-1.0, 1.0], len(mant)),
+        (np.float64(1 << 52) + np.arange(200_000)), (np.float64(1 << 53) - 1 - np.arange(200_000)),
+        20.0 * (np.float64(1 << 52) + rng.integers(0, 1 << 40, 200_000)) + rng.integers(-12, 13, 200_000),     # quotients next to integers
+        rng.uniform(-2.5, 2.5, 400_000) * rng.uniform(-1, 1, 400_000) * 5e-2, [0.0, -0.0, 20.0, 1.0, 5e-2, 1e-200, 1e300]])
+    ta = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    out = torch.empty_like(ta)
+    L.check(lib.hope_debug_math(12, ta.numel(), C.c_void_p(ta.data_ptr()), None, C.c_void_p(out.data_ptr()), None), 'hope_debug_math')
+    torch.cuda.synchronize()
+    dev, host = out.cpu().numpy(), x / 20.0
+    same = dev.view(np.int64) == host.view(np.int64)
+    assert same.all(), (int((~same).sum()), x[~same][:3], dev[~same][:3], host[~same][:3])
