@@ -522,17 +522,17 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     __shared__ int ntl[8];
     __shared__ double hdrl[8][8];                            // per search: start pose x, y, heading, map box xmin, xmax, ymin, ymax
     const int lane = threadIdx.x, ls = lane >> 3, k0 = lane & 7;
-    // queue entry and candidate keys are requested BEFORE the queue length is known (see k_rs_words): a memory round trip less
+    // the queue entry is requested BEFORE the queue length is known (see k_rs_words): a memory round trip less
     const int qi = blockIdx.x * 8 + ls;
     const int qs = qi < p.max_queue ? qi : p.max_queue - 1;
     const int scene = p.rs_list[qs];
     double* rec = p.rs_rec + (size_t)(p.slot_base + p.slot_dir * qs) * RS_REC_DOUBLES;
-    double keyv[RS_WORDS_PER_SCENE / 8];
-#pragma unroll
-    for (int j = 0; j < RS_WORDS_PER_SCENE / 8; j++) keyv[j] = rec[RS_REC_KEYS + 8 * j + k0];
     const int count = *p.rs_count;
     if ((int)blockIdx.x * 8 >= count) return;
     const bool live = qi < count;
+    double keyv[RS_WORDS_PER_SCENE / 8];
+#pragma unroll
+    for (int j = 0; j < RS_WORDS_PER_SCENE / 8; j++) keyv[j] = live ? rec[RS_REC_KEYS + 8 * j + k0] : -1.0;
     const double* st = p.state + (size_t)scene * ST_WORDS;
     // the header's inputs, requested now: they arrive while lane 0 replays the heap
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
@@ -1040,13 +1040,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     unsigned long long tsec[16] = {};
     const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
     RS_T0();
-    // The record is requested BEFORE the queue length is known (one memory round trip less in front of every search): scene_of_block
-    // depends on the count only in the queue's last 64 entries, and any block's guess lies inside this chain's record slots.
     const int b_ = (int)blockIdx.x;
-    const int q_guess = ((b_ | 63) < p.max_queue) ? (b_ ^ ((b_ >> 3) & 7)) : b_;
-    const double* rec_guess = p.rs_rec + (size_t)(p.slot_base + p.slot_dir * q_guess) * RS_REC_DOUBLES;
-    double r0 = lane < RS_REC_HDR ? rec_guess[lane] : 0.0;
-    double tb = lane < RS_SEG_TABLE ? rec_guess[RS_REC_SEGS + lane] : 0.0;
     const int count = *p.rs_count;
     if (b_ >= count) return;
     const int qidx = scene_of_block(b_, count);
@@ -1066,11 +1060,9 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     unsigned char* eflag = qseg + RSB_QCAP;
 
     const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
+    const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
     const double* tables = rec + RS_REC_SEGS;
-    if (qidx != q_guess) {                                // (only in the queue's last, partial group of 64)
-        r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
-        tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
-    }
+    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
     const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);
     if (n_paths == 0) return;
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);

@@ -381,14 +381,13 @@ __device__ __forceinline__ int build_near_list_box(const double* tile, int n_obs
 // copied to LDS, compacted: tile slot i = i-th such obstacle, list[i] = i.  Returns their number.
 __device__ __forceinline__ int stage_near(const float4* obb, const double2* src, int n_obst, double bx0, double bx1,
                                           double by0, double by1, double* tile, int* list, int lane,
-                                          const float4* pre,       // &obb[lane] requested before n_obst was known (one round trip less) or null
                                           const uint8_t* gflags = nullptr, uint8_t* lflags = nullptr) {
     int cnt = 0;
     for (int base = 0; base < n_obst; base += WAVE) {
         const int o = base + lane;
         bool near = false;
         if (o < n_obst) {
-            const float4 bb = (pre && base == 0) ? *pre : obb[o];
+            const float4 bb = obb[o];
             near = !((double)bb.x > bx1 || (double)bb.y < bx0 || (double)bb.z > by1 || (double)bb.w < by0);
         }
         const unsigned long long m = __ballot(near);
@@ -704,10 +703,6 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     const int n_slots = 4 * n_obst;
     const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
     const float4* obb_s = p.obb + (size_t)scene * p.max_obst;
-    // (two-launch form: the first 64 obstacle boxes are requested together with n_obst, not after it -- any lane below the tile
-    // capacity reads inside the scene's own slots)
-    float4 bb0;
-    if (PART != 0) bb0 = lane < p.tile_cap ? obb_s[lane] : make_float4(0, 0, 0, 0);
     // (observation launch: this lane's two beam directions too -- four loads that waited a round trip of their own in front of the lidar)
     double bm0, bm1, bm2, bm3;
     if (PART == 2) {
@@ -753,8 +748,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             n_near = build_near_list_box(tile, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), nlist, lane);
         else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
     } else if (moving)
-        n_near = stage_near(obb_s, src, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), tile, nlist, lane, &bb0);
-    else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane, &bb0);
+        n_near = stage_near(obb_s, src, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), tile, nlist, lane);
+    else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
     if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
     wsync();
     ST_T(0);
@@ -963,7 +958,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         // the action-less step's status decides whether _get_reward runs (it only touches accum_arrive_reward)
         wsync();
         const int n_near0 = (PART == 0 || redrawn) ? build_near_list(tile, n_obst, x, y, 3.9, nlist, lane)
-                                                   : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane, nullptr);
+                                                   : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
         wsync();
         const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
         bool cont = !detect_collision(x, y, ct, sn, tile, nlist, n_near0, xl, lane, TIMING ? &cen_und : nullptr) && !(x > xmax || x < xmin || y > ymax || y < ymin);
@@ -1016,7 +1011,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     wsync();                                                  // the near list (same words) is dead
     const double lr = LIDAR_RANGE + 1e-6;
     const uint8_t* eflag_s = p.eflag + (size_t)scene * eflag_stride(p.max_obst);
-    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane, &bb0, eflag_s, cfl)
+    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane, eflag_s, cfl)
                               : build_near_list(tile, n_obst, x, y, lr, llist, lane);
     wsync();
     {
