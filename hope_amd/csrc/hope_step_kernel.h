@@ -547,7 +547,7 @@ __device__ __forceinline__ double div_by_20(double x) {
     const double R = 0.05;
     const double q0 = x * R;
     const double r = fma(-q0, 20.0, x);
-    return fma(r, R, q0);
+    return copysign(fma(r, R, q0), x);                   // (the quotient has x's sign; the fma chain turns -0 into +0)
 }
 
 template <typename AT>
