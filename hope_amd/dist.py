@@ -72,6 +72,14 @@ def init_from_env(backend=None):
 _AR = {'calls': 0, 'bytes': 0, 'events': [], 'ms': 0.0}
 
 
+def _single(group=None):
+    """True when there is nobody to exchange with.  HOPE_DIST_FORCE=1 sends a one-rank group through the backend anyway (the
+    1-GPU RCCL test: library, device kernels and IPC environment exercised without a second GPU)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get('HOPE_DIST_FORCE') != '1'
+
+
 def allreduce_stats(reset=False):
     """fused gradient all-reduces since the last reset: {'calls', 'bytes', 'ms'} -- ms from device events around the collective
     (CUDA tensors; 0 for gloo / CPU), resolved here, not in the hot loop"""
@@ -89,7 +97,7 @@ def allreduce_stats(reset=False):
 def allreduce_gradients(params, average=True, group=None):
     """sum (or mean) the .grad of every parameter across ranks through ONE flat buffer."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not grads or _single(group):
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
     ev = None
@@ -117,7 +125,7 @@ def gather_eval_stats(status, steps, reward, path_len, group=None):
     status/steps: int32 [n_local]; reward/path_len: float32 [n_local] (n_local may differ by one)."""
     rec = torch.stack([status.to(torch.float32), steps.to(torch.float32), reward.to(torch.float32),
                        path_len.to(torch.float32)], dim=1).contiguous()
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single(group):
         return rec
     world = dist.get_world_size(group)
     n = torch.tensor([rec.shape[0]], device=rec.device, dtype=torch.int64)

@@ -193,6 +193,8 @@ def _nccl_rank(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if world == 1:
+        os.environ['HOPE_DIST_FORCE'] = '1'                                  # a one-rank group still goes through RCCL
     torch.cuda.set_device(rank)
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{rank}'))
     from hope_amd import agents as A
@@ -230,6 +232,23 @@ def test_rccl_gradient_allreduce_and_eval_gather_two_gpus():
     assert res[0][2] == res[1][2] == 1 and res[0][3] > 0
     assert np.array_equal(res[0][1], res[1][1])
     assert res[0][4] == res[1][4] == (4096, 4) and res[0][5] == res[1][5]
+
+
+def test_rccl_single_rank_group_runs_the_exchange_points():
+    """backend "nccl" (= RCCL on ROCm) on the ONE GPU of this box: a process group of a single rank initialises RCCL on the device
+    and sends the fused gradient all-reduce of a PPO update and the evaluator's all-gather through it -- the library, its device
+    kernels and the HSA_ENABLE_IPC_MODE_LEGACY=0 environment are exercised even where a second GPU is missing (the two-rank
+    form of the same function is the test above)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    pr = ctx.Process(target=_nccl_rank, args=(0, 1, port, q))
+    pr.start()
+    res = q.get(timeout=900)
+    pr.join(120)
+    assert res[0] == 0 and res[2] == 1 and res[3] > 0            # one update, gradient bytes went through the all-reduce
+    assert res[4] == (4096, 4) and np.isfinite(res[1]).all()
 
 
 def test_rollout_with_deferred_rs_join_takes_the_same_actions():
