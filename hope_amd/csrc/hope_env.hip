@@ -1033,6 +1033,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // with auto-reset every scene shows its NEW episode's first observation, like lidar / action_mask / target
         b.active = active;
         b.debug = (stages >> 12) & 0xF;
+        if (const char* e_ = getenv("HOPE_BEV_DEBUG")) b.debug |= atoi(e_);   // (profiling) further switches: 16 no block cache, 64 no image stores
         if (getenv("HOPE_BEV_LEGACY")) b.debug |= 32;          // (tests) the per-tile raster of the moving boxes instead of the trajectory layer
         if (fork && n_chain == 2) {
             // the image depends on the step kernels only (pose, trajectory ring), not on the Reeds-Shepp search: render it on
