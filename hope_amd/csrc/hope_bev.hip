@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
     auto dyn_paint = [&](uint32_t sp, int miny, int nrows, int minx, int maxx, int code) {
         const int y = miny + lane;
         const int a = max((int)(sp & 0xffff) - 1, 0), b = min((int)(sp >> 16) - 1, WIN - 1);
-        if (lane < nrows && y >= 0 && y < WIN) {
+        if (lane < nrows && y >= 0 && y < WIN && !(p.debug & 512)) {                 // (512, profiling: no paint)
             uint8_t* row = dyn + ((((y & (BEV_DYN_DIM - 1)) >> 3) << 4) << 7) + ((y & 7) << 4);
             for (int x = a; x <= b;) {
                 const int xb = (x & (BEV_DYN_DIM - 1)) >> 4;
@@ -485,10 +485,21 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
         const bool legacy = dyn_bad || (!(p.debug & 4) && !veh_hidden && !veh_simple) || (p.debug & 32);
         if (legacy) p.legacy_list[1 + atomicAdd(&p.legacy_list[0], 1)] = scene;
         p.traj_valid[scene] = traj_len;
-        if (p.layer_valid[scene] == 0) {                      // a new map since the layer was built: queue the scene for k_bev_static
-            p.layer_valid[scene] = 1;
-            p.rebuild[1 + atomicAdd(&p.rebuild[0], 1)] = scene;
-        }
+    }
+}
+
+// ====================================================================================================================
+// k_bev_list: the scenes whose map is newer than their static layer (layer_valid == 0: set_scenes, the step kernel's episode turnover,
+// a device-side draw) are queued for k_bev_static -- one lane per scene.  Its own launch, so that the rebuild of the layers does not
+// wait for k_bev_prep (the two run side by side on two streams when the step is pipelined; launch_bev_image).
+// ====================================================================================================================
+__global__ __launch_bounds__(256) void k_bev_list(BevParams p) {
+    const int scene = blockIdx.x * blockDim.x + threadIdx.x;
+    if (scene >= p.n) return;
+    if (p.active && !p.active[scene]) return;
+    if (p.layer_valid[scene] == 0) {
+        p.layer_valid[scene] = 1;
+        p.rebuild[1 + atomicAdd(&p.rebuild[0], 1)] = scene;
     }
 }
 
@@ -507,17 +518,24 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_static(BevParams p) {
     // SL_PARTS workgroups per scene, each a quarter of the bands: a rebuilt scene is on the image's critical path
     for (int it = blockIdx.x; it < SL_PARTS * count; it += gridDim.x) {
         const int scene = p.rebuild[1 + it / SL_PARTS], part = it % SL_PARTS;
-        const int* scr = p.scratch + (size_t)scene * BEV_SCENE_INTS;
         const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
         const double offx = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 1] + sc[SC_BBOX])), offy = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 3] + sc[SC_BBOX + 2]));
         const int n_obst = p.n_obst[scene];
         uint8_t* layer = p.layer + (size_t)scene * BEV_LAYER_ROWS * BEV_LAYER_STRIDE;
-        // start outline and dest box: the pixel corners k_bev_prep computed (box headers 0 and 1)
+        // start outline and dest box: their pixel corners, with k_bev_prep's arithmetic (box headers 0 and 1 hold the same numbers, but
+        // this launch does not wait for k_bev_prep): even lanes the start box, odd lanes the dest box
         int sx[5], sy[5], dx[5], dy[5];
+        {
+            const double* bp = sc + ((lane & 1) ? SC_DEST : SC_START);
+            double sb, cb;
+            hm_sincos(bp[2], &sb, &cb);
+            const Box bb = make_box(bp[0], bp[1], cb, sb);                   // State.create_box  vehicle.py:32-36
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            sx[k] = scr[OFF_HDR + H_VX + k]; sy[k] = scr[OFF_HDR + H_VY + k];
-            dx[k] = scr[OFF_HDR + HDR_INTS + H_VX + k]; dy[k] = scr[OFF_HDR + HDR_INTS + H_VY + k];
+            for (int k = 0; k < 4; k++) {
+                const int vx = to_px(bb.x[k], bb.y[k], RENDER_K, 0.0, offx), vy = to_px(bb.x[k], bb.y[k], 0.0, RENDER_K, offy);
+                sx[k] = __builtin_amdgcn_readlane(vx, 0); sy[k] = __builtin_amdgcn_readlane(vy, 0);
+                dx[k] = __builtin_amdgcn_readlane(vx, 1); dy[k] = __builtin_amdgcn_readlane(vy, 1);
+            }
         }
         sx[4] = sx[0]; sy[4] = sy[0]; dx[4] = dx[0]; dy[4] = dy[0];
         const int n_chunks = (n_obst + WAVE - 1) / WAVE;
@@ -922,16 +940,30 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
         // and two shifts from scalar offsets) rather than kept in 32 registers.
         auto gather = [&](auto cached_tag, auto plain_tag) {
         constexpr bool CACHED = decltype(cached_tag)::value, PLAIN = decltype(plain_tag)::value;
+        // cache byte of world pixel (px, py): block (bx, by) of the layer at ((by - cby0) * 4 + bx - cbx0) * 128, inside it
+        // (py & 15) * 8 + (px & 31) / 4.  Written as bit fields of py and px plus ONE wave-uniform offset (the window's origin folded
+        // into the base); on the plain path the fields are cut straight out of the 16.16 source position (dx, dy >= 0 there).
+        const uint8_t* const fbk = fb - ((cby0 << 9) + (cbx0 << 7));
         auto static_byte = [&](int px, int py) -> int {
-            if (CACHED) return fb[(((((py >> 4) - cby0) << 2) + ((px >> 5) - cbx0)) << 7) + ((py & 15) << 3) + ((px & 31) >> 2)];
+            if (CACHED) return fbk[(((py << 5) & ~0x1ff) | ((py << 3) & 0x78)) + ((px << 2) & ~0x7f) + ((px >> 2) & 7)];
             return layer[layer_byte(px, py)];
+        };
+        auto static_byte_fx = [&](unsigned dx, unsigned dy) -> int {           // (plain path) from the fixed-point position
+            if (CACHED) return fbk[(((dy >> 11) & ~0x1ffu) | ((dy >> 13) & 0x78u)) + ((dx >> 14) & ~0x7fu) + ((dx >> 18) & 7u)];
+            return layer[layer_byte((int)(dx >> 16), (int)(dy >> 16))];
         };
         // world pixel (lx, ly) sample k = 4 jj + s of this lane reads; `white`: outside `rotate` (observation.fill), `outside`:
         // outside the source surface (rotate()'s bgcolor) -- both false on the plain path
+        auto sample_fx = [&](int k, int& dx, int& dy) {                      // 16.16 source position of sample k
+            const int jj = k >> 2, s = k & 3;
+            const int ax_ = 4 * jj + (s & 1), ay_ = s >> 1;                   // crop offset from the lane's first sample
+            dx = dxb + ax_ * m.dxx + ay_ * m.dxy; dy = dyb + ax_ * m.dyx + ay_ * m.dyy;
+        };
         auto sample = [&](int k, int& lx, int& ly, bool& white, bool& outside) {
             const int jj = k >> 2, s = k & 3;
             const int ax_ = 4 * jj + (s & 1), ay_ = s >> 1;                   // crop offset from the lane's first sample
-            const int dx = dxb + ax_ * m.dxx + ay_ * m.dxy, dy = dyb + ax_ * m.dyx + ay_ * m.dyy;
+            int dx, dy;
+            sample_fx(k, dx, dy);
             if (PLAIN) { lx = dx >> 16; ly = dy >> 16; white = false; outside = false; return; }
             white = (unsigned)(4 * u0 + 1 + ax_ + m.rox) >= (unsigned)WIN || (ay_ ? row_out1 : row_out0);
             outside = (unsigned)dx > (unsigned)SRC_MAX || (unsigned)dy > (unsigned)SRC_MAX;
@@ -946,9 +978,15 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
         {   // static layer
             int raw[NS];
 #pragma unroll
-            for (int k = 0; k < NS; k++) { int lx, ly; sample(k0 + k, lx, ly, wh, out); raw[k] = static_byte(lx, ly); }
+            for (int k = 0; k < NS; k++) {
+                if (PLAIN) { int dx, dy; sample_fx(k0 + k, dx, dy); raw[k] = static_byte_fx((unsigned)dx, (unsigned)dy); }
+                else { int lx, ly; sample(k0 + k, lx, ly, wh, out); raw[k] = static_byte(lx, ly); }
+            }
 #pragma unroll
-            for (int k = 0; k < NS; k++) { int lx, ly; sample(k0 + k, lx, ly, wh, out); id[k] = (p.debug & 2) ? 0 : ((raw[k] >> ((lx & 3) * 2)) & 3); }
+            for (int k = 0; k < NS; k++) {
+                if (PLAIN) { int dx, dy; sample_fx(k0 + k, dx, dy); id[k] = (raw[k] >> (((unsigned)dx >> 15) & 6)) & 3; }
+                else { int lx, ly; sample(k0 + k, lx, ly, wh, out); id[k] = (raw[k] >> ((lx & 3) * 2)) & 3; }
+            }
         }
         if (LEGACY && has_dyn) {                                              // per-tile raster of the moving boxes (window in LDS)
             int raw[NS];
@@ -1045,13 +1083,12 @@ size_t bev_lds_bytes(bool legacy) {
                   : (size_t)BEV_WAVES * WAVE_LDS;
 }
 
-hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer) {
+hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     hipError_t e = hipSuccess;
-    // (p.rebuild[0], the length of the list of stale layers, is zero here: hope_env_create clears it and k_bev_image resets it)
-    if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
-    hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
-    // the layers of the scenes that got a new map since the last image (a fixed grid strides over k_bev_prep's list; the usual
-    // step has a fraction of a per cent of the scenes in it, the first one all of them)
+    // The layers of the scenes that got a new map since the last image (k_bev_list queues them; a fixed grid strides over the list:
+    // the usual step has a fraction of a per cent of the scenes in it, the first one all of them) depend on the maps only, the crop
+    // maps / span tables / trajectory layer of k_bev_prep on the poses only: with a `side` stream the two run side by side (both are
+    // short latency-bound launches on the critical path of a step with the image), joined in front of the image launches.
     const size_t lds_static = (size_t)BEV_WAVES * SL_SLOT;
     static bool attr_done = false;
     if (!attr_done && lds_static > 48 * 1024) {
@@ -1059,8 +1096,19 @@ hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer*
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_bev_static, dim3(std::min(SL_PARTS * p.n, 4096)), dim3(BEV_WAVES * WAVE), lds_static, stream, p);
+    hipStream_t ss = side ? side : stream;
+    if (side) {
+        if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side, ev_fork, 0)) != hipSuccess) return e;
+    }
+    // (p.rebuild[0], the length of the list of stale layers, is zero here: hope_env_create clears it and k_bev_image resets it)
+    hipLaunchKernelGGL(k_bev_list, dim3((p.n + 255) / 256), dim3(256), 0, ss, p);
+    hipLaunchKernelGGL(k_bev_static, dim3(std::min(SL_PARTS * p.n, 4096)), dim3(BEV_WAVES * WAVE), lds_static, ss, p);
+    if (side && (e = hipEventRecord(ev_join, side)) != hipSuccess) return e;
+    if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
+    hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
+    if (side && (e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;
     const dim3 grid(p.n), block(BEV_WAVES * WAVE);
     if (timer) timer->begin(HOPE_K_IMAGE, stream);
     // (scenes with a box that is not a plain car box, or whose drawn boxes outgrew the trajectory torus: none in practice; first,

@@ -124,6 +124,7 @@ struct hope_env {
     int sub_chains = 1;
     hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {}, ev_segs[2] = {}, ev_post[2] = {};
+    hipEvent_t ev_bev[2] = {};                              // image: fork / join of the static-layer rebuild next to k_bev_prep
     int rs_parity = 0;                                      // which of the two queue counters of a chain this step uses (pipelined steps)
     // HOPE_DEFER_RS: the chains of the last step have not been joined into the caller's stream (events ev_join[1], ev_join[RS_SIDE])
     static constexpr int RS_SIDE = 5;                       // the stream of the first chain when it may not run on the caller's
@@ -573,6 +574,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_bev[i], hipEventDisableTiming));
         for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_segs[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming)); }
         // HOPE_PRIO=1 (experiment, rejected): highest stream priority for the launch chains (the critical path), lowest for
         // the observation / image streams [2], [3], [4].  Measured 0.80 -> 1.08 ms per step at 65 536 scenes: the second
@@ -629,7 +631,7 @@ int hope_env_destroy(hope_env_t* h) {
     DeviceGuard guard(h->device);
     drain_events(h);
     hipDeviceSynchronize();
-    for (hipEvent_t e : {h->ev_fork, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_bev[0], h->ev_bev[1], h->ev_fork, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
     for (int i = 0; i < hope_env::MAX_CHAINS; i++) {
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
         if (h->side[i]) hipStreamDestroy(h->side[i]);
@@ -1043,7 +1045,10 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             hipStream_t si = defer ? s : h->side[2];
             HIPCHK(hipStreamWaitEvent(si, h->ev_step[0], 0));
             HIPCHK(hipStreamWaitEvent(si, h->ev_step[1], 0));
-            HIPCHK(launch_bev_image(b, si, tm));
+            // (pipelined steps: the image is on the caller's stream and the third library stream is free for the layer rebuild)
+            static const bool bev_side = !(getenv("HOPE_BEV_SIDE") && atoi(getenv("HOPE_BEV_SIDE")) == 0);
+            if (defer && bev_side && h->side[2] && h->ev_bev[0]) HIPCHK(launch_bev_image(b, si, tm, h->side[2], h->ev_bev[0], h->ev_bev[1]));
+            else HIPCHK(launch_bev_image(b, si, tm));
             HIPCHK(hipEventRecord(h->ev_join[2], si));
         } else {
             if (fork) for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }

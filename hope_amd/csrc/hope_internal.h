@@ -97,7 +97,8 @@ hipError_t rs_fdump_read(double* out /*[64][16]*/);
 hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset);   // HOPE_RS_TIMING per-search log
 size_t rs_lds_bytes(int max_obst);
 size_t rs_rec_bytes_per_scene();
-hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer);
+hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer, hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr,
+                            hipEvent_t ev_join = nullptr);   // side: stream for the static-layer rebuild (next to k_bev_prep), or null
 size_t bev_lds_bytes(bool legacy);
 
 }  // namespace hope

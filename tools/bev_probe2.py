@@ -22,6 +22,16 @@ for name, dbg in (('full', 0), ('no stores', 64), ('no gather', 8), ('no gather,
         env.reset_obs(stages=L.STAGE_IMG)
     torch.cuda.synchronize()
     ms, cnt = env.kernel_ms(reset=True)['k_bev_image']
-    ms2, cnt2 = env.kernel_ms(reset=True).get('k_bev_prep', (0, 1))
     print(f'{name:22s} {ms / cnt * 1e3:8.1f} us per {N} scenes', flush=True)
+for name, dbg in (('prep full', 0), ('prep no paint', 512)):
+    os.environ['HOPE_BEV_DEBUG'] = str(dbg)
+    for i in range(3):
+        env.step(acts[i % 4], auto_reset=True)
+    torch.cuda.synchronize()
+    env.kernel_ms(reset=True)
+    for i in range(8):
+        env.step(acts[i % 4], auto_reset=True)
+    torch.cuda.synchronize()
+    k = env.kernel_ms(reset=True)
+    print(name, {n: round(v[0] / v[1] * 1e3, 1) for n, v in k.items() if 'bev' in n}, flush=True)
 env.close()
