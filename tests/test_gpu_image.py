@@ -349,3 +349,44 @@ def test_gpu_image_obeys_the_analytic_invariants_of_the_reference_geometry():
                 assert imgs[k][:, 29:35, 14:24].any(), k                    # behind: the older boxes / the start outline
         env.close()
     assert seen['dest'] > 200 and seen['obstacle'] > 200, seen
+
+
+def test_image_in_pipelined_steps_equals_the_joined_step():
+    """Pipelined steps (HOPE_DEFER_RS with the overlap streams: the image is rendered on the caller's stream, and the static-layer
+    rebuild of the scenes that got a NEW map -- k_bev_list + k_bev_static -- runs on a side stream next to k_bev_prep, joined in
+    front of the image launches) give the same image bytes as the joined step, every step, with episode turnover on new maps from
+    the pool / Dragon-Lake cases; and so do all other outputs."""
+    from hope_amd import ParkingBatch
+    from hope_amd.scene_gen import mixed_arrays, generate_arrays
+    n = 4096
+    arrs = mixed_arrays(n, seed=31, max_obst=128)
+    parts = [generate_arrays(lv, 128, seed=40 + j, max_obst=128) for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
+    pool = tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(6))
+    envs = [ParkingBatch(n, 128, overlap=True, image=True) for _ in range(2)]
+    for e in envs:
+        e.set_scene_arrays(np.arange(n), *arrs[:5])
+        e.set_draw_class(np.arange(3, n, 4), 1)
+        e.set_pool(pool)
+        e.set_dlp_cases()
+        e.set_redraw_seed(9)
+        e.reset_obs()
+    torch.cuda.synchronize()
+    assert torch.equal(envs[0].img, envs[1].img)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    turnovers = 0
+    for it in range(40):
+        a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+        a[:, 1] = torch.sign(a[:, 1] + 1e-9)                 # full speed: episodes end (collisions, out of bounds) within the run
+        envs[0].step(a, auto_reset=True, fresh=True)
+        envs[1].step(a, auto_reset=True, fresh=True, defer_rs=True)
+        torch.cuda.current_stream().synchronize()            # the image is ordered on the caller's stream
+        assert torch.equal(envs[1].img, envs[0].img), it
+        for k in ('lidar', 'action_mask', 'target', 'status', 'pose'):
+            assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), (it, k)
+        turnovers += int(envs[0].done.sum())
+    envs[1].wait_rs()
+    torch.cuda.synchronize()
+    assert torch.equal(envs[1].rs_word, envs[0].rs_word)
+    assert turnovers > 100, turnovers                       # that many layers were rebuilt on the side stream
+    for e in envs:
+        e.close()

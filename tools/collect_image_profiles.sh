@@ -1,5 +1,5 @@
 set -u
-TAG=r03
+TAG=${1:-r04}
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
@@ -17,5 +17,5 @@ done
 # the non-image directories the reducer expects
 for d in kstats pmc_FETCH_SIZE pmc_WRITE_SIZE busy_1 busy_2 busy_3; do mkdir -p $O/$d; done
 python $R/tools/reduce_profiles.py $O $TAG 2>&1 | tail -3
-python $R/tools/bev_probe.py 2>/dev/null > $O/${TAG}_image_stage_times.txt
+python $R/tools/bev_probe2.py 2>/dev/null > $O/${TAG}_image_stage_times.txt
 ls $O | grep image

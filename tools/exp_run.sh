@@ -1,8 +1,1 @@
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_image.py -x -q 2>&1 | tail -3
-run() { tag=$1; shift; env "$@" timeout 300 python bench.py --image --steps 20 --warmup 5 --preroll 150 --no-cpu-baseline --witness 0 --repeat-passes 2 --repeat-steps 60 > gpurun_out/i_$tag.json 2>/dev/null; python -c "
-import json,sys; d=json.load(open('gpurun_out/i_$tag.json')); print('$tag', round(d['ms_per_step'],4), round(d['value']/1e6,2), [round(x,4) for x in d['repeat']['ms_per_step']], {k:round(v,3) for k,v in d['roofline']['ms_per_bench_step_by_kernel'].items() if 'bev' in k})"; }
-for i in 1 2; do
-run side A=1
-run serial HOPE_BEV_SIDE=0
-done
+timeout 900 python -m pytest tests/test_gpu_image.py -x -q -k "pipelined" 2>&1 | tail -15
