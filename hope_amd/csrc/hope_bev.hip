@@ -12,16 +12,17 @@
 //      new this step (vehicle, newest trajectory entry; dest / start once per episode), its integer pixel corners and
 //      its scan-line spans under pygame's rule (lane = row).  A box keeps its spans for the 20 steps it stays in the
 //      trajectory ring, so they live in a per-scene table in HBM (7 KB/scene), indexed like the ring.
-//   k_bev_image (4 waves per scene sharing the span tables, each looping over 4 of the 16 tiles of 16 x 16 outputs, so
-//      that the map, the box headers, the span tables and the obstacle pixels are fetched once per wave and the waves
-//      live long enough to hide latency): the world pixels
-//      a tile can touch form a window of at most 90 x 90 px, kept as one byte per pixel (palette id) in LDS.  Obstacles are converted to
-//      integer pixels lane-parallel (lane = obstacle), culled against the window with a ballot and rasterised with
-//      pygame's exact scan-line rule (lane = row; floor / ceil on alternate intersections; horizontal border pass);
-//      the start outline is pygame's Bresenham walk in closed form (lane = step); boxes are filled from their span
-//      table (copied into LDS once), each trajectory box only where its successor -- drawn next, overlapping ~90 % --
-//      will not overwrite it.  Then the tile's 1024 samples gather their palette id through the fixed-point map,
-//      colours are summed in a packed 3 x 10-bit word, rounded like OpenCV ((s + 2) >> 2) and stored as uint8 CHW.
+//   k_bev_list / k_bev_static: the scenes whose map is newer than their static layer are queued and the layer (everything _render
+//      draws that does not move within an episode, 2 bits per pixel, tiled) is rebuilt with pygame's exact scan-line rule (lane = row;
+//      floor / ceil on alternate intersections; horizontal border pass; the start outline is pygame's Bresenham walk in closed form).
+//   k_bev_image (4 independent waves per scene, each looping over 4 of the 16 tiles of 16 x 16 outputs): the world pixels a tile can
+//      touch form a window of at most 90 x 90 px.  Raster-free launch (every scene in practice): the window's layer blocks are
+//      prefetched global -> LDS one tile ahead; the tile's 1024 samples (lane = 4 outputs = 16 samples) gather their palette id
+//      through the fixed-point map in branch-free phases -- static layer from the LDS cache, vehicle from its span table, trajectory
+//      from the per-scene torus layer k_bev_prep paints -- colours are summed in a packed 3 x 10-bit word, rounded like OpenCV
+//      ((s + 2) >> 2) and stored as uint8 CHW.  Per-tile-raster launch (scenes with a moving box that is not a plain one-span-per-row
+//      box: none in practice, kept exact): the moving boxes are filled from their span tables into a one-byte-per-pixel LDS window,
+//      each trajectory box only where its successor -- drawn next, overlapping ~90 % -- will not overwrite it.
 // Integer work throughout, except the pose -> pixel conversion and the rotation setup (float64, shared hope_math.h),
 // so the result is bit-identical to oracle/hope_oracle_img.c.
 #include <hip/hip_runtime.h>
