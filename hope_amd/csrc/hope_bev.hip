@@ -628,7 +628,10 @@ __device__ __forceinline__ int tile_of(int wave, int it) {
 #define BEV_OCC 5                             // (6: 80 VGPRs + 8 spilled, 2.20 ms; 5: 90 VGPRs, 2.15 ms per 65 536 scenes)
 #endif
 constexpr int CACHE_ROWS = 7, CACHE_SLOT = CACHE_ROWS * 4 * 128;   // layer blocks of one tile's window (4 x 7 at most), rows of 4 blocks
-constexpr int WAVE_LDS = 32 * 4 + TAB_ROWS * 4 + 2 * CACHE_SLOT;         // raster-free launch, per wave: palette, vehicle span table, two cache slots
+#ifndef BEV_SLOTS
+#define BEV_SLOTS 2                            // cache slots per wave: 2 = the next tile's blocks travel while this tile is gathered
+#endif
+constexpr int WAVE_LDS = 32 * 4 + TAB_ROWS * 4 + BEV_SLOTS * CACHE_SLOT;         // raster-free launch, per wave: palette, vehicle span table, two cache slots
 template <bool LEGACY>
 __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int scene, uint8_t* lds_raw) {
     // LDS.  LEGACY: palette (128 B) | all span tables, shared by the workgroup's waves (5.6 KB) | per wave the window (8.3 KB + 72).
@@ -799,7 +802,7 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
         typedef __attribute__((address_space(3))) void* lds_ptr;
         const int cbx0 = w.x0 >> 5, cby0 = w.y0 >> 4, ncx = (w.x1 >> 5) - cbx0 + 1, ncy = (w.y1 >> 4) - cby0 + 1;
         const int l = lane & 31, bx = l >> 3, piece = l & 7;
-        uint8_t* dst = fb0 + (it & 1) * CACHE_SLOT;
+        uint8_t* dst = fb0 + (it & (BEV_SLOTS - 1)) * CACHE_SLOT;
         const uint8_t* src = layer + ((cbx0 + bx) << 7) + (piece << 4);
 #pragma unroll
         for (int i = 0; i < (CACHE_ROWS + 1) / 2; i++) {                     // lanes 0-31: row 2 i, lanes 32-63: row 2 i + 1
@@ -807,13 +810,13 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
             if (l < 8 * ncx && r < ncy) __builtin_amdgcn_global_load_lds((const void*)(src + ((cby0 + r) << 11)), (lds_ptr)(dst + i * 1024), 16, 0, 0);
         }
     };
-    if (!LEGACY) prefetch_tile(0);
+    if (!LEGACY && BEV_SLOTS == 2) prefetch_tile(0);
 
 #pragma unroll 1
     for (int it = 0; it < TILES * TILES / BEV_WAVES; it++) {
         const int tile = tile_of(wave, it);
         const int tx = tile & 3, ty = tile >> 2;
-        uint8_t* const fb = LEGACY ? fb0 : fb0 + (it & 1) * CACHE_SLOT;
+        uint8_t* const fb = LEGACY ? fb0 : fb0 + (it & (BEV_SLOTS - 1)) * CACHE_SLOT;
         Window w;
         const int tfl = tile_rec(it, w);
         const bool need_bg = (tfl & TF_BG) != 0;
@@ -900,6 +903,10 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
         const int ncx = (w.x1 >> 5) - cbx0 + 1, ncy = (w.y1 >> 4) - cby0 + 1;
         const bool veh_on = (tfl & TF_VEH) != 0, traj_on = (tfl & TF_TRAJ) != 0;      // the moving boxes that can reach this tile's window
         const bool cached = !has_dyn && (tfl & TF_CACHED);
+        if (!LEGACY && BEV_SLOTS == 1) {                                     // (one slot: the tile's own blocks, waited for at once)
+            wave_phase();
+            prefetch_tile(it);
+        }
         if (cached) {
             if (LEGACY) {
                 wave_phase();                                                // the previous tile's gather is done
@@ -916,7 +923,7 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (!LEGACY && it + 1 < TILES * TILES / BEV_WAVES) {
+        if (!LEGACY && BEV_SLOTS == 2 && it + 1 < TILES * TILES / BEV_WAVES) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the other slot's last reads -- tile it - 1 -- have returned)
             prefetch_tile(it + 1);
         }
