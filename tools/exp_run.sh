@@ -1,8 +1,9 @@
 mkdir -p gpurun_out
 run() { tag=$1; shift; env "$@" timeout 300 python bench.py --image --steps 20 --warmup 5 --preroll 150 --no-cpu-baseline --witness 0 --repeat-passes 2 --repeat-steps 60 > gpurun_out/i_$tag.json 2>/dev/null; python -c "
 import json,sys; d=json.load(open('gpurun_out/i_$tag.json')); print('$tag', round(d['ms_per_step'],4), round(d['value']/1e6,2), [round(x,4) for x in d['repeat']['ms_per_step']], {k:round(v,3) for k,v in d['roofline']['ms_per_bench_step_by_kernel'].items() if 'bev' in k})"; }
-for i in 1 2; do
-run A A=1
-for b in hope_amd/libhope_env_b*.so; do run $(basename $b .so) HOPE_AMD_LIB=$PWD/$b; done
-done
-HOPE_AMD_LIB=$PWD/hope_amd/libhope_env_b1.so timeout 600 python -m pytest tests/test_gpu_image.py -x -q 2>&1 | tail -2
+run q4 A=1
+run q6 GPU_MAX_HW_QUEUES=6
+run q8 GPU_MAX_HW_QUEUES=8
+run q8_lib GPU_MAX_HW_QUEUES=8 HOPE_IMG_CALLER=0
+run q12 GPU_MAX_HW_QUEUES=12
+run q6_obs5 GPU_MAX_HW_QUEUES=6 HOPE_OBS_SIDE0=5
