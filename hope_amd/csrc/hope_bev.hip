@@ -937,7 +937,7 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
         int dxb, dyb;
         map_raw(m, 4 * u0 + 1, 4 * v + 1, dxb, dyb);                          // first sample of this lane
         const bool row_out0 = (unsigned)(4 * v + 1 + m.roy) >= (unsigned)WIN, row_out1 = (unsigned)(4 * v + 2 + m.roy) >= (unsigned)WIN;
-        uint32_t ids[4] = {0, 0, 0, 0};                                       // 4 palette ids per output, one byte each
+        uint32_t out_r = 0, out_g = 0, out_b = 0;                             // this lane's 4 outputs per channel, one byte each
         // the usual tile lies completely inside `rotate` and inside the source: no border tests, no clamps
         const int rxa = 4 * TILE_OUT * tx + 1 + m.rox, rxb = rxa + 4 * TILE_OUT - 3, rya = 4 * TILE_OUT * ty + 1 + m.roy, ryb = rya + 4 * TILE_OUT - 3;
         const bool plain = !need_bg && rxa >= 0 && rxb < WIN && rya >= 0 && ryb < WIN;      // wave-uniform
@@ -1056,19 +1056,18 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
                 id[k] = wh ? 0 : id[k];                                       // observation.fill(BG_COLOR) -> black later
             }
         }
+        // colours of the four samples of an output summed in a packed 3 x 10-bit word, rounded like OpenCV: (s + 2) >> 2
 #pragma unroll
-        for (int jj = 0; jj < NS / 4; jj++) ids[k0 / 4 + jj] = (uint32_t)id[4 * jj] | ((uint32_t)id[4 * jj + 1] << 8) | ((uint32_t)id[4 * jj + 2] << 16) | ((uint32_t)id[4 * jj + 3] << 24);
+        for (int jj = 0; jj < NS / 4; jj++) {
+            const uint32_t sum = pal[id[4 * jj]] + pal[id[4 * jj + 1]] + pal[id[4 * jj + 2]] + pal[id[4 * jj + 3]];
+            const uint32_t r = ((sum & 1023) + 2) >> 2, g = (((sum >> 10) & 1023) + 2) >> 2, bl = (((sum >> 20) & 1023) + 2) >> 2;
+            const int sh = 8 * (k0 / 4 + jj);
+            out_r |= r << sh; out_g |= g << sh; out_b |= bl << sh;
+        }
         }
         };
         if (cached) { if (plain) gather(std::true_type{}, std::true_type{}); else gather(std::true_type{}, std::false_type{}); }
         else { if (plain) gather(std::false_type{}, std::true_type{}); else gather(std::false_type{}, std::false_type{}); }
-        uint32_t out_r = 0, out_g = 0, out_b = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            const uint32_t sum = pal[ids[jj] & 255] + pal[(ids[jj] >> 8) & 255] + pal[(ids[jj] >> 16) & 255] + pal[ids[jj] >> 24];
-            const uint32_t r = ((sum & 1023) + 2) >> 2, g = (((sum >> 10) & 1023) + 2) >> 2, bl = (((sum >> 20) & 1023) + 2) >> 2;
-            out_r |= r << (8 * jj); out_g |= g << (8 * jj); out_b |= bl << (8 * jj);
-        }
         uint8_t* img = p.img + (size_t)scene * 3 * BEV_IMG * BEV_IMG + v * BEV_IMG + u0;
         if ((p.debug & 64) && (out_r ^ out_g) != 0x9e3779b9u) continue;       // (profiling: everything but the stores)
         *(uint32_t*)(img) = out_r;
