@@ -625,11 +625,13 @@ __device__ __forceinline__ int tile_of(int wave, int it) {
 #define BEV_NS 4
 #endif
 #ifndef BEV_OCC
-#define BEV_OCC 5                             // (6: 80 VGPRs + 8 spilled, 2.20 ms; 5: 90 VGPRs, 2.15 ms per 65 536 scenes)
+#define BEV_OCC 8                             // waves per SIMD the raster-free launch is compiled for (63 VGPRs; with one cache slot 8 workgroups per CU fit the LDS)
 #endif
 constexpr int CACHE_ROWS = 7, CACHE_SLOT = CACHE_ROWS * 4 * 128;   // layer blocks of one tile's window (4 x 7 at most), rows of 4 blocks
 #ifndef BEV_SLOTS
-#define BEV_SLOTS 2                            // cache slots per wave: 2 = the next tile's blocks travel while this tile is gathered
+#define BEV_SLOTS 1                            // cache slots per wave.  2 = the next tile's blocks travel while this tile is gathered (30 KB per workgroup: 5 per
+                                              // CU); 1 = own blocks, waited for at once.  Measured with the 63-register kernel: 2 slots / 5 waves per SIMD 1.04 ms,
+                                              // 1 slot / 6: 0.99, 1 / 7: 0.98, 1 / 8: 0.96 -- the resident waves hide the wait better than the prefetch does
 #endif
 constexpr int WAVE_LDS = 32 * 4 + TAB_ROWS * 4 + BEV_SLOTS * CACHE_SLOT;         // raster-free launch, per wave: palette, vehicle span table, two cache slots
 template <bool LEGACY>

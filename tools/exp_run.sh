@@ -1,8 +1,2 @@
-mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_image.py -x -q 2>&1 | tail -2
-run() { tag=$1; shift; env "$@" timeout 300 python bench.py --image --steps 20 --warmup 5 --preroll 150 --no-cpu-baseline --witness 0 --repeat-passes 2 --repeat-steps 60 > gpurun_out/i_$tag.json 2>/dev/null; python -c "
-import json,sys; d=json.load(open('gpurun_out/i_$tag.json')); print('$tag', round(d['ms_per_step'],4), round(d['value']/1e6,2), [round(x,4) for x in d['repeat']['ms_per_step']], {k:round(v,3) for k,v in d['roofline']['ms_per_bench_step_by_kernel'].items() if 'bev' in k})"; }
-for i in 1 2 3; do
-run A A=1
-run b0 HOPE_AMD_LIB=$PWD/hope_amd/libhope_env_b0.so
-done
+timeout 600 python tools/bev_probe2.py 2>&1 | tail -12
