@@ -644,7 +644,6 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
     // on the vector unit too
     auto uni = [](int x) -> int { return __builtin_amdgcn_readfirstlane(x); };
     const int lane = threadIdx.x & (WAVE - 1), wave = uni(threadIdx.x / WAVE);
-    constexpr int SLOT_BYTES = LEGACY ? FB_BYTES : CACHE_SLOT;
     uint32_t* const pal = (uint32_t*)(LEGACY ? lds_raw : lds_raw + wave * WAVE_LDS);
     uint32_t* const tabs = pal + 32;                                         // LEGACY: [N_TAB][TAB_ROWS]
     uint32_t* const vtab = LEGACY ? tabs + TAB_ROWS : pal + 32;              // the vehicle's span table
