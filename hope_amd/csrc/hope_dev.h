@@ -213,9 +213,20 @@ __device__ __forceinline__ bool hull_edge_intersect_robust(double px, double py,
 // XCD-aware block -> scene map.  Workgroup b runs on XCD b % 8 (8 XCDs, each with its own L2 and 32 CUs).  With
 // scene = b any per-scene cost pattern whose period divides 8 (e.g. scene classes interleaved with period 4, as a
 // round-robin level mix produces) would pile the expensive scenes onto 2 of the 8 XCDs (measured: 2.6x slower).
-// XOR-ing bits 3..5 into bits 0..2 is a bijection inside every aligned group of 64 blocks and gives each XCD every
-// residue mod 8 equally often; sorted batches stay spread too.  The tail group (n not a multiple of 64) is left as is.
+// The map keeps the FOUR list entries 4 L .. 4 L + 3 (one 128-byte line of `state`, half a line of `post`, when the list is
+// contiguous) on ONE XCD, so that such a line is fetched into one L2 instead of up to four (k_env_step fetch -9 %, step time
+// unchanged), and spreads the lines: inside an aligned group of 256 blocks, block b = 256 G + 32 h + 8 r + x (x = its XCD) takes
+// entry 256 G + 4 (8 h + (x ^ h)) + r.  A bijection of the group; every XCD gets every residue of the line index mod 8 once per
+// group and every entry residue mod 4 equally often, so cost patterns of period 3, 4, 8, 16, 32 and sorted lists stay spread.
+// The last partial group falls back to the round-2 map (XOR of bits 3..5 into bits 0..2 inside aligned groups of 64), the
+// tail (n not a multiple of 64) is left as is.  HOPE_XCD_XOR: the round-2 map everywhere.
 __device__ __forceinline__ int scene_of_block(int b, int n) {
+#ifndef HOPE_XCD_XOR
+    if ((b | 255) < n) {
+        const int x = b & 7, r = (b >> 3) & 3, h = (b >> 5) & 7;
+        return (b & ~255) + 4 * (8 * h + (x ^ h)) + r;
+    }
+#endif
     if ((b | 63) >= n) return b;
     return b ^ ((b >> 3) & 7);
 }

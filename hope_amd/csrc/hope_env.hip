@@ -122,6 +122,7 @@ struct hope_env {
     // HOPE_F_OVERLAP: the two tile classes' launches go to two streams (fork / join with events)
     static constexpr int MAX_CHAINS = 8;                    // launch chains in flight: tile classes x HOPE_CHAINS sub-lists
     int sub_chains = 1;
+    bool sub_chains_auto = true;                            // HOPE_CHAINS not given: hope_env_step picks (single-class batches, see there)
     hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {}, ev_segs[2] = {}, ev_post[2] = {};
     hipEvent_t ev_bev[2] = {};                              // image: fork / join of the static-layer rebuild next to k_bev_prep
@@ -573,6 +574,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     if (flags & HOPE_F_OVERLAP) {
         const char* ch = getenv("HOPE_CHAINS");              // sub-lists per tile class, each its own chain / stream
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
+        h->sub_chains_auto = ch == nullptr;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_bev[i], hipEventDisableTiming));
         for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_segs[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming)); }
@@ -854,7 +856,21 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     struct Chain { int c, a, b, st; };                      // st: 0 = the caller's stream, k = side[k]
     Chain chains[hope_env::MAX_CHAINS];
     int n_chain = 0, n_streams = 1;
-    const int subs = overlap ? h->sub_chains : 1;
+    int subs = overlap ? h->sub_chains : 1;
+    // A batch whose scenes all sit in ONE tile class has one chain: no second stream, and none of the two-chain forms below (observation
+    // half on its own stream, pipelined steps).  Cut that class's list into two sub-chains where that was measured to pay for
+    // deferred steps (profiles/r04_single_class_chains.txt; same bits: the chains share nothing): the small-tile class from 32 768
+    // scenes (65 536 generated lots 0.790 -> 0.680 ms; below that the single chain in the one-launch form is the faster one), the
+    // large-tile class from 4 096 to 32 768 scenes (4 096 Dragon-Lake scenes 0.190 -> 0.155 ms, 16 384: 0.278 -> 0.232; 65 536: 0.698 vs 0.717, not there).
+    // HOPE_CHAINS=n overrides; HOPE_AUTO_CHAINS=lo0:hi0:lo1:hi1 moves the two ranges (tests force the form at small sizes).
+    bool auto_subs = false;
+    if (overlap && h->sub_chains_auto && want_rs && (stages & HOPE_STAGE_OBS) && (stages & HOPE_DEFER_RS) && !(stages & HOPE_STAGE_IMG) &&
+        (h->cls_count[0] == 0) != (h->cls_count[1] == 0)) {
+        int range[4] = {32768, 1 << 30, 4096, 32768};
+        if (const char* e = getenv("HOPE_AUTO_CHAINS")) sscanf(e, "%d:%d:%d:%d", range, range + 1, range + 2, range + 3);   // (read per call)
+        const int c1 = h->cls_count[0] == 0 ? 1 : 0, cnt = h->cls_count[c1];
+        if (cnt >= range[2 * c1] && cnt <= range[2 * c1 + 1]) { subs = 2; auto_subs = true; }
+    }
     static const int balance = getenv("HOPE_BALANCE") ? atoi(getenv("HOPE_BALANCE")) : 100;
     // experiment: 1 = the chain of the class with more scenes is enqueued first; 2 = and the other chain starts only when the
     // first chain's motion launch is done (its kinematics / motion kernels then do not share the GPU with the critical ones)
@@ -936,7 +952,8 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // stream and the caller's costs that cycle 20-30 us (two hops per step: 0.648 -> 0.60 ms).  Not with the image, which
         // runs on the caller's stream next to the observation launches.
         static const bool pipe_on_caller = !(getenv("HOPE_PIPE_CALLER") && atoi(getenv("HOPE_PIPE_CALLER")) == 0);
-        const bool on_caller = pipe && pipe_on_caller && !(stages & HOPE_STAGE_IMG) && h->cls_count[c] >= h->cls_count[1 - c];
+        // (two sub-chains of one class: neither -- both would land on the caller's stream and serialise: 0.80 vs 0.68 ms)
+        const bool on_caller = pipe && pipe_on_caller && !auto_subs && !(stages & HOPE_STAGE_IMG) && h->cls_count[c] >= h->cls_count[1 - c];
         if (on_caller) so = s;
         // ... and k_post, whose outputs the caller's stream joins too, runs at the head of the search stream instead of behind the
         // observation launch (the search stream has slack, the env stream is the critical one)

@@ -84,7 +84,11 @@ extern "C" {
  *   HOPE_CLS1_FRAC   share of the scenes the large-tile launch chain should hold after the small-tile class has handed
  *                    scenes over (default 0.42 below 32768 scenes, else 0 = no hand-over); read by hope_env_set_scenes
  *   HOPE_RS_EXACT    validate Reeds-Shepp words with the all-float64 kernel (the reference of the default kernel's float32 filter)
- *   HOPE_CHAINS, HOPE_BALANCE, HOPE_PRIO, HOPE_RS_OCC   rejected launch / build variants kept for experiments
+ *   HOPE_AUTO_CHAINS lo0:hi0:lo1:hi1 -- scene-count ranges in which a batch whose scenes all sit in ONE tile class (0: <= 32 obstacles,
+ *                    1: larger) is stepped as two sub-chains of that class, so that the two-stream pipelined form of deferred steps
+ *                    applies (default 32768:2^30:4096:32768, measured: profiles/r04_single_class_chains.txt); HOPE_CHAINS=n fixes
+ *                    the number of sub-chains per class instead (1 = never)
+ *   HOPE_BALANCE, HOPE_PRIO, HOPE_RS_OCC   rejected launch / build variants kept for experiments
  *   HOPE_STEP_TIMING, HOPE_RS_TIMING, HOPE_RS_DEBUG      instrumented kernel builds and profiling switches (tools/) */
 
 /* hope_env_step stage mask */

@@ -1255,3 +1255,57 @@ def test_lidar_back_face_cull_changes_no_bit():
                 e.close()
         finally:
             os.environ.pop('HOPE_SPLIT_MIN', None)
+
+
+@pytest.mark.parametrize('which', ['generated', 'dragon_lake'])
+def test_single_class_batch_in_two_sub_chains_equals_the_single_chain(which):
+    """A batch whose scenes all sit in one obstacle-tile class is cut into two sub-chains for deferred steps (hope_env_step: automatic
+    from 32 768 small-tile scenes / up to 32 768 large-tile scenes; forced here at a small size with HOPE_AUTO_CHAINS) so that the
+    two-stream pipelined form applies.  Same bits as the joined single-chain step on every output, every step, with episode
+    turnover on new maps; and switching between the forms from step to step (deferred <-> joined) is safe."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scene_gen import mixed_arrays, generate_arrays
+    n = 4096
+    if which == 'generated':
+        arrs = mixed_arrays(n, levels=('Normal', 'Complex', 'Extrem'), seed=31, max_obst=128)
+    else:
+        arrs = mixed_arrays(n, levels=('dlp',), seed=32, max_obst=128)
+    parts = [generate_arrays(lv, 256, seed=33 + j, max_obst=128) for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
+    pool = tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(6))
+    os.environ['HOPE_AUTO_CHAINS'] = '1:1073741824:1:1073741824'
+    os.environ['HOPE_SPLIT_MIN'] = '1'                       # the two-launch form of the step kernel at this size, as at 32 768 scenes
+    try:
+        envs = [ParkingBatch(n, 128, overlap=True) for _ in range(2)]
+        for e in envs:
+            e.set_scene_arrays(np.arange(n), *arrs[:5])
+            if which == 'dragon_lake':
+                e.set_draw_class(np.arange(n), 1)
+            e.set_pool(pool)
+            e.set_dlp_cases()
+            e.set_redraw_seed(9)
+            e.reset_obs()
+        g = torch.Generator(device='cuda').manual_seed(13)
+        names = ('lidar', 'action_mask', 'target', 'reward', 'reward_info', 'status', 'done', 'pose', 'rs_word', 'rs_lengths')
+        found = turnovers = 0
+        for it in range(30):
+            a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+            envs[0].step(a, auto_reset=True, fresh=True)                                      # joined: one chain
+            envs[1].step(a, auto_reset=True, fresh=True, defer_rs=(it % 7 != 5))              # deferred: two sub-chains, pipelined; now and then a joined step in between
+            if it % 3 == 0:
+                envs[1].wait_rs()
+                torch.cuda.synchronize()
+                for k in names:
+                    assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), (it, k)
+                found += int((envs[1].rs_word[:, 6] > 0).sum())
+                turnovers += int(envs[1].done.sum())
+        envs[1].wait_rs()
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(getattr(envs[1], k), getattr(envs[0], k)), k
+        assert found > 0 and turnovers > 0
+        for e in envs:
+            e.close()
+    finally:
+        del os.environ['HOPE_AUTO_CHAINS']
+        del os.environ['HOPE_SPLIT_MIN']
