@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def run(seed, n, steps, split, level):
+def run(seed, n, steps, split, level, defer=False):
     import torch
     from hope_amd import ParkingBatch
     from hope_amd.scenes import DlpScenePool, SceneSource, pack_scenes
@@ -54,7 +54,11 @@ def run(seed, n, steps, split, level):
         act = rng.uniform(-1.2, 1.2, (n, 2))
         if it % 3 == 0:
             act[:, 1] = np.sign(act[:, 1])
-        env.step(torch.from_numpy(act).to(env.device))
+        if defer:                 # HOPE_DEFER_RS: the pipelined launch structure (two sub-chains for a single-class batch), joined before the compare
+            env.step(torch.from_numpy(act).to(env.device), defer_rs=True)
+            env.wait_rs()
+        else:
+            env.step(torch.from_numpy(act).to(env.device))
         o = orc.step(act)
         torch.cuda.synchronize()
         pose, tt, acc = env.download_state()
@@ -86,11 +90,12 @@ def main():
     ap.add_argument('--seeds', type=int, default=8)
     ap.add_argument('--scenes', type=int, default=4096)
     ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--defer', action='store_true', help='deferred steps (HOPE_DEFER_RS) + wait_rs; with HOPE_AUTO_CHAINS=1:1073741824:1:1073741824 the Dragon-Lake runs go through two sub-chains')
     args = ap.parse_args()
     total = 0
     for seed in range(100, 100 + args.seeds):
         for split in (False, True):
-            total += run(seed, args.scenes, args.steps, split, 'mixed' if seed % 2 else 'dlp')
+            total += run(seed, args.scenes, args.steps, split, 'mixed' if seed % 2 else 'dlp', args.defer)
     print('total differences:', total)
     sys.exit(1 if total else 0)
 
