@@ -593,6 +593,11 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         // large-tile class with HOPE_DEFER_RS) the a-th ... created stream.  Default: the two observation launches on streams that do
         // not share a hardware queue (3 and 7; with 3 and 4 the larger class's observation started only when the smaller class's
         // was done, 180 us after its motion launch): 0.695 -> 0.675 ms (profiles/r04_stream_roles.txt).
+        // A handle with the image (HOPE_F_IMAGE) has six streams at work in a step (the image on the caller's stream, two env, two search
+        // streams, the layer rebuild): other roles have to share.  Measured over 40 random assignments under the final launch structure
+        // (profiles/r04_stream_roles_pipelined.txt): 65 536 scenes 1.92 -> 1.85 ms, 8 192 scenes 0.527 -> 0.445 ms with the image; the
+        // same assignment costs a step WITHOUT the image 15 % (0.60 -> 0.69 ms), hence by the handle's flag, not for everyone.
+        if (flags & HOPE_F_IMAGE) { static const int pi[hope_env::MAX_CHAINS] = {0, 6, 2, 3, 1, 4, 5, 7}; for (int i = 0; i < hope_env::MAX_CHAINS; i++) perm[i] = pi[i]; }
         {
             const char* pe = getenv("HOPE_SIDE_PERM");
             if (pe) {
