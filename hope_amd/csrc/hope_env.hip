@@ -586,13 +586,17 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         // HOPE_PRIO (experiment): stream priorities by ROLE -- 1: chains highest, observation / image lowest; 2: chains default,
         // observation lowest; 3: chains highest, observation default
         static const int prio_mode = getenv("HOPE_PRIO") ? atoi(getenv("HOPE_PRIO")) : 0;
-        int perm[hope_env::MAX_CHAINS] = {0, 1, 2, 3, 7, 5, 6, 4};
+        int perm[hope_env::MAX_CHAINS] = {0, 1, 6, 3, 2, 5, 4, 7};
         // Which library stream plays which role decides which roles share a HARDWARE queue (the runtime spreads streams over a few
         // queues in creation order, and launches of streams that share one serialise): HOPE_SIDE_PERM="a,b,c,d,e,f,g" gives role i
         // (1: chain of the small-tile class, 2: image, 3 / 4: observation half of the large- / small-tile class, 5: chain of the
         // large-tile class with HOPE_DEFER_RS) the a-th ... created stream.  Default: the two observation launches on streams that do
         // not share a hardware queue (3 and 7; with 3 and 4 the larger class's observation started only when the smaller class's
-        // was done, 180 us after its motion launch): 0.695 -> 0.675 ms (profiles/r04_stream_roles.txt).
+        // was done, 180 us after its motion launch): 0.695 -> 0.675 ms (profiles/r04_stream_roles.txt).  Third session, final
+        // (pipelined) structure, profiles/r04_stream_roles_pipelined.txt: the deferred forms use roles 1, 3, 5 (+ the caller's stream)
+        // and their assignment is in the best class; role 4 matters to the JOINED form, which wants it on the 2nd stream (65 536 scenes
+        // 0.672 -> 0.660 ms, 16 384: 0.343 -> 0.305), and to the second sub-chain of a single-class batch, which wants the 7th stream
+        // (on the 2nd: 0.68 -> 0.89 ms) and therefore takes role 7 (hope_env_step).
         // A handle with the image (HOPE_F_IMAGE) has six streams at work in a step (the image on the caller's stream, two env, two search
         // streams, the layer rebuild): other roles have to share.  Measured over 40 random assignments under the final launch structure
         // (profiles/r04_stream_roles_pipelined.txt): 65 536 scenes 1.92 -> 1.85 ms, 8 192 scenes 0.527 -> 0.445 ms with the image; the
@@ -951,7 +955,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // through the LDS request.)
         static const int obs_side[2] = {getenv("HOPE_OBS_SIDE0") ? atoi(getenv("HOPE_OBS_SIDE0")) : 3, getenv("HOPE_OBS_SIDE1") ? atoi(getenv("HOPE_OBS_SIDE1")) : 4};
         static const int obs_wpc[2] = {getenv("HOPE_OBS_WPC0") ? atoi(getenv("HOPE_OBS_WPC0")) : 0, getenv("HOPE_OBS_WPC1") ? atoi(getenv("HOPE_OBS_WPC1")) : 0};
-        hipStream_t so = (split || pipe1) ? h->side[std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
+        hipStream_t so = (split || pipe1) ? h->side[(auto_subs && (i & 1)) ? 7 : std::max(1, std::min(hope_env::MAX_CHAINS - 1, obs_side[i & 1]))] : sc;
         // pipelined: the env stream of the class with MORE scenes is the caller's stream itself -- its kernels are the step's critical
         // cycle (kinematics -> motion -> observation -> the caller's next actions -> kinematics ...), and every hop between a library
         // stream and the caller's costs that cycle 20-30 us (two hops per step: 0.648 -> 0.60 ms).  Not with the image, which
