@@ -245,7 +245,7 @@ __device__ __forceinline__ double wave_min_d(double v) {
 
 // Cycle accounting of the validation kernel (instantiated only when HOPE_RS_TIMING is set; s_memtime per section):
 // [0] prologue [1] word setup [2] sample generator [3] interpolate + transform [4] pose_hits: hull, union box, obstacle cull
-// [5] pose_hits: candidate loop [6] whole wave [8] waves [9] words tested [10] generator rounds [11] passes [12] passes with
+// [5] pose_hits: candidate loop [6] whole wave [7] screen pass (round 5) [8] waves [9] words tested [10] generator rounds [11] passes [12] passes with
 // candidates [13] candidate obstacles visited
 __device__ unsigned long long g_rs_prof[64 * 16];       // 64 shards (block index mod 64), summed by the host
 // per-search log of the instrumented build (tools/rs_tail.py): cycles, words tested, samples tested, found
@@ -917,6 +917,8 @@ __device__ double g_rs_fdump[64 * 16];    // self-check: details of the first 64
                                                // [5] float32 "clear" that exact says hit (must stay 0) [6] samples checked
                                                // [8..12] passes with an undecided edge because: not a certain crossing / axis-parallel
                                                // obstacle edge / axis-parallel hull / hull corner near the line / shallow angle
+                                               // [7] words the screen condemned that the full walk found VALID (self-check build; must stay 0)
+                                               // [13] words condemned by the screen [14] searches whose every word the screen condemned
 
 // the float64 evaluation of the queued samples `idx` (one per lane, -1: none): interpolate (:510-537), calc_all_paths'
 // rotation (:47-49) and is_traj_valid's tests -- exactly the per-pass body of k_rs_validate.  Rare: out of line, reads the
@@ -1029,6 +1031,70 @@ __device__ __forceinline__ void lsync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- the SCREEN pass of k_rs_validate_f (round 5) ---------------------------------------------------------------------------
+// 92 % of the searches end with every tested word invalid, and an invalid word's colliding samples come in long runs (the hull
+// is 4.7 m long, the samples 0.1 m apart): of the invalid words of the bench workload 98 % have a colliding sample among every
+// 8th of their first 128 (tools/rs_screen_study.py, CPU oracle).  So before the words are walked one by one, up to FOUR words are
+// looked at in ONE pass: 64 / nw lanes per word, lane k of a word takes the sample nearest to arc position (k + 1) stride step
+// (stride = 128 / lanes per word) and runs the float32 filter's CERTAIN-HIT test on it.  A word with a certain hit is invalid
+// whatever else its samples do (is_traj_valid: any colliding sample, car_parking_base.py:452-534) and is skipped by the main loop;
+// a word without one is walked as before, from its first sample -- the screen never accepts anything.
+//
+// The samples are produced in CLOSED FORM, lane-parallel, instead of by the sequential `pd += d` chain.  generate_local_course
+// (reeds_shepp.py:452-507) walks segment i at pd = pd0_i + j d_i while |pd| <= |l_i|; with u = pd sign(l_i) (position along the
+// segment's own direction), s = step and r_i = (first u beyond the segment) - |l_i| the code's `ll` bookkeeping gives
+//     u0_0 = s,   u0_i = +r_(i-1) if l_(i-1) l_i > 0 (same direction), -r_(i-1) otherwise,   r_i = u0_i + n_i s - |l_i|,
+// n_i = 0 if |u0_i| > |l_i|, else floor((|l_i| - u0_i) / s) + 1.  A closed form differs from the chain by ~1e-14 (64 roundings),
+// nine orders below the float32 filter's error budget -- EXCEPT at a tie, where a sample within rounding of a segment end is in
+// or out (n_i off by one).  Then r_i flips between ~0 and s, i.e. the next segment's lattice {u0 + j s} keeps its points and only
+// gains or loses its FIRST one (u ~ 0: the same pose as the previous segment's end; or, across a direction change, the
+// reference's off-path sample at u = -s).  The screen therefore only uses lattice points with SCREEN_EPS < u < |l_i| - SCREEN_EPS:
+// every one of them is a sample of the reference whichever way the ties fall.
+constexpr double SCREEN_EPS = 1e-7;
+constexpr int SCREEN_SPAN = 128;         // samples of a word the screen spreads its lanes over
+
+// one obstacle against one sample pose in the float32 frame: a CERTAIN hit on one of the four edges (the same classification,
+// margins and robustness conditions as the main pass of k_rs_validate_f below: phase 1 "not clear", phase 2 "certain crossing")
+__device__ __forceinline__ bool screen_obstacle_hit(const float4 v01, const float4 v23, float cx, float cy, float hc, float hs,
+                                                    int efl, bool hull_ok) {
+    constexpr float FEPS_ = FEPS, FKAPPA_ = FKAPPA, HL = F_HL, HW = F_HW;
+    float u[4], w[4];
+    {
+        const float dx0 = v01.x - cx, dy0 = v01.y - cy, dx1 = v01.z - cx, dy1 = v01.w - cy;
+        const float dx2 = v23.x - cx, dy2 = v23.y - cy, dx3 = v23.z - cx, dy3 = v23.w - cy;
+        u[0] = hc * dx0 + hs * dy0; w[0] = hc * dy0 - hs * dx0;
+        u[1] = hc * dx1 + hs * dy1; w[1] = hc * dy1 - hs * dx1;
+        u[2] = hc * dx2 + hs * dy2; w[2] = hc * dy2 - hs * dx2;
+        u[3] = hc * dx3 + hs * dy3; w[3] = hc * dy3 - hs * dx3;
+    }
+    const float umin = fminf(fminf(u[0], u[1]), fminf(u[2], u[3])), umax = fmaxf(fmaxf(u[0], u[1]), fmaxf(u[2], u[3]));
+    const float wmin = fminf(fminf(w[0], w[1]), fminf(w[2], w[3])), wmax = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+    if (umin > HL + FEPS_ || umax < -HL - FEPS_ || wmin > HW + FEPS_ || wmax < -HW - FEPS_) return false;
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) g[k] = fmaxf(fabsf(u[k]) - HL, fabsf(w[k]) - HW);
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int k2 = (k + 1) & 3;
+        const float nu = w[k2] - w[k], nw = u[k] - u[k2];
+        const float dist = fabsf(__builtin_fmaf(nu, u[k], nw * w[k]));
+        const float dn = dist - __builtin_fmaf(fabsf(nu), HL, fabsf(nw) * HW);
+        const float eu0 = fminf(u[k], u[k2]), eu1 = fmaxf(u[k], u[k2]);
+        const float ew0 = fminf(w[k], w[k2]), ew1 = fmaxf(w[k], w[k2]);
+        const float esep = fmaxf(fmaxf(eu0 - HL, -HL - eu1), fmaxf(ew0 - HW, -HW - ew1));
+        const float n1 = fabsf(nu) + fabsf(nw), mg = FEPS_ * n1;
+        const bool clear = dn > mg || esep > FEPS_ || fmaxf(g[k], g[k2]) < -FEPS_;
+        const bool cross = dn < -mg && esep < -FEPS_ && fminf(fabsf(g[k]), fabsf(g[k2])) > FEPS_ && fmaxf(g[k], g[k2]) > FEPS_;
+        const float A = fabsf(nu) * HL, B = fabsf(nw) * HW;
+        const bool corners_ok = fminf(fabsf(dn), fabsf(dist - fabsf(A - B))) > mg;
+        const bool cross_u = fabsf(dist - A) <= B + mg, cross_w = fabsf(dist - B) <= A + mg;
+        const bool angle_ok = (!cross_u || fabsf(nw) >= FKAPPA_ * n1) && (!cross_w || fabsf(nu) >= FKAPPA_ * n1);
+        hit = hit || (!clear && cross && corners_ok && angle_ok && hull_ok && ((efl >> k) & 1));
+    }
+    return hit;
+}
+
 template <int OCC, bool TIMING, bool STATS>
 __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1102,13 +1168,124 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     const bool paranoid = (obs_f64 & 0x2000) != 0;        // self-check: float64 for every sample, disagreements counted
     unsigned long long st_pass = 0, st_hit = 0, st_exact = 0, st_unc = 0, st_bad_hit = 0, st_bad_clear = 0, st_samples = 0;
     unsigned long long st_why[5] = {};
+    // ---- screen pass (see screen_obstacle_hit above): up to four words per pass, certain float32 hits only ----
+    unsigned long long condemned = 0;                      // bit k: the k-th popped word has a certainly colliding sample
+    if (!(obs_f64 & 0x20000)) {                            // (HOPE_RS_DEBUG=0x20000: no screen -- A/B and the parity tests)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the obstacle view's global_load_lds have landed
+        tile_pending = false;
+        const double inv_step = 1.0 / step;
+        for (int w0 = 0; w0 < n_paths; w0 += 4) {
+            const int nw = min(4, n_paths - w0);
+            // the chunk's segment tables lie back to back in the record: into the sample queue's LDS words (not in use yet)
+            for (int t = lane; t < RS_SEG_TABLE * nw; t += WAVE) qpd[t] = tables[RS_SEG_TABLE * w0 + t];
+            lsync();
+            const int G = nw == 1 ? 64 : (nw == 2 ? 32 : (nw == 3 ? 21 : 16));         // lanes per word
+            const int stride = SCREEN_SPAN / G;                                           // 2, 4, 6, 8 samples between two lanes
+            const int wl_ = nw == 1 ? 0 : (nw == 2 ? lane >> 5 : (nw == 3 ? (lane >= 42 ? 2 : (lane >= 21 ? 1 : 0)) : lane >> 4));
+            const int kk = lane - wl_ * G;
+            const double* T = qpd + RS_SEG_TABLE * wl_;
+            const double w7s = T[7];
+            const int codew = __double2loint(w7s), nsegw = __double2hiint(w7s);
+            // closed-form sample: the lattice point of the segment that holds arc position a, at or behind it
+            const double a = (double)((kk + 1) * stride) * step;
+            double c = 0.0, u0 = step, r = 0.0, lprev = 0.0, pdv = 0.0;
+            int si = -1;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (i < nsegw) {
+                    const double l = T[RS_SEGW * i + 6], al = fabs(l);
+                    if (i >= 1) u0 = (lprev * l > 0) ? r : -r;
+                    if (si < 0 && a < c + al) {
+                        double j = ceil((a - c - u0) * inv_step);
+                        j = j < 0.0 ? 0.0 : j;
+                        const double u = u0 + j * step;
+                        si = (u > SCREEN_EPS && u < al - SCREEN_EPS) ? i : 5;           // 5: no usable sample for this lane
+                        pdv = l > 0.0 ? u : -u;
+                    }
+                    const double n = fabs(u0) > al ? 0.0 : floor((al - u0) * inv_step) + 1.0;
+                    r = u0 + n * step - al;
+                    c += al;
+                    lprev = l;
+                }
+            }
+            const bool active = lane < G * nw && si >= 0 && si < 5;
+            float X = 0, Y = 0, hc = 1, hs = 0;
+            if (active) {                                      // the pose, as in the main pass below
+                const float lf = (float)pdv;
+                const float4 row = ((const float4*)(T + RS_SEG_F32))[si];
+                const int m = type_of(codew, si);
+                const float rev = lf * 0.15915494309189535f;
+                const float sl = m == TS ? 0.0f : __builtin_amdgcn_sinf(rev), cl = m == TS ? 1.0f : __builtin_amdgcn_cosf(rev);
+                const float sgn = m == TR ? -1.0f : 1.0f;
+                const float ldx = m == TS ? lf * F_INV_MAXC : sl * F_INV_MAXC;
+                const float ldy = sgn * (1.0f - cl) * F_INV_MAXC;
+                X = row.x + (row.z * ldx - row.w * ldy);
+                Y = row.y + (row.w * ldx + row.z * ldy);
+                const float ss = sgn * sl;
+                hc = row.z * cl - row.w * ss;
+                hs = row.w * cl + row.z * ss;
+            }
+            bool hit = active && (X < fxmin - FEPS || X > fxmax + FEPS || Y < fymin - FEPS || Y > fymax + FEPS);
+            const float cx = X + hc * F_MID, cy = Y + hs * F_MID;
+            const float ex = fabsf(hc) * F_HL + fabsf(hs) * F_HW + FEPS, ey = fabsf(hs) * F_HL + fabsf(hc) * F_HW + FEPS;
+            const float lox = cx - ex, hix = cx + ex, loy = cy - ey, hiy = cy + ey;
+            const float ulox = wave_min_f(active ? lox : INFINITY), uhix = wave_max_f(active ? hix : -INFINITY);
+            const float uloy = wave_min_f(active ? loy : INFINITY), uhiy = wave_max_f(active ? hiy : -INFINITY);
+            int nc = 0;
+            for (int base = 0; base < n_obst; base += WAVE) {
+                const int o = base + lane;
+                bool near = false;
+                if (o < n_obst) {
+                    const float4 bb = fbox[o];
+                    near = !(bb.x > uhix || bb.y < ulox || bb.z > uhiy || bb.w < uloy);
+                }
+                const unsigned long long mm = __ballot(near);
+                if (near) cand[nc + __popcll(mm & ((1ull << lane) - 1))] = o;
+                nc += __popcll(mm);
+            }
+            const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1);
+            const int all_w = (1 << nw) - 1;
+            int dead = 0;
+            if (nc > 0) {
+                lsync();
+                const bool hull_ok = fminf(fabsf(hc), fabsf(hs)) >= FETA_HULL;
+                for (int ci = 0; ci < nc; ci++) {
+                    const int ro = cand[ci];
+                    const float4 bb = fbox[ro];
+                    const bool near = active && !hit && !(bb.x > hix || bb.y < lox || bb.z > hiy || bb.w < loy);
+                    if (!__any(near)) continue;
+                    const float4 v01 = ((const float4*)fv)[2 * ro], v23 = ((const float4*)fv)[2 * ro + 1];
+                    const int efl = (int)eflag[ro];
+                    if (near) hit = screen_obstacle_hit(v01, v23, cx, cy, hc, hs, efl, hull_ok);
+                    const unsigned long long hm = __ballot(hit);
+                    dead = 0;
+                    for (int w = 0; w < nw; w++) dead |= ((hm >> (w * G)) & gmask) ? (1 << w) : 0;
+                    if (dead == all_w) break;                  // every word of the chunk is condemned
+                }
+            }
+            {
+                const unsigned long long hm = __ballot(hit);   // (out-of-box hits too)
+                dead = 0;
+                for (int w = 0; w < nw; w++) dead |= ((hm >> (w * G)) & gmask) ? (1 << w) : 0;
+            }
+            condemned |= (unsigned long long)dead << w0;
+            lsync();                                           // the next chunk's tables / the first word's queue overwrite these words
+        }
+    }
+    const bool verify_screen = STATS && paranoid;          // self-check build: condemned words are walked anyway and must come out invalid
+    const bool all_condemned = condemned == ((1ull << n_paths) - 1);
+    unsigned long long st_scr_words = __popcll(condemned), st_scr_dead = all_condemned ? 1 : 0, st_scr_bad = 0;
+    RS_T(7);
     for (int idx = 1; idx <= n_paths; idx++) {
+        if (all_condemned && !verify_screen) break;        // nothing left to walk: no path
         const double tcur = tb;
         if (idx < n_paths && lane < RS_SEG_TABLE) tb = tables[RS_SEG_TABLE * idx + lane];      // prefetch the next word's
         const double len0 = readlane_d(tcur, 6), w6 = readlane_d(tcur, 7);
         const int code = __double2loint(w6), nseg = __double2hiint(w6);
         const int cls1 = type_of(code, 0) * 2 + (len0 > 0.0 ? 1 : 0);
         if (fabs(len0) >= bad1[cls1]) continue;           // contains a sample already known to collide
+        const bool screened = (condemned >> (idx - 1)) & 1;
+        if (screened && !verify_screen) continue;         // the screen found a certainly colliding sample of this word
         bool invalid = false;
         if (lane < RS_SEG_TABLE) segp[lane] = tcur;
         if (TIMING) tsec[9] += 1;
@@ -1389,9 +1566,11 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
             }
             lsync();
         }
+        if (STATS && screened && !invalid) { st_scr_bad += 1; continue; }   // (must never happen; the product build never gets here)
         if (!invalid) { found = idx - 1; break; }
     }
     if (STATS && lane == 0) {                              // statistics of the filter (tools/rs_filter_stats.py, the soak test)
+        atomicAdd(&g_rs_fstat[7], st_scr_bad); atomicAdd(&g_rs_fstat[13], st_scr_words); atomicAdd(&g_rs_fstat[14], st_scr_dead);
         for (int b = 0; b < 5; b++) atomicAdd(&g_rs_fstat[8 + b], st_why[b]);
         atomicAdd(&g_rs_fstat[0], st_pass); atomicAdd(&g_rs_fstat[1], st_hit); atomicAdd(&g_rs_fstat[2], st_exact);
         atomicAdd(&g_rs_fstat[3], st_unc); atomicAdd(&g_rs_fstat[4], st_bad_hit); atomicAdd(&g_rs_fstat[5], st_bad_clear);

@@ -14,8 +14,15 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <pthread.h>
+
+#include <new>
+
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -250,6 +257,69 @@ int default_threads() {
     return hc > 0 ? hc : 1;
 }
 
+
+// Persistent worker pool (round 5).  hope_scenegen_generate used to start fresh std::threads on every call: a pool refill is
+// three calls of ~2 700 lots, i.e. ~1 ms of generation behind ~3 ms of thread start-up for the 86 threads a 256-CPU host gave
+// it -- 0.9 M lots/s on 256 hardware threads against 0.25 M/s on ONE, and worse on a rank pinned to 32 CPUs.  The workers are
+// now created once (lazily, up to the largest fan-out asked for), sleep on a condition variable between calls and are shared
+// by every caller of the process (calls are serialised; a fork()ed child starts with an empty pool).
+class WorkerPool {
+    std::mutex run_m_;                     // one job at a time
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> workers_;
+    const std::function<void()>* job_ = nullptr;
+    uint64_t generation_ = 0;
+    int want_ = 0, claimed_ = 0, pending_ = 0;
+
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (claimed_ >= want_) continue;                // more workers than this job wants
+            claimed_++;
+            const std::function<void()>* job = job_;
+            lk.unlock();
+            (*job)();
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+
+public:
+    // runs fn on n_threads threads (the caller is one of them) and returns when all of them are done
+    void run(int n_threads, const std::function<void()>& fn) {
+        std::lock_guard<std::mutex> run_lk(run_m_);
+        const int helpers = std::max(0, n_threads - 1);
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            while ((int)workers_.size() < helpers) {
+                workers_.emplace_back([this] { loop(); });
+                workers_.back().detach();                   // (process-lifetime threads: nothing to join at exit)
+            }
+            job_ = &fn; want_ = helpers; claimed_ = 0; pending_ = helpers;
+            generation_++;
+        }
+        if (helpers > 0) cv_work_.notify_all();
+        fn();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    void forget_workers() { new (this) WorkerPool(); }      // fork(): the child has none of the parent's threads
+};
+WorkerPool* g_pool = nullptr;
+std::once_flag g_pool_once;
+WorkerPool& pool() {
+    std::call_once(g_pool_once, [] {
+        g_pool = new WorkerPool();
+        pthread_atfork(nullptr, nullptr, [] { if (g_pool) g_pool->forget_workers(); });
+    });
+    return *g_pool;
+}
+
 }  // namespace
 
 extern "C" {
@@ -269,14 +339,17 @@ int hope_scenegen_generate(int level, int bay_mode, int n, uint64_t seed, int64_
     if (level_index(level) < 0 || n < 0 || max_obstacles <= 0 || !start || !dest || !bbox || !verts || !n_obst) return HOPE_EINVAL;
     if (n == 0) return HOPE_OK;
     int nt = n_threads > 0 ? n_threads : default_threads();
-    nt = std::max(1, std::min(nt, (n + 31) / 32));
+    // chunks of 8 .. 32 lots handed out from one counter: at least ~8 chunks per thread, so that the rejection samplers' uneven
+    // cost per lot evens out, and no more threads than chunks
+    const int chunk = std::max(8, std::min(32, n / std::max(1, 8 * nt)));
+    nt = std::max(1, std::min(nt, (n + chunk - 1) / chunk));
     std::atomic<int> next{0}, err{0};
-    auto work = [&]() {
+    const std::function<void()> work = [&]() {
         Case c;
         for (;;) {
-            const int a = next.fetch_add(32);
+            const int a = next.fetch_add(chunk);
             if (a >= n) break;
-            for (int i = a; i < std::min(n, a + 32); i++) {
+            for (int i = a; i < std::min(n, a + chunk); i++) {
                 Rng rng(seed * 0x9E3779B97F4A7C15ull + (uint64_t)(first_index + i) * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull);
                 rng.next();
                 const bool bay = level != 2 && (bay_mode == 1 || (bay_mode < 0 && rng.uni() > 0.5));
@@ -295,10 +368,8 @@ int hope_scenegen_generate(int level, int bay_mode, int n, uint64_t seed, int64_
             }
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    if (nt == 1) work();
+    else pool().run(nt, work);
     return err.load();
 }
 

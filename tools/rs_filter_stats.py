@@ -46,7 +46,9 @@ def main():
           f'{100 * (v[0] - v[1] - v[2]) / max(v[0], 1):.1f} %')
     names = ('no certain crossing', 'axis-parallel obstacle edge', 'axis-parallel hull', 'hull corner near the edge line', 'shallow angle')
     print('undecided passes by cause (a pass can have several): ' + ', '.join(f'{nm} {v[8 + i]}' for i, nm in enumerate(names)))
+    print(f'screen pass: {v[13]} words condemned, {v[14]} searches with every tested word condemned')
     if args.check:
+        print(f'screen self-check: condemned words the full walk found valid {v[7]}  (must be 0)')
         print(f'self-check over {v[6]} samples: float32 hit / float64 clear {v[4]}, float32 clear / float64 hit {v[5]}  (both must be 0)')
 
 
