@@ -50,6 +50,10 @@ def parse():
                          'device-resident pool of --pool generated scenes inside the step kernel (HOPE_AUTO_REDRAW)')
     ap.add_argument('--fresh-scenes', action='store_true', help='(the default now; kept for old command lines)')
     ap.add_argument('--pool', type=int, default=8192)
+    ap.add_argument('--refresh-every', type=int, default=8,
+                    help='the device-resident pool of generated lots is REPLACED in the background while the steps run, as a rollout does it '
+                         '(scene_gen.PoolRefresher: the native generator fills pinned staging on host threads, an asynchronous upload swaps the '
+                         'pool in): the step loop polls it every this many steps, inside the timed region.  0 = a static pool')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
                     help='launch chains of the two tile classes on two streams (auto = on)')
     ap.add_argument('--max-obst', type=int, default=128)
@@ -70,8 +74,10 @@ def parse():
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--rs-join', default='deferred', choices=['deferred', 'joined'],
                     help='deferred (HOPE_DEFER_RS): the caller\'s stream is ordered after the observation / reward outputs of a step; its '
-                         'Reeds-Shepp outputs are ordered by hope_env_wait_rs or the next step, so consecutive steps pipeline on the '
-                         'library\'s streams.  joined: every output ordered on the caller\'s stream before the next step is enqueued')
+                         'Reeds-Shepp outputs are ordered by a hope_env_wait_rs issued BEFORE the next step -- the next step REPLACES them '
+                         '(consecutive steps pipeline on the library\'s streams, also for single-class batches cut into sub-chains); the bench '
+                         'reads them after its last step only.  joined: every output ordered on the caller\'s stream before the next step is '
+                         'enqueued (reported next to `value` as value_joined)')
     ap.add_argument('--witness', type=int, default=1024,
                     help='after the timed region: this many random scene slots of the TIMED configuration are rebuilt in the CPU '
                          'oracle from the state on the device and one more fused step is compared (parity_check); 0 = off')
@@ -109,8 +115,24 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's line does
+        # (one process per GPU over RCCL; rank 0 of that run prints the JSON line, which passes through)
+        import socket
+        import subprocess
+        if os.environ.get('HOPE_BENCH_SHARE_GPU') != '1' and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus}: this node shows {torch.cuda.device_count()} HIP device(s) (HOPE_BENCH_SHARE_GPU=1 runs the '
+                             'ranks on one GPU over gloo: control-flow test only)')
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})')
+        raise SystemExit(f'--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree')
     dist = None
     # test hook (1-GPU boxes): HOPE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the
     # barrier / MAX-reduce, so the multi-rank control flow can be exercised without N GPUs
@@ -177,9 +199,11 @@ def main():
 
     defer = args.rs_join == 'deferred'
 
-    def one_step(i):
+    bench_refresher = None
+
+    def one_step(i, defer_=None):
         # episode turnover is fused into the step (HOPE_AUTO_RESET = step + restart(done) + reset_obs(active=done))
-        env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, defer_rs=defer)
+        env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, defer_rs=defer if defer_ is None else defer_)
 
     fresh = not args.same_map
     gen_rate = None
@@ -198,9 +222,16 @@ def main():
             env.set_dlp_cases()
         env.set_redraw_seed(args.seed * 7919 + 1)
 
-        def one_step(i):  # noqa: F811
+        bench_refresher = None
+        if gl and args.refresh_every > 0 and args.policy == 'none':
+            from hope_amd.scene_gen import PoolRefresher
+            bench_refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5)
+
+        def one_step(i, defer_=None):  # noqa: F811
             # the new map is drawn inside the step kernel (HOPE_AUTO_REDRAW = step + redraw(done) + reset_obs(active=done))
-            env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, fresh=True, defer_rs=defer)
+            env.step(act_bank[i % len(act_bank)], stages=stages, auto_reset=True, fresh=True, defer_rs=defer if defer_ is None else defer_)
+            if bench_refresher is not None and i % args.refresh_every == 0:
+                bench_refresher.poll()                        # never blocks: commits a finished batch of new lots, starts the next fill
 
     trainer = None
     if args.policy == 'hope':
@@ -228,7 +259,7 @@ def main():
             for net in (getattr(agent, 'actor', None), getattr(agent, 'critic', None), getattr(agent, 'critic_target', None)):
                 if net is not None:
                     set_img_amp(net, True)
-        one_step = lambda i: trainer.step()  # noqa: E731
+        one_step = lambda i, defer_=None: trainer.step()  # noqa: E731
 
     # HIP events bracket the launches of the kernel the roofline is stated for, live in the timed region; timing EVERY
     # launch costs ~4 % of the step in launch latency (16 event records per step), so the other kernels are timed in a
@@ -246,6 +277,12 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize(dev)
+    # the maps resident NOW (the pre-roll redrew finished episodes on the device): SURVEY.md §8(d)'s E per scene from them
+    edges = 4.0 * env.n_obst_now()
+    bytes_per_launch = float(np.sum(808.0 + 16.0 * edges))
+    if args.image:
+        bytes_per_launch = float(np.sum(64.0 + 16.0 * edges + 3.0 * 64 * 64))
+    commits0 = bench_refresher.commits if bench_refresher is not None else 0
     env.kernel_union_ms(reset=True)
     env.kernel_ms(reset=True)
     if dist is not None:
@@ -259,6 +296,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    commits_timed = (bench_refresher.commits - commits0) if bench_refresher is not None else 0
     n_break = min(args.steps, 10)
     dom_union = env.kernel_union_ms(reset=True)[dom]
     dom_stats = env.kernel_ms(reset=True)[dom]
@@ -287,11 +325,23 @@ def main():
             dsum += float(env.done.float().mean().item())
             env.kernel_union_ms(reset=True)
             env.kernel_ms(reset=True)
+        # the JOINED form of the same step (what a caller with the Reeds-Shepp planner in its loop gets: every output ordered on
+        # its stream before the next step is enqueued), same run, same population
+        torch.cuda.synchronize(dev)
+        tj = time.perf_counter()
+        for i in range(args.repeat_steps):
+            one_step(i, False)
+        torch.cuda.synchronize(dev)
+        joined_ms = (time.perf_counter() - tj) / args.repeat_steps * 1e3
+        env.kernel_union_ms(reset=True)
+        env.kernel_ms(reset=True)
         sm = sorted(ms)
-        repeat = {'passes': args.repeat_passes, 'steps_per_pass': args.repeat_steps, 'ms_per_step': ms, 'min': sm[0],
+        repeat = {'passes': args.repeat_passes, 'steps_per_pass': args.repeat_steps, 'ms_per_step': ms, 'min': sm[0], 'joined_ms_per_step': joined_ms,
                   'median': sm[len(sm) // 2], 'max': sm[-1], 'spread': (sm[-1] - sm[0]) / sm[len(sm) // 2],
                   'env_steps_per_s_median': N / (sm[len(sm) // 2] * 1e-3), 'done_frac_at_pass_ends': dsum / args.repeat_passes,
                   'note': 'this rank, after the driver-timed region; not part of `value`'}
+    if bench_refresher is not None:
+        bench_refresher.close()
     # ---- in-run correctness witness of exactly this configuration (after all timing)
     parity = None
     if args.witness > 0 and trainer is None and rank == 0:
@@ -341,7 +391,8 @@ def main():
         # labelled as such.  They describe the default workload only.
         default_workload = (N == 65536 and args.mix == 'mixed' and args.stages == 'all' and trainer is None and fresh)
         traffic = traffic_source = None
-        pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic_image.json' if args.image else 'r04_pmc_traffic.json')
+        pmc = next((q for q in (os.path.join(ROOT, 'profiles', f'{r}_pmc_traffic{"_image" if args.image else ""}.json') for r in ('r05', 'r04'))
+                    if os.path.exists(q)), '')
         if os.path.exists(pmc) and default_workload:
             try:
                 traffic = json.load(open(pmc))['kernels'][dom]['hbm_bytes']
@@ -355,7 +406,7 @@ def main():
         # rocprofv3 --pmc pass of this command (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64).  floor = sum over classes
         # of count / rate; frac = floor / measured time.  Counts are static (labelled), the step time is this run's.
         valu = None
-        sq = os.path.join(ROOT, 'profiles', 'r04_sq_counters.json')
+        sq = next((q for q in (os.path.join(ROOT, 'profiles', f'{r}_sq_counters.json') for r in ('r05', 'r04')) if os.path.exists(q)), '')
         vr = os.path.join(ROOT, 'profiles', 'r03_valu_rates.json')
         if os.path.exists(sq) and os.path.exists(vr) and default_workload and not args.image:
             try:
@@ -378,7 +429,7 @@ def main():
                 valu = {'valu_insts_per_bench_step': insts, 'mix_weighted_floor_ms_per_step': floor_s * 1e3,
                         'frac': floor_s / (elapsed / args.steps), 'rates_wave_insts_per_s': {'f64_arith': r64, 'f64_trans': rtr, 'other': r32},
                         'per_kernel': per_kernel,
-                        'source': 'static instruction counts by class: profiles/r04_sq_counters.json (rocprofv3 --pmc passes of this command); '
+                        'source': 'static instruction counts by class: ' + os.path.relpath(sq, ROOT) + ' (rocprofv3 --pmc passes of this command); '
                                   'issue rates: profiles/r03_valu_rates.json (tools/valu_rate.py on the same GPU type); step and kernel times: this run. '
                                   'A single wave issues at most one instruction per ~8-10 cycles, so a kernel needs >= 4 waves per SIMD to reach these rates.'}
             except Exception:
@@ -408,7 +459,7 @@ def main():
             'host': {'cpus_this_rank': host_cpus, 'cpus_node': os.cpu_count(), 'generator_threads': L.load_library().hope_scenegen_default_threads(),
                      'pinned': world > 1 and os.environ.get('HOPE_NO_PIN') != '1'},
             'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
-                                   'auto-restart of finished episodes', 'scenes_per_gpu': N, 'preroll_steps': args.preroll if trainer is None else 0, 'mean_edges': float(edges.mean()),
+                                   'auto-restart of finished episodes', 'scenes_per_gpu': N, 'preroll_steps': args.preroll if trainer is None else 0, 'mean_edges': float(edges.mean()), 'mean_edges_of': 'the maps resident after the pre-roll (hope_env_download_n_obst)',
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap),
                        'rs_join': ('deferred: the caller\'s stream is ordered after each step\'s observation / reward / status outputs, its '
@@ -418,6 +469,9 @@ def main():
                                             f'{args.pool} scenes, Dragon-Lake cases drawn on the device (start candidate, jitter, flips, cull per episode)'
                                             if fresh else 'restart on the same map, fused into the step (HOPE_AUTO_RESET)'),
                        'host_generator_scenes_per_s': gen_rate,
+                       'timed_window': f'{args.steps} steps between two synchronisations: `value` includes one pipeline fill and drain (the last '
+                                       'step\'s search chain runs out after its observation); value_steady is the same loop over '
+                                       f'{args.repeat_steps}-step passes',
                        'done_frac_last': done_frac, 'rs_found_frac_last': rs_found},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': dom,
@@ -443,7 +497,17 @@ def main():
                          'ms_per_bench_step_by_kernel': per_step, 'breakdown_steps': n_break},
         }
         result['repeat'] = repeat
+        if repeat is not None:
+            # next to the driver-timed `value`: the steady-state figure (median of the longer passes) and the joined form, this rank x ranks
+            result['value_steady'] = total_scenes / (repeat['median'] * 1e-3)
+            result['value_joined'] = total_scenes / (repeat['joined_ms_per_step'] * 1e-3)
+            result['value_vs_steady'] = value / result['value_steady']
+        result['pool_refresh'] = ({'every_steps': args.refresh_every, 'commits_in_timed_region': commits_timed, 'refresher_commits': bench_refresher.commits,
+                                   'generator_seconds': bench_refresher.gen_seconds, 'lots_per_commit': args.pool,
+                                   'host_generator_lots_per_s': (bench_refresher.commits + 1) * args.pool / max(bench_refresher.gen_seconds, 1e-9)}
+                                  if bench_refresher is not None else None)
         result['parity_check'] = parity
+        result['queue_check'] = env.queue_check() if env.overlap else None
         if trainer is not None:
             from hope_amd.policy import count_parameters
             result['metric'] = 'env+agent steps/sec (full CarParking step + HOPE transformer policy' + \

@@ -263,10 +263,43 @@ class ParkingBatch:
                                        self._stream()), 'hope_env_step')
         return self
 
-    def wait_rs(self):
-        """orders the current stream after the Reeds-Shepp outputs of the last step(defer_rs=True); no-op otherwise."""
-        L.check(self.lib.hope_env_wait_rs(self.h, self._stream()), 'hope_env_wait_rs')
+    def last_step(self):
+        """sequence number of the most recent step() / reset_obs() of this handle (hope_env_last_step)"""
+        g = C.c_uint64(0)
+        L.check(self.lib.hope_env_last_step(self.h, C.byref(g)), 'hope_env_last_step')
+        return int(g.value)
+
+    def wait_rs(self, step=None):
+        """orders the current stream after the Reeds-Shepp outputs of the last step(defer_rs=True); no-op otherwise.
+        step = a value of last_step(): the wait is for THAT step's search and raises (HOPE_ESTATE) when a newer step has been
+        enqueued since -- consecutive deferred steps pipeline and the newer one replaces rs_word / rs_lengths."""
+        if step is None:
+            L.check(self.lib.hope_env_wait_rs(self.h, self._stream()), 'hope_env_wait_rs')
+        else:
+            L.check(self.lib.hope_env_wait_rs_step(self.h, C.c_uint64(int(step)), self._stream()), 'hope_env_wait_rs_step')
         return self
+
+    def queue_check(self):
+        """hope_env_create's measurement of which library streams share a hardware queue (hope_env_queue_check):
+        {'queue_of_role': [8 ints, [0] = the NULL stream], 'distinct_queues': n, 'roles_shared': pairs of roles busy in the same step
+        form that sit on one queue, 'ms': cost of the measurement}"""
+        q = (C.c_int32 * 8)()
+        n, ms = C.c_int32(0), C.c_double(0)
+        L.check(self.lib.hope_env_queue_check(self.h, q, C.byref(n), C.byref(ms)), 'hope_env_queue_check')
+        q = [int(v) for v in q]
+        shared = []
+        for group in ((0, 5, 1, 3), (0, 1, 3, 4), (5, 1, 3, 7)):
+            for i, a in enumerate(group):
+                for b in group[i + 1:]:
+                    if q[a] >= 0 and q[a] == q[b] and [a, b] not in shared:
+                        shared.append([a, b])
+        return {'queue_of_role': q, 'distinct_queues': int(n.value), 'roles_shared': shared, 'ms': float(ms.value)}
+
+    def n_obst_now(self):
+        """obstacle count of every scene as it is on the device now (device-side draws change it): numpy int32 [N]"""
+        out = np.zeros(self.n, np.int32)
+        L.check(self.lib.hope_env_download_n_obst(self.h, out.ctypes.data), 'hope_env_download_n_obst')
+        return out
 
     def restart(self, mask):
         """episodes flagged in mask (u8 [N]) go back to their start pose, t = 0 (same map)."""

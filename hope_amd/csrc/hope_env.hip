@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -127,11 +128,25 @@ struct hope_env {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {}, ev_segs[2] = {}, ev_post[2] = {};
     hipEvent_t ev_bev[2] = {};                              // image: fork / join of the static-layer rebuild next to k_bev_prep
     int rs_parity = 0;                                      // which of the two queue counters of a chain this step uses (pipelined steps)
+    int queue_of_role[MAX_CHAINS] = {-1, -1, -1, -1, -1, -1, -1, -1};   // measured hardware-queue class of role r's stream ([0]: the NULL stream)
+    int n_queues = 0;
+    double queue_check_ms = 0.0;
     // HOPE_DEFER_RS: the chains of the last step have not been joined into the caller's stream (events ev_join[1], ev_join[RS_SIDE])
     static constexpr int RS_SIDE = 5;                       // the stream of the first chain when it may not run on the caller's
     bool rs_pending = false;
 };
 
+
+// Live handles: hope_env_destroy on a pointer that is not (or no longer) a handle, and the hot entry points on a destroyed one, fail
+// with HOPE_EINVAL instead of touching freed memory (a ~50 ns set lookup per call next to ~15 launches).
+#include <mutex>
+#include <unordered_set>
+static std::mutex g_live_m;
+static std::unordered_set<const void*> g_live;
+static bool is_live(const void* h) {
+    std::lock_guard<std::mutex> lk(g_live_m);
+    return h && g_live.count(h) != 0;
+}
 
 // every entry point runs on the handle's device and puts the caller's current device back (a process that drives
 // several GPUs keeps PyTorch's notion of the current device)
@@ -243,6 +258,12 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
         traj_valid[s] = 0;
         layer_valid[s] = 0;                                           // a new map: the static image layer is rebuilt
     }
+}
+
+// hope_env_create's hardware-queue measurement: one wave that idles for `ticks` of the 100 MHz real-time counter
+__global__ void k_spin(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
 __global__ void k_debug_math(int fn, int n, const double* a, const double* b, double* out) {
@@ -359,7 +380,7 @@ constexpr int COMPACT_THREADS = HOPE_COMPACT_THREADS;
 template <typename OT>
 __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list, int n, uint8_t* flag, const uint8_t* active,
                                                                  int32_t* out, int32_t* rs_count, const double* post,
-                                                                 const double* scene_c, int8_t* rs_word, void* rs_lengths) {
+                                                                 const double* scene_c, int8_t* rs_word, void* rs_lengths, const int32_t* n_obst) {
     __shared__ int wsum[COMPACT_THREADS / WAVE];
     __shared__ int base;
     const int i = blockIdx.x * COMPACT_THREADS + threadIdx.x;
@@ -394,7 +415,11 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
     for (int w = 0; w < COMPACT_THREADS / WAVE; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
     if (threadIdx.x == 0) base = total ? atomicAdd(rs_count, total) : 0;
     __syncthreads();
+#ifdef HOPE_RS_NOPACK
     if (gate) out[base + woff + before] = s;
+#else
+    if (gate) out[base + woff + before] = rs_list_pack(s, n_obst[s]);               // (hope_internal.h)
+#endif
 }
 
 // one block per uploaded scene: copy its obstacle tile
@@ -452,6 +477,7 @@ static int settle_rs(hope_env_t* h) {
 const char* hope_last_error(void) { return g_err.c_str(); }
 int hope_abi_version(void) { return HOPE_ABI_VERSION; }
 
+static int destroy_impl(hope_env_t* h);
 int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int device_id, uint32_t flags) {
     if (!out || n_scenes <= 0 || max_obstacles <= 0) return fail(HOPE_EINVAL, "hope_env_create: bad argument");
     if (flags & 0x20)
@@ -468,8 +494,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
     size_t lds = step_lds_bytes(max_obstacles);
     size_t lds_rs = rs_lds_bytes(max_obstacles);
-    if (lds > 160 * 1024 || lds_rs > 160 * 1024)
-        return fail(HOPE_EINVAL, "hope_env_create: max_obstacles too large for the 160 KiB LDS tile");
+    if (lds > 160 * 1024 || lds_rs > 160 * 1024 || max_obstacles > 255 || n_scenes >= RS_LIST_MAX_SCENES)
+        return fail(HOPE_EINVAL, "hope_env_create: max_obstacles too large for the 160 KiB LDS tile (or > 255), or more than 2^24 - 1 scenes per handle");
     hope_env* h = new (std::nothrow) hope_env();
     if (!h) return fail(HOPE_ENOMEM, "hope_env_create: host allocation failed");
     h->n = n_scenes; h->max_obst = max_obstacles; h->device = device_id; h->flags = flags;
@@ -481,7 +507,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     do {                                                                                           \
         hipError_t e2 = hipMalloc((void**)&(ptr), (bytes));                                        \
         if (e2 != hipSuccess) {                                                                    \
-            hope_env_destroy(h);                                                                   \
+            destroy_impl(h);                                                                       \
             return fail(HOPE_ENOMEM, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e2)); \
         }                                                                                          \
     } while (0)
@@ -629,16 +655,93 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
             HIPCHK(hipStreamCreateWithPriority(&created[c], hipStreamNonBlocking, prio));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
         }
+        // ---- which created streams share a hardware queue: measure, then give the roles that are busy together different queues ----
+        // cls[c]: queue class of the c-th created stream (c = 0: the NULL stream, where PyTorch's default current stream lives).
+        // A stream is compared with one representative of every class seen so far: <= 4 classes x 7 streams pairs.
+        int cls[hope_env::MAX_CHAINS];
+        for (int c = 0; c < hope_env::MAX_CHAINS; c++) cls[c] = -1;
+        static const bool no_check = getenv("HOPE_QUEUE_CHECK") && atoi(getenv("HOPE_QUEUE_CHECK")) == 0;
+        if (!no_check) {
+            const auto t_begin = std::chrono::steady_clock::now();
+            const long long ticks = 10000;                    // 100 us at 100 MHz
+            auto pair_ms = [&](hipStream_t a, hipStream_t b) -> double {   // both spinning "at once": ~0.1 ms on two queues, ~0.2 ms on one
+                hipStreamSynchronize(a); hipStreamSynchronize(b);
+                const auto t0 = std::chrono::steady_clock::now();
+                hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+                hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+                hipStreamSynchronize(a); hipStreamSynchronize(b);
+                return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            };
+            created[0] = nullptr;
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, created[1], 100LL);      // (first launch of the kernel: module load, not measured)
+            hipStreamSynchronize(created[1]);
+            int rep[hope_env::MAX_CHAINS], n_cls = 0;
+            bool ok = true;
+            for (int c = 0; c < hope_env::MAX_CHAINS && ok; c++) {
+                int found = -1;
+                for (int k = 0; k < n_cls && found < 0; k++) {
+                    double t = pair_ms(created[rep[k]], created[c]);
+                    if (t > 0.15 && t < 0.19) t = std::min(t, pair_ms(created[rep[k]], created[c]));   // near the threshold: once more
+                    if (t >= 0.17) found = k;                 // serialised: the same hardware queue
+                    if (t > 2.0) ok = false;                  // something else is using the GPU: do not trust any of it
+                }
+                if (found < 0) { rep[n_cls] = c; found = n_cls++; }
+                cls[c] = found;
+            }
+            HIPCHK(hipGetLastError());
+            h->queue_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            if (!ok) { for (int c = 0; c < hope_env::MAX_CHAINS; c++) cls[c] = -1; n_cls = 0; }
+            h->n_queues = n_cls;
+            // Assignment.  Roles busy at the same time: deferred step {caller, 5, 1, 3}; joined step {caller, 1, 3, 4}; two sub-chains of one
+            // class {5, 1, 3, 7}.  Greedy in that order of importance: every role takes the free stream whose class collides with the fewest
+            // roles it must not share with; ties keep the hand-found table (so a box that shows nothing to gain gets exactly round 4's
+            // assignment).  Not for image handles (six busy streams on four queues: the measured table stays), not when the user gave one.
+            if (n_cls >= 2 && !getenv("HOPE_SIDE_PERM") && !(flags & HOPE_F_IMAGE)) {
+                static const int order[7] = {5, 1, 3, 4, 7, 2, 6};
+                static const int conflicts[hope_env::MAX_CHAINS][4] = {{-1, -1, -1, -1}, {0, 5, -1, -1}, {-1, -1, -1, -1}, {0, 5, 1, -1},
+                                                                       {0, 1, 3, -1}, {0, -1, -1, -1}, {-1, -1, -1, -1}, {5, 1, 3, -1}};
+                int newperm[hope_env::MAX_CHAINS] = {0, 0, 0, 0, 0, 0, 0, 0};
+                bool taken[hope_env::MAX_CHAINS] = {};
+                for (int oi = 0; oi < 7; oi++) {
+                    const int r = order[oi];
+                    int best = -1, best_cost = 1 << 30;
+                    for (int c = 1; c < hope_env::MAX_CHAINS; c++) {
+                        if (taken[c]) continue;
+                        int cost = 0;
+                        for (int k = 0; k < 4; k++) {
+                            const int o = conflicts[r][k];
+                            if (o < 0) continue;
+                            const int oc = o == 0 ? cls[0] : (newperm[o] ? cls[newperm[o]] : -2);
+                            if (oc == cls[c]) cost += 4;
+                        }
+                        if (c != perm[r]) cost += 1;          // prefer the table's stream among equals
+                        if (cost < best_cost) { best_cost = cost; best = c; }
+                    }
+                    newperm[r] = best; taken[best] = true;
+                }
+                for (int r = 1; r < hope_env::MAX_CHAINS; r++) perm[r] = newperm[r];
+            }
+        }
         for (int r = 1; r < hope_env::MAX_CHAINS; r++) h->side[r] = created[perm[r]];
+        h->queue_of_role[0] = cls[0];
+        for (int r = 1; r < hope_env::MAX_CHAINS; r++) h->queue_of_role[r] = cls[perm[r]];
     }
     HIPCHK(hipDeviceSynchronize());
+    { std::lock_guard<std::mutex> lk(g_live_m); g_live.insert(h); }
     *out = h;
     return HOPE_OK;
 }
 
 int hope_env_destroy(hope_env_t* h) {
-    settle_rs(h);
     if (!h) return HOPE_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_live_m);
+        if (g_live.erase(h) == 0) return fail(HOPE_EINVAL, "hope_env_destroy: not a live handle (destroyed twice?)");
+    }
+    return destroy_impl(h);
+}
+static int destroy_impl(hope_env_t* h) {                   // (also the clean-up of a hope_env_create that failed half-way: not registered yet)
+    settle_rs(h);
     DeviceGuard guard(h->device);
     drain_events(h);
     hipDeviceSynchronize();
@@ -712,6 +815,14 @@ int hope_debug_rs_log(int32_t* out, int cap, int32_t* n, int reset) {
     if (!out || !n || cap < 0) return fail(HOPE_EINVAL, "hope_debug_rs_log: bad argument");
     hipError_t e = rs_log_read(out, cap, n, reset);
     return e == hipSuccess ? HOPE_OK : fail(HOPE_EHIP, std::string("hope_debug_rs_log: ") + hipGetErrorString(e));
+}
+
+int hope_env_queue_check(hope_env_t* h, int32_t* queue_of_role, int32_t* n_queues, double* ms) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_queue_check: null handle");
+    if (queue_of_role) for (int r = 0; r < hope_env::MAX_CHAINS; r++) queue_of_role[r] = h->queue_of_role[r];
+    if (n_queues) *n_queues = h->n_queues;
+    if (ms) *ms = h->queue_check_ms;
+    return HOPE_OK;
 }
 
 int hope_env_num_scenes(const hope_env_t* h) { return h ? h->n : HOPE_EINVAL; }
@@ -1031,9 +1142,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         {
             const dim3 cg((p.n_list + COMPACT_THREADS - 1) / COMPACT_THREADS);
             if (of64) hipLaunchKernelGGL(k_rs_compact<double>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
-                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
+                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst);
             else hipLaunchKernelGGL(k_rs_compact<float>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
-                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths);
+                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst);
         }
         if (tm) tm->end(sc);
         RsParams r;
@@ -1115,6 +1226,7 @@ static int check_pool_classes(hope_env_t* h, const char* who) {
 static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active, uint32_t stages,
                        const hope_step_out* out, void* stream, int has_action) {
     if (!h || !out) return fail(HOPE_EINVAL, "hope_env_step: null argument");
+    if (!is_live(h)) return fail(HOPE_EINVAL, "hope_env_step: not a live handle (destroyed?)");
     if (!h->have_tables) return fail(HOPE_ESTATE, "hope_env_step: hope_env_upload_tables has not been called");
     if (!h->have_scenes) return fail(HOPE_ESTATE, "hope_env_step: hope_env_set_scenes has not been called");
     if (has_action && !actions) return fail(HOPE_EINVAL, "hope_env_step: actions is null");
@@ -1189,6 +1301,30 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
 }
 
 // ---- scene pool: pinned staging -> asynchronous upload into the set the kernels are not reading -> swap by stream order ----
+// pool identity (hope_env_pool_generation): a hash chain over what was uploaded, so that equal histories give equal values across
+// processes and different pools differ (a counter said "1" for any first pool)
+static uint64_t hmix64(uint64_t z) {                        // splitmix64 finaliser (host twin of hope_dev.h's mix64)
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t fold64(uint64_t a, uint64_t b) { return hmix64(a ^ hmix64(b + 0x9E3779B97F4A7C15ull)); }
+// (one multiply per 8 bytes: hope_env_commit_pool hashes ~0.8 MB on the thread that enqueues the steps -- ~0.1 ms per commit; the
+// splitmix chain above cost 0.7 ms, more than a 65 536-scene step)
+static uint64_t hash_bytes(uint64_t hsh, const void* p, size_t bytes) {
+    const unsigned char* q = (const unsigned char*)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, q + i, 8); hsh = (hsh ^ w) * 0x100000001B3ull; hsh ^= hsh >> 29; }
+    uint64_t w = 0;
+    if (i < bytes) { memcpy(&w, q + i, bytes - i); hsh = (hsh ^ w) * 0x100000001B3ull; }
+    return fold64(hsh, bytes);
+}
+static void bump_pool_generation(hope_env_t* h, uint64_t content) {
+    h->pool_generation = fold64(h->pool_generation, content);
+    if (h->pool_generation == 0) h->pool_generation = 1;   // 0 is reserved: "no pool" / "skip the check"
+}
+
 static int pool_init_streams(hope_env_t* h) {
     if (h->pool_stream) return HOPE_OK;
     HIPCHK(hipStreamCreateWithFlags(&h->pool_stream, hipStreamNonBlocking));
@@ -1323,7 +1459,22 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     h->pool_nobst_host.assign(h->pstage.nobst, h->pstage.nobst + n_pool);
     h->pactive = t;
     h->pool_wait_pending = true;
-    h->pool_generation++;
+    {   // identity of the new pool: every scalar of every entry and two vertex words of each
+        uint64_t c = hash_bytes(0x706f6f6cull, h->pstage.start, P * 24);
+        c = hash_bytes(c, h->pstage.dest, P * 24);
+        c = hash_bytes(c, h->pstage.bbox, P * 32);
+        c = hash_bytes(c, h->pstage.nobst, P * sizeof(int32_t));
+        const size_t tile_words = (size_t)h->max_obst * 8;
+        for (size_t k = 0; k < P; k++) {                     // two vertex words of every entry (the whole tile array is 67 MB per 8 192 lots)
+            const size_t nw = (size_t)h->pstage.nobst[k] * 8;
+            if (nw == 0) continue;
+            uint64_t b0, b1;
+            memcpy(&b0, h->pstage.verts + k * tile_words + (k * 7) % nw, 8);
+            memcpy(&b1, h->pstage.verts + k * tile_words + nw - 1, 8);
+            c = (c ^ b0) * 0x100000001B3ull; c = (c ^ b1) * 0x100000001B3ull; c ^= c >> 29;
+        }
+        bump_pool_generation(h, c);
+    }
     (void)stream;
     return HOPE_OK;
 }
@@ -1363,7 +1514,6 @@ static int refresh_pool_lists_sync(hope_env_t* h) {
     if (!l1.empty()) HIPCHK(hipMemcpy(ps.list[1], l1.data(), l1.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
     h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
-    h->pool_generation++;
     return HOPE_OK;
 }
 
@@ -1395,7 +1545,10 @@ int hope_env_set_dlp_cases(hope_env_t* h, int n_cases, const double* dest, const
         h->dlp.dest = (const double*)h->dlp_mem[0]; h->dlp.cand_off = (const int32_t*)h->dlp_mem[1];
         h->dlp.cand = (const double*)h->dlp_mem[2]; h->dlp.case_set = (const int32_t*)h->dlp_mem[3];
         h->dlp.set_off = (const int32_t*)h->dlp_mem[4]; h->dlp.set_verts = (const double*)h->dlp_mem[5];
-    }
+        uint64_t c = 0x646c70ull;
+        for (int i = 0; i < 6; i++) c = hash_bytes(c, src[i], bytes[i]);
+        bump_pool_generation(h, c);
+    } else bump_pool_generation(h, 0x6e6f646c70ull);        // the cases were removed
     return refresh_pool_lists_sync(h);
 }
 
@@ -1584,6 +1737,33 @@ int hope_env_wait_rs(hope_env_t* h, void* stream) {
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
     return join_rs(h, (hipStream_t)stream);
+}
+
+int hope_env_last_step(hope_env_t* h, uint64_t* step) {
+    if (!h || !step) return fail(HOPE_EINVAL, "hope_env_last_step: null argument");
+    *step = h->step_seq;
+    return HOPE_OK;
+}
+
+int hope_env_wait_rs_step(hope_env_t* h, uint64_t step, void* stream) {
+    if (!h) return fail(HOPE_EINVAL, "hope_env_wait_rs_step: null handle");
+    if (step == 0 || step > h->step_seq) return fail(HOPE_EINVAL, "hope_env_wait_rs_step: no such step (hope_env_last_step)");
+    if (step != h->step_seq)
+        return fail(HOPE_ESTATE, "hope_env_wait_rs_step: step " + std::to_string(step) + " is not the last one (" + std::to_string(h->step_seq) +
+                                 "): a later hope_env_step / hope_env_reset_obs has replaced its Reeds-Shepp outputs -- wait before enqueuing the next step");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    return join_rs(h, (hipStream_t)stream);
+}
+
+int hope_env_download_n_obst(hope_env_t* h, int32_t* n_obst) {
+    { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
+    if (!h || !n_obst) return fail(HOPE_EINVAL, "hope_env_download_n_obst: null argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(n_obst, h->n_obst, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HOPE_OK;
 }
 
 int hope_env_reset_obs(hope_env_t* h, const uint8_t* active, uint32_t stages, const hope_step_out* out, void* stream) {

@@ -15,6 +15,15 @@ struct RsWord {
     double pad;
 };
 constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generate_path
+// A Reeds-Shepp queue entry (rs_list, written by k_rs_compact): scene << 8 | obstacle count -- the validation kernel requests the
+// scene's obstacle view with the record's header instead of behind it (n_obst <= 255: the 160 KiB LDS tile bounds max_obstacles far
+// below; < 2^24 scenes per handle).  The scene sits in the HIGH bits and comes out by a shift on purpose: with `entry & 0xFFFFFF`
+// the AMDGPU backend (ROCm 7.2) selected a 24-bit multiply for the `scene * SC_WORDS` address, dropped the mask as redundant for
+// it, and then widened the multiply back to v_mad_u64_u32 on the UNMASKED register -- k_rs_words faulted on the first packed entry.
+constexpr int RS_LIST_MAX_SCENES = 1 << 24;
+__host__ __device__ inline int rs_list_pack(int scene, int n_obst) { return (int)(((unsigned)scene << 8) | (unsigned)n_obst); }
+__host__ __device__ inline int rs_list_scene(int entry) { return (int)((unsigned)entry >> 8); }
+__host__ __device__ inline int rs_list_n_obst(int entry) { return (int)((unsigned)entry & 0xFFu); }
 // Per-search record (float64 words):
 //   [0] int2 (scene, n_obst)   [1] int2 (kept words, words the stop rule :443 lets find_rs_path test)
 //   [2..4] pose x, y, heading  [5..8] map box xmin, xmax, ymin, ymax   [9] unused

@@ -68,7 +68,14 @@ HM_FN void hm_sincos(double x, double* s, double* c) {
     double r = fma(-kd, 1.5707963267341256, ax);
     r = fma(-kd, 6.077100506303966e-11, r);
     r = fma(-kd, 2.0222662487959506e-21, r);
-    const int q = (int)kd & 3;                        /* (|kd| < 2^31: one conversion instruction on the GPU instead of the 64-bit sequence) */
+    /* quadrant: one 32-bit conversion instruction on the GPU (v_cvt_i32_f64 SATURATES: kd >= 2^31 -> INT_MAX, NaN -> 0).  On the host
+     * an out-of-range conversion is undefined behaviour (x86 gives INT_MIN), so the host spells the GPU's saturation out: both sides
+     * return the same bits for EVERY input, also beyond the reduction's accurate range (|x| < 2^20 pi/2; the env's angles are < 1e3) */
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int q = (int)kd & 3;
+#else
+    const int q = (kd != kd ? 0 : (kd >= 2147483647.0 ? 2147483647 : (int)kd)) & 3;
+#endif
     const double ks = hm_ksin(r), kc = hm_kcos(r);
     double ss = (q & 1) ? kc : ks;
     double cc = (q & 1) ? ks : kc;

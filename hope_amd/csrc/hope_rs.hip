@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     const int qi = blockIdx.x * RSA_SCENES + ls;
     // the queue entry is requested BEFORE the queue length is known (one memory round trip less): entries at or beyond the count
     // are stale or zero (hope_env_create clears the list) -- valid scene numbers either way, and lanes without work store nothing
-    const int scene = p.rs_list[qi < p.max_queue ? qi : p.max_queue - 1];
+    const int scene = rs_list_scene(p.rs_list[qi < p.max_queue ? qi : p.max_queue - 1]);      // (entry = scene << 8 | n_obst, k_rs_compact)
     const int count = *p.rs_count;
     if ((int)blockIdx.x * RSA_SCENES >= count) return;
     const bool live = qi < count;
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     // the queue entry is requested BEFORE the queue length is known (see k_rs_words): a memory round trip less
     const int qi = blockIdx.x * 8 + ls;
     const int qs = qi < p.max_queue ? qi : p.max_queue - 1;
-    const int scene = p.rs_list[qs];
+    const int entry = p.rs_list[qs];
+    const int scene = rs_list_scene(entry);
     double* rec = p.rs_rec + (size_t)(p.slot_base + p.slot_dir * qs) * RS_REC_DOUBLES;
     const int count = *p.rs_count;
     if ((int)blockIdx.x * 8 >= count) return;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     int hdr_n = 0;
     if (k0 < 3) hdr = st[k0];
     else if (k0 < 7) hdr = sc[SC_BBOX + k0 - 3];
-    else hdr_n = p.n_obst[scene];
+    else hdr_n = rs_list_n_obst(entry);      // the obstacle count k_rs_compact read
     // the kept candidates of the search as a bit mask (bit c = candidate slot c): eight lanes x six keys, one ballot per stride
     unsigned long long keptm = 0;
 #pragma unroll
@@ -1095,6 +1096,141 @@ __device__ __forceinline__ bool screen_obstacle_hit(const float4 v01, const floa
     return hit;
 }
 
+// the screen pass itself (shared by k_rs_screen and the one-kernel form of k_rs_validate_f): the obstacle view (fv / fbox / eflag) and
+// the first four segment tables (qpd[0 .. 200)) are in LDS; returns the mask of condemned words (bit k: the k-th popped word)
+template <bool TIMING>
+__device__ __forceinline__ unsigned long long screen_words(int lane, int n_paths, int n_obst, const double* tables, double* qpd, int* pq, int* cand,
+                                                           const float2* fv, const float4* fbox, const unsigned char* eflag, float fxmax,
+                                                           float fymax, unsigned long long* tsec) {
+    const float fxmin = 0.0f, fymin = 0.0f;
+    const double step = RS_STEP * MAXC;
+    unsigned long long condemned = 0;
+    RS_T0();
+    const double inv_step = 1.0 / step;
+    for (int w0 = 0; w0 < n_paths; w0 += 4) {
+        const int nw = min(4, n_paths - w0);
+        // the chunk's segment tables: into the sample queue's LDS words (not in use yet)
+        if (w0 > 0)                                        // (the first chunk's were requested in the prologue)
+            for (int t = lane; t < RS_SEG_TABLE * nw; t += WAVE) qpd[t] = tables[RS_SEG_TABLE * w0 + t];
+        lsync();
+        RS_T(14);
+        const int G = nw == 1 ? 64 : (nw == 2 ? 32 : (nw == 3 ? 21 : 16));         // lanes per word
+        const int stride = SCREEN_SPAN / G;                                           // 2, 4, 6, 8 samples between two lanes
+        const int wl_ = nw == 1 ? 0 : (nw == 2 ? lane >> 5 : (nw == 3 ? (lane >= 42 ? 2 : (lane >= 21 ? 1 : 0)) : lane >> 4));
+        const int kk = lane - wl_ * G;
+        const double* T = qpd + RS_SEG_TABLE * wl_;
+        const double w7s = T[7];
+        const int codew = __double2loint(w7s), nsegw = __double2hiint(w7s);
+        // closed-form sample: the lattice point of the segment that holds arc position a, at or behind it
+        const double a = (double)((kk + 1) * stride) * step;
+        double c = 0.0, u0 = step, r = 0.0, lprev = 0.0, pdv = 0.0;
+        int si = -1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            if (i < nsegw) {
+                const double l = T[RS_SEGW * i + 6], al = fabs(l);
+                if (i >= 1) u0 = (lprev * l > 0) ? r : -r;
+                if (si < 0 && a < c + al) {
+                    double j = ceil((a - c - u0) * inv_step);
+                    j = j < 0.0 ? 0.0 : j;
+                    const double u = u0 + j * step;
+                    si = (u > SCREEN_EPS && u < al - SCREEN_EPS) ? i : 5;           // 5: no usable sample for this lane
+                    pdv = l > 0.0 ? u : -u;
+                }
+                const double n = fabs(u0) > al ? 0.0 : floor((al - u0) * inv_step) + 1.0;
+                r = u0 + n * step - al;
+                c += al;
+                lprev = l;
+            }
+        }
+        const bool active = lane < G * nw && si >= 0 && si < 5;
+        float X = 0, Y = 0, hc = 1, hs = 0;
+        if (active) {                                      // the pose, as in the main pass below
+            const float lf = (float)pdv;
+            const float4 row = ((const float4*)(T + RS_SEG_F32))[si];
+            const int m = type_of(codew, si);
+            const float rev = lf * 0.15915494309189535f;
+            const float sl = m == TS ? 0.0f : __builtin_amdgcn_sinf(rev), cl = m == TS ? 1.0f : __builtin_amdgcn_cosf(rev);
+            const float sgn = m == TR ? -1.0f : 1.0f;
+            const float ldx = m == TS ? lf * F_INV_MAXC : sl * F_INV_MAXC;
+            const float ldy = sgn * (1.0f - cl) * F_INV_MAXC;
+            X = row.x + (row.z * ldx - row.w * ldy);
+            Y = row.y + (row.w * ldx + row.z * ldy);
+            const float ss = sgn * sl;
+            hc = row.z * cl - row.w * ss;
+            hs = row.w * cl + row.z * ss;
+        }
+        const bool oob = active && (X < fxmin - FEPS || X > fxmax + FEPS || Y < fymin - FEPS || Y > fymax + FEPS);
+        const float cx = X + hc * F_MID, cy = Y + hs * F_MID;
+        const float ex = fabsf(hc) * F_HL + fabsf(hs) * F_HW + FEPS, ey = fabsf(hs) * F_HL + fabsf(hc) * F_HW + FEPS;
+        const float lox = cx - ex, hix = cx + ex, loy = cy - ey, hiy = cy + ey;
+        const float ulox = wave_min_f(active ? lox : INFINITY), uhix = wave_max_f(active ? hix : -INFINITY);
+        const float uloy = wave_min_f(active ? loy : INFINITY), uhiy = wave_max_f(active ? hiy : -INFINITY);
+        int nc = 0;
+        for (int base = 0; base < n_obst; base += WAVE) {
+            const int o = base + lane;
+            bool near = false;
+            if (o < n_obst) {
+                const float4 bb = fbox[o];
+                near = !(bb.x > uhix || bb.y < ulox || bb.z > uhiy || bb.w < uloy);
+            }
+            const unsigned long long mm = __ballot(near);
+            if (near) cand[nc + __popcll(mm & ((1ull << lane) - 1))] = o;
+            nc += __popcll(mm);
+        }
+        RS_T(15);
+        const int all_w = (1 << nw) - 1;
+        int dead = 0;                                      // bit w: word w0 + w has a certain hit
+        for (int w = 0; w < nw; w++) dead |= __ballot(oob && wl_ == w) ? (1 << w) : 0;
+        // The obstacles near the union of the samples' hulls are few for any ONE sample but many for the wave (four words leave
+        // the start pose in different directions): a loop over the candidates with one sample per lane kept 60 of 64 lanes idle
+        // per obstacle (28 k cycles per search in the first version).  So the (sample, obstacle) pairs whose boxes meet are
+        // queued and classified 64 pairs at a time, every lane busy; the sample's pose travels by ds_bpermute.
+        auto classify = [&](int count) {                   // pairs pq[0 .. count), count <= 64
+            const bool has = lane < count;
+            const int pr = has ? pq[lane] : 0;
+            const int sl_ = pr & 63, ro = pr >> 6;
+            const float scx = __shfl(cx, sl_), scy = __shfl(cy, sl_), shc = __shfl(hc, sl_), shs = __shfl(hs, sl_);
+            const int sw = __shfl(wl_, sl_);
+            bool h = false;
+            if (has && !((dead >> sw) & 1)) {
+                const float4 v01 = ((const float4*)fv)[2 * ro], v23 = ((const float4*)fv)[2 * ro + 1];
+                h = screen_obstacle_hit(v01, v23, scx, scy, shc, shs, (int)eflag[ro], fminf(fabsf(shc), fabsf(shs)) >= FETA_HULL);
+            }
+            for (int w = 0; w < nw; w++) dead |= __ballot(h && sw == w) ? (1 << w) : 0;
+        };
+        if (nc > 0 && dead != all_w) {
+            lsync();
+            int npq = 0;
+            for (int ci = 0; ci < nc; ci++) {
+                const int ro = cand[ci];
+                const float4 bb = fbox[ro];
+                const bool near = active && !oob && !((dead >> wl_) & 1) && !(bb.x > hix || bb.y < lox || bb.z > hiy || bb.w < loy);
+                const unsigned long long nm = __ballot(near);
+                if (!nm) continue;
+                if (near) pq[npq + __popcll(nm & ((1ull << lane) - 1))] = (ro << 6) | lane;
+                npq += __popcll(nm);
+                if (npq >= WAVE) {
+                    lsync();
+                    classify(WAVE);
+                    if (dead == all_w) { npq = 0; break; }     // every word of the chunk is condemned
+                    const int rem = npq - WAVE;               // carry the tail to the front of the queue
+                    int cv = 0;
+                    if (lane < rem) cv = pq[WAVE + lane];
+                    lsync();
+                    if (lane < rem) pq[lane] = cv;
+                    npq = rem;
+                }
+            }
+            if (npq > 0 && dead != all_w) { lsync(); classify(npq); }
+        }
+        condemned |= (unsigned long long)dead << w0;
+        lsync();                                           // the next chunk's tables / the first word's queue overwrite these words
+        RS_T(7);
+    }
+    return condemned;
+}
+
 template <int OCC, bool TIMING, bool STATS>
 __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1107,10 +1243,26 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     const unsigned long long tstart_ = TIMING ? __builtin_readcyclecounter() : 0;
     RS_T0();
     const int b_ = (int)blockIdx.x;
+    // Two memory round trips in front of the first sample instead of three (round 5): the block -> queue entry map does not depend on
+    // the queue length (a bijection of the launch's max_queue blocks; the length only decides who leaves), and the queue entry itself
+    // carries the scene AND its obstacle count (k_rs_compact), so that the record's header, the segment tables and the obstacle view
+    // are all requested at once -- the header used to be a round trip of its own in front of the tile.
+#ifdef HOPE_RS_3TRIPS                                      // (A/B build: the round-4 order -- queue length, then header, then tile)
     const int count = *p.rs_count;
     if (b_ >= count) return;
     const int qidx = scene_of_block(b_, count);
+    const int entry = p.rs_list[qidx];
+#else
+    const int qidx = scene_of_block(b_, p.max_queue);
+    const int entry = p.rs_list[qidx];                   // (entries beyond the queue length are stale or zero: valid scenes, and we leave)
+    const int count = *p.rs_count;
+    if (qidx >= count) return;
+#endif
     const int slot = p.slot_base + p.slot_dir * qidx;
+#ifndef HOPE_RS_HDR
+    const int scene = rs_list_scene(entry);
+    const int n_obst = rs_list_n_obst(entry);
+#endif
     // LDS: float2 V[4 cap] | float4 box[cap] | float64 tile 8 cap + world boxes float4[cap] (filled when the first pass needs the
     //      float64 arithmetic) | scratch doubles: segment table 50, sample queue pd[256], bad1[8] | int cand[cap] | bytes: qseg[256],
     //      edge flags[cap]
@@ -1128,19 +1280,23 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     const double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
     const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
     const double* tables = rec + RS_REC_SEGS;
-    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
-    const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);
-    if (n_paths == 0) return;
+#ifdef HOPE_RS_3TRIPS
+    if (__builtin_amdgcn_readlane(__double2hiint(r0), 1) == 0) return;        // (waits for the header, as round 4 did)
+#endif
+#ifdef HOPE_RS_HDR                                         // (bisecting build: scene / obstacle count from the record's header)
     const int scene = __builtin_amdgcn_readlane(__double2loint(r0), 0);
     const int n_obst = __builtin_amdgcn_readlane(__double2hiint(r0), 0);
-    const double* verts_g = p.verts + (size_t)scene * p.max_obst * 8;
-    {   // first-segment samples into LDS (ordinary loads: requested with the record's header, they arrive together)
-        const double T0 = g_rs_steps[lane], T1 = g_rs_steps[WAVE + lane], T2 = g_rs_steps[2 * WAVE + lane], T3 = g_rs_steps[3 * WAVE + lane];
-        tabl[lane] = T0; tabl[WAVE + lane] = T1; tabl[2 * WAVE + lane] = T2; tabl[3 * WAVE + lane] = T3;
+    (void)entry;
+#endif
+    // the segment tables of the first FOUR words lie back to back behind the header (200 doubles; a record has room for 48 tables, so
+    // the request never leaves it): all of them now, for the screen pass ...
+    double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
+    {   // ... straight into the sample queue's LDS words (global_load_lds, 16 bytes per lane: no registers, nobody waits here)
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const double2* t2 = (const double2*)tables;
+        __builtin_amdgcn_global_load_lds((const void*)(t2 + lane), (lds_ptr)qpd, 16, 0, 0);
+        if (lane < 2 * RS_SEG_TABLE - WAVE) __builtin_amdgcn_global_load_lds((const void*)(t2 + WAVE + lane), (lds_ptr)(qpd + 2 * WAVE), 16, 0, 0);
     }
-    // map box in the frame of the scene's float32 obstacle view (origin = its lower left corner): the rear axle must stay inside (:462-464)
-    const float fxmin = 0.0f, fxmax = (float)(readlane_d(r0, 6) - readlane_d(r0, 5)), fymin = 0.0f, fymax = (float)(readlane_d(r0, 8) - readlane_d(r0, 7));
-    const double step = RS_STEP * MAXC;
     // The float32 view of the obstacles -- vertices in that frame, their boxes, the edges' robustness flags -- was made when the
     // scene got its map (obstacle_f32, hope_dev.h).  It goes from global memory STRAIGHT INTO LDS (global_load_lds: no staging
     // registers, and the wave does not wait): the first word's setup and its first samples are generated while the tile is in
@@ -1159,6 +1315,16 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
         for (int base = 0; 4 * base < n_obst; base += WAVE)
             if (4 * (base + lane) < n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfl + base + lane), (lds_ptr)((uint32_t*)eflag + base), 4, 0, 0);
     }
+    // (everything that READS the header comes behind the requests above: a use of r0 makes the wave wait for it)
+    const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);      // words the stop rule lets the search test
+    if (n_paths == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a wave must not end with loads into its LDS in flight)
+        return;
+    }
+    const double* verts_g = p.verts + (size_t)scene * p.max_obst * 8;
+    // map box in the frame of the scene's float32 obstacle view (origin = its lower left corner): the rear axle must stay inside (:462-464)
+    const float fxmin = 0.0f, fxmax = (float)(readlane_d(r0, 6) - readlane_d(r0, 5)), fymin = 0.0f, fymax = (float)(readlane_d(r0, 8) - readlane_d(r0, 7));
+    const double step = RS_STEP * MAXC;
     bool tile_pending = true;
     int found = -1;
     double* bad1 = scr + RSB_BAD;
@@ -1173,109 +1339,24 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     if (!(obs_f64 & 0x20000)) {                            // (HOPE_RS_DEBUG=0x20000: no screen -- A/B and the parity tests)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the obstacle view's global_load_lds have landed
         tile_pending = false;
-        const double inv_step = 1.0 / step;
-        for (int w0 = 0; w0 < n_paths; w0 += 4) {
-            const int nw = min(4, n_paths - w0);
-            // the chunk's segment tables lie back to back in the record: into the sample queue's LDS words (not in use yet)
-            for (int t = lane; t < RS_SEG_TABLE * nw; t += WAVE) qpd[t] = tables[RS_SEG_TABLE * w0 + t];
-            lsync();
-            const int G = nw == 1 ? 64 : (nw == 2 ? 32 : (nw == 3 ? 21 : 16));         // lanes per word
-            const int stride = SCREEN_SPAN / G;                                           // 2, 4, 6, 8 samples between two lanes
-            const int wl_ = nw == 1 ? 0 : (nw == 2 ? lane >> 5 : (nw == 3 ? (lane >= 42 ? 2 : (lane >= 21 ? 1 : 0)) : lane >> 4));
-            const int kk = lane - wl_ * G;
-            const double* T = qpd + RS_SEG_TABLE * wl_;
-            const double w7s = T[7];
-            const int codew = __double2loint(w7s), nsegw = __double2hiint(w7s);
-            // closed-form sample: the lattice point of the segment that holds arc position a, at or behind it
-            const double a = (double)((kk + 1) * stride) * step;
-            double c = 0.0, u0 = step, r = 0.0, lprev = 0.0, pdv = 0.0;
-            int si = -1;
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (i < nsegw) {
-                    const double l = T[RS_SEGW * i + 6], al = fabs(l);
-                    if (i >= 1) u0 = (lprev * l > 0) ? r : -r;
-                    if (si < 0 && a < c + al) {
-                        double j = ceil((a - c - u0) * inv_step);
-                        j = j < 0.0 ? 0.0 : j;
-                        const double u = u0 + j * step;
-                        si = (u > SCREEN_EPS && u < al - SCREEN_EPS) ? i : 5;           // 5: no usable sample for this lane
-                        pdv = l > 0.0 ? u : -u;
-                    }
-                    const double n = fabs(u0) > al ? 0.0 : floor((al - u0) * inv_step) + 1.0;
-                    r = u0 + n * step - al;
-                    c += al;
-                    lprev = l;
-                }
-            }
-            const bool active = lane < G * nw && si >= 0 && si < 5;
-            float X = 0, Y = 0, hc = 1, hs = 0;
-            if (active) {                                      // the pose, as in the main pass below
-                const float lf = (float)pdv;
-                const float4 row = ((const float4*)(T + RS_SEG_F32))[si];
-                const int m = type_of(codew, si);
-                const float rev = lf * 0.15915494309189535f;
-                const float sl = m == TS ? 0.0f : __builtin_amdgcn_sinf(rev), cl = m == TS ? 1.0f : __builtin_amdgcn_cosf(rev);
-                const float sgn = m == TR ? -1.0f : 1.0f;
-                const float ldx = m == TS ? lf * F_INV_MAXC : sl * F_INV_MAXC;
-                const float ldy = sgn * (1.0f - cl) * F_INV_MAXC;
-                X = row.x + (row.z * ldx - row.w * ldy);
-                Y = row.y + (row.w * ldx + row.z * ldy);
-                const float ss = sgn * sl;
-                hc = row.z * cl - row.w * ss;
-                hs = row.w * cl + row.z * ss;
-            }
-            bool hit = active && (X < fxmin - FEPS || X > fxmax + FEPS || Y < fymin - FEPS || Y > fymax + FEPS);
-            const float cx = X + hc * F_MID, cy = Y + hs * F_MID;
-            const float ex = fabsf(hc) * F_HL + fabsf(hs) * F_HW + FEPS, ey = fabsf(hs) * F_HL + fabsf(hc) * F_HW + FEPS;
-            const float lox = cx - ex, hix = cx + ex, loy = cy - ey, hiy = cy + ey;
-            const float ulox = wave_min_f(active ? lox : INFINITY), uhix = wave_max_f(active ? hix : -INFINITY);
-            const float uloy = wave_min_f(active ? loy : INFINITY), uhiy = wave_max_f(active ? hiy : -INFINITY);
-            int nc = 0;
-            for (int base = 0; base < n_obst; base += WAVE) {
-                const int o = base + lane;
-                bool near = false;
-                if (o < n_obst) {
-                    const float4 bb = fbox[o];
-                    near = !(bb.x > uhix || bb.y < ulox || bb.z > uhiy || bb.w < uloy);
-                }
-                const unsigned long long mm = __ballot(near);
-                if (near) cand[nc + __popcll(mm & ((1ull << lane) - 1))] = o;
-                nc += __popcll(mm);
-            }
-            const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1);
-            const int all_w = (1 << nw) - 1;
-            int dead = 0;
-            if (nc > 0) {
-                lsync();
-                const bool hull_ok = fminf(fabsf(hc), fabsf(hs)) >= FETA_HULL;
-                for (int ci = 0; ci < nc; ci++) {
-                    const int ro = cand[ci];
-                    const float4 bb = fbox[ro];
-                    const bool near = active && !hit && !(bb.x > hix || bb.y < lox || bb.z > hiy || bb.w < loy);
-                    if (!__any(near)) continue;
-                    const float4 v01 = ((const float4*)fv)[2 * ro], v23 = ((const float4*)fv)[2 * ro + 1];
-                    const int efl = (int)eflag[ro];
-                    if (near) hit = screen_obstacle_hit(v01, v23, cx, cy, hc, hs, efl, hull_ok);
-                    const unsigned long long hm = __ballot(hit);
-                    dead = 0;
-                    for (int w = 0; w < nw; w++) dead |= ((hm >> (w * G)) & gmask) ? (1 << w) : 0;
-                    if (dead == all_w) break;                  // every word of the chunk is condemned
-                }
-            }
-            {
-                const unsigned long long hm = __ballot(hit);   // (out-of-box hits too)
-                dead = 0;
-                for (int w = 0; w < nw; w++) dead |= ((hm >> (w * G)) & gmask) ? (1 << w) : 0;
-            }
-            condemned |= (unsigned long long)dead << w0;
-            lsync();                                           // the next chunk's tables / the first word's queue overwrite these words
-        }
+        condemned = screen_words<TIMING>(lane, n_paths, n_obst, tables, qpd, (int*)tabl /* pair queue: the sample table is loaded behind the screen */,
+                                         cand, fv, fbox, eflag, fxmax, fymax, tsec);
+        if (TIMING) t0_ = __builtin_readcyclecounter();
+    }
+    else {                                                 // (no screen: the tables' loads must have landed before the queue's words are used)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tile_pending = false;
     }
     const bool verify_screen = STATS && paranoid;          // self-check build: condemned words are walked anyway and must come out invalid
     const bool all_condemned = condemned == ((1ull << n_paths) - 1);
     unsigned long long st_scr_words = __popcll(condemned), st_scr_dead = all_condemned ? 1 : 0, st_scr_bad = 0;
-    RS_T(7);
+    if (!all_condemned || verify_screen) {
+        // first-segment samples into LDS, for the words that are walked (it was part of the prologue; four searches out of five
+        // now end at the screen and never need it)
+        const double T0 = g_rs_steps[lane], T1 = g_rs_steps[WAVE + lane], T2 = g_rs_steps[2 * WAVE + lane], T3 = g_rs_steps[3 * WAVE + lane];
+        tabl[lane] = T0; tabl[WAVE + lane] = T1; tabl[2 * WAVE + lane] = T2; tabl[3 * WAVE + lane] = T3;
+        lsync();
+    }
     for (int idx = 1; idx <= n_paths; idx++) {
         if (all_condemned && !verify_screen) break;        // nothing left to walk: no path
         const double tcur = tb;
@@ -1696,13 +1777,17 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     }
     if (!exact) { hipError_t e = rs_init_tables(); if (e != hipSuccess) return e; }
     // grid = number of scenes in this tile class (upper bound of the queue length, which lives on the device)
+    const int stop_after = getenv("HOPE_RS_STOP") ? atoi(getenv("HOPE_RS_STOP")) : 0;   // (debugging: 1 = no RS kernel, 2 = words only, 3 = words + segs; results invalid)
+    if (stop_after == 1) return hipSuccess;
     if (timer) timer->begin(HOPE_K_RS_WORDS, stream);
     hipLaunchKernelGGL(k_rs_words, dim3((p.max_queue + RSA_SCENES - 1) / RSA_SCENES, RSA_GROUPS), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
+    if (stop_after == 2) return hipGetLastError();
     if (timer) timer->begin(HOPE_K_RS_SEGS, stream);
     hipLaunchKernelGGL(k_rs_segs, dim3((p.max_queue + 7) / 8), dim3(WAVE), 0, stream, p);
     if (timer) timer->end(stream);
     if (after_segs) { hipError_t e = hipEventRecord(after_segs, stream); if (e != hipSuccess) return e; }   // (pipelined steps: the next motion launch waits here)
+    if (stop_after == 3) return hipGetLastError();
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
     static const bool no_prio = getenv("HOPE_RS_PRIO") && atoi(getenv("HOPE_RS_PRIO")) == 0;
     // only for the launch of the class with more scenes, i.e. the longer chain (both launches: 0.657 ms / steady 0.688; only the

@@ -272,8 +272,11 @@ class WorkerPool {
     uint64_t generation_ = 0;
     int want_ = 0, claimed_ = 0, pending_ = 0;
 
-    void loop() {
+    std::vector<int> cpus_;                // the CPUs of the process's affinity mask when the current job was posted
+
+    void loop(int index) {
         uint64_t seen = 0;
+        int my_cpu = -1;
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             cv_work_.wait(lk, [&] { return generation_ != seen; });
@@ -281,7 +284,18 @@ class WorkerPool {
             if (claimed_ >= want_) continue;                // more workers than this job wants
             claimed_++;
             const std::function<void()>* job = job_;
+            // Worker i sits on the i-th CPU of the mask, the caller's current CPU left out.  Without this a woken worker
+            // is queued on the CPU that woke it -- the caller's, which is busy with the job -- and waits for the periodic load
+            // balancer: measured here, a 27 ms job on 2 .. 8 sleeping workers finished in 27 ms.  Re-pinned when the mask changed
+            // (hope_amd.dist.pin_rank_to_cores runs after the first pool use in a multi-rank process).
+            const int cpu = cpus_.empty() ? -1 : cpus_[(size_t)index % cpus_.size()];
             lk.unlock();
+            if (cpu >= 0 && cpu != my_cpu) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpu, &one);
+                if (sched_setaffinity(0, sizeof(one), &one) == 0) my_cpu = cpu;
+            }
             (*job)();
             lk.lock();
             if (--pending_ == 0) cv_done_.notify_all();
@@ -295,8 +309,15 @@ public:
         const int helpers = std::max(0, n_threads - 1);
         {
             std::unique_lock<std::mutex> lk(m_);
+            cpus_.clear();
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            const int here = sched_getcpu();                 // not the CPU the caller runs on: a pinned worker there would hold up the
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) //   thread that posted the job (often the one that enqueues the env steps)
+                for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &set) && c != here) cpus_.push_back(c);
             while ((int)workers_.size() < helpers) {
-                workers_.emplace_back([this] { loop(); });
+                const int index = (int)workers_.size();
+                workers_.emplace_back([this, index] { loop(index); });
                 workers_.back().detach();                   // (process-lifetime threads: nothing to join at exit)
             }
             job_ = &fn; want_ = helpers; claimed_ = 0; pending_ = helpers;
@@ -338,9 +359,14 @@ int hope_scenegen_generate(int level, int bay_mode, int n, uint64_t seed, int64_
                            double* dest, double* bbox, double* verts, int32_t* n_obst, int32_t* case_id, int n_threads) {
     if (level_index(level) < 0 || n < 0 || max_obstacles <= 0 || !start || !dest || !bbox || !verts || !n_obst) return HOPE_EINVAL;
     if (n == 0) return HOPE_OK;
-    int nt = n_threads > 0 ? n_threads : default_threads();
-    // chunks of 8 .. 32 lots handed out from one counter: at least ~8 chunks per thread, so that the rejection samplers' uneven
-    // cost per lot evens out, and no more threads than chunks
+    // Fan-out: at most the CPUs of the affinity mask, at most 64 unless asked for (n_threads > 0 / HOPE_HOST_THREADS), and at least
+    // 64 lots per thread -- measured on the 256-CPU host of an MI355X box (profiles/r05_host_generator_threads.txt, a pool refill =
+    // 3 calls of 2 730 lots): 1 thread 0.61 M lots/s, 8: 4.3 M, 32: 9.6 M, 64: 8.0 M, 128: 5.4 M, 256: 0.3 M (waking and pinning 255
+    // sleepers costs more than the 3 us a lot takes).
+    int nt = n_threads > 0 ? n_threads : std::min(default_threads(), getenv("HOPE_HOST_THREADS") ? (1 << 20) : 64);
+    nt = std::max(1, std::min(nt, n / 64));
+    // chunks of 8 .. 32 lots handed out from one counter: ~8 chunks per thread, so that the rejection samplers' uneven cost per lot
+    // evens out
     const int chunk = std::max(8, std::min(32, n / std::max(1, 8 * nt)));
     nt = std::max(1, std::min(nt, (n + chunk - 1) / chunk));
     std::atomic<int> next{0}, err{0};

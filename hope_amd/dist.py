@@ -87,10 +87,11 @@ def allreduce_stats(reset=False):
         b.synchronize()
         _AR['ms'] += a.elapsed_time(b)
     _AR['events'].clear()
-    out = {'calls': _AR['calls'], 'bytes': _AR['bytes'], 'ms': _AR['ms'],
-           'ms_per_call': _AR['ms'] / _AR['calls'] if _AR['calls'] else None, 'bytes_per_call': _AR['bytes'] / _AR['calls'] if _AR['calls'] else None}
+    timed = _AR.get('timed_calls', 0)
+    out = {'calls': _AR['calls'], 'timed_calls': timed, 'bytes': _AR['bytes'], 'ms': _AR['ms'],
+           'ms_per_call': _AR['ms'] / timed if timed else None, 'bytes_per_call': _AR['bytes'] / _AR['calls'] if _AR['calls'] else None}
     if reset:
-        _AR.update(calls=0, bytes=0, ms=0.0)
+        _AR.update(calls=0, timed_calls=0, bytes=0, ms=0.0)
     return out
 
 
@@ -108,6 +109,7 @@ def allreduce_gradients(params, average=True, group=None):
     if ev is not None:
         ev[1].record()
         _AR['events'].append(ev)
+        _AR['timed_calls'] = _AR.get('timed_calls', 0) + 1          # (ms_per_call divides by THIS count: untimed calls beyond the cap are not in the ms)
     _AR['calls'] += 1
     _AR['bytes'] += flat.numel() * flat.element_size()
     if average:

@@ -57,7 +57,9 @@ class PoolRefresher:
     thread that owns the env, e.g. once per policy update -- commits a finished batch (asynchronous upload + swap,
     hope_env_commit_pool) and starts the next one.  Every batch is new: batch b of the run uses first_index = b * n_pool."""
 
-    def __init__(self, env, n_pool, levels=('Normal', 'Complex', 'Extrem'), seed=0, threads=0):
+    def __init__(self, env, n_pool, levels=('Normal', 'Complex', 'Extrem'), seed=0, threads=8):
+        # threads: 8 workers of the native generator's pool refill 8 192 lots in ~2 ms (4 M lots/s, profiles/r05_host_generator_threads.txt),
+        # a hundred times what 65 536 scenes consume; more would only compete with the thread that enqueues the steps.  0 = all CPUs
         self.env, self.n, self.levels, self.seed, self.threads = env, int(n_pool), tuple(levels), int(seed), int(threads)
         self.batch = 0
         self.thread = None

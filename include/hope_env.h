@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HOPE_ABI_VERSION 7
+#define HOPE_ABI_VERSION 8
 
 #define HOPE_LIDAR_NUM 120   /* configs.py:96  */
 #define HOPE_N_ACTION 42     /* configs.py:108-115 */
@@ -188,9 +188,17 @@ int hope_env_set_scenes(hope_env_t *h, const int32_t *scene_ids, int n, const do
 int hope_env_step(hope_env_t *h, const void *actions, const uint8_t *active, uint32_t stages,
                   const hope_step_out *out, void *stream);
 
-/* Orders `stream` after the Reeds-Shepp outputs of the last hope_env_step that carried HOPE_DEFER_RS (no-op if none is
- * outstanding). */
+/* Orders `stream` after the Reeds-Shepp outputs of the LAST hope_env_step that carried HOPE_DEFER_RS (no-op if none is
+ * outstanding).  "Last" is literal: since ABI 7 consecutive deferred steps pipeline, and step k + 1 REPLACES step k's rs_word /
+ * rs_lengths instead of ordering them -- a hope_env_wait_rs issued after step k + 1 was enqueued joins step k + 1's search. */
 int hope_env_wait_rs(hope_env_t *h, void *stream);
+/* (ABI 8) The same wait with the caller saying WHICH step's search it means: hope_env_last_step returns the sequence number of
+ * the most recent hope_env_step / hope_env_reset_obs call of the handle (1, 2, ...); hope_env_wait_rs_step(h, step, stream)
+ * orders `stream` after that step's Reeds-Shepp outputs and fails with HOPE_ESTATE -- touching nothing -- when a newer step has
+ * been enqueued since (its outputs have been, or are being, replaced).  What a planner-in-the-loop caller should use: an
+ * accidental "step, step, wait" then fails loudly instead of handing it the other step's (or a mix of both steps') words. */
+int hope_env_last_step(hope_env_t *h, uint64_t *step);
+int hope_env_wait_rs_step(hope_env_t *h, uint64_t step, void *stream);
 
 /* The action-less step of CarParking.reset (:138) / CarParkingWrapper.step(None) (:74-75):
  * t += 1, observation, status, reward; no motion. */
@@ -225,8 +233,12 @@ int hope_env_commit_pool(hope_env_t *h, int n_pool, void *stream);
 /* 1 when hope_env_pool_staging would return without waiting (the previous commit's copies have left the pinned arrays), 0 when not
  * yet, < 0 on error: a background refresher polls this instead of blocking the thread that drives the step loop */
 int hope_env_pool_staging_ready(hope_env_t *h);
-/* A counter that changes whenever the set of maps a draw can return changes (hope_env_set_pool / hope_env_commit_pool /
- * hope_env_set_dlp_cases).  Part of a snapshot of drawn maps: hope_env_restore_maps refuses a snapshot of another generation. */
+/* An identity of the set of maps a draw can return: changes whenever that set changes (hope_env_set_pool / hope_env_commit_pool /
+ * hope_env_set_dlp_cases).  Part of a snapshot of drawn maps: hope_env_restore_maps refuses a snapshot of another generation.
+ * ABI 8: the value is a HASH CHAIN over the contents of every upload since hope_env_create (pool entries' start / dest / box /
+ * obstacle counts and a strided sample of their vertices; the Dragon-Lake case table), not a per-handle counter -- a snapshot taken
+ * in one process is refused by another process whose pool holds other maps even if both uploaded "one pool".  0 is never
+ * returned for a handle with a pool (0 = "no pool yet" / "skip the check" in hope_env_restore_maps). */
 int hope_env_pool_generation(hope_env_t *h, uint64_t *generation);
 /* seed of HOPE_AUTO_REDRAW's draws (default 0) */
 int hope_env_set_redraw_seed(hope_env_t *h, uint64_t seed);
@@ -256,6 +268,8 @@ int hope_env_pool_overflow(hope_env_t *h, int32_t *count);
  * hope_env_set_scenes; host-synchronous */
 int hope_env_download_scenes(hope_env_t *h, const int32_t *scene_ids, int n, double *start, double *dest, double *bbox, double *verts,
                              int32_t *n_obst);
+/* (ABI 8) the obstacle count of EVERY scene as it is now (device-side draws change it behind the host): one copy; host-synchronous */
+int hope_env_download_n_obst(hope_env_t *h, int32_t *n_obst /*[N]*/);
 /* Snapshot / restore of drawn maps.  A draw is a pure function of (seed, scene, episode counter) and of the pool / case lists:
  * hope_env_download_pool_state returns the pool index and the episode counter of every scene; hope_env_restore_maps (host arrays:
  * drawn[i] != 0 where the scene held a drawn map, the saved counters, the seed in use when the maps were drawn) repeats those draws
@@ -265,6 +279,18 @@ int hope_env_download_scenes(hope_env_t *h, const int32_t *scene_ids, int n, dou
  * hope_env_set_scenes).  Restore pose / t / accumulator afterwards with hope_env_upload_state.  Host-synchronous. */
 int hope_env_download_pool_state(hope_env_t *h, int32_t *pool_index /*[N]*/, uint32_t *episode /*[N]*/);
 int hope_env_restore_maps(hope_env_t *h, const uint8_t *drawn /*[N]*/, const uint32_t *episode /*[N]*/, uint64_t seed, uint64_t pool_generation);
+
+/* (ABI 8) Which of the library's streams share a HARDWARE queue.  The runtime spreads HIP streams over a few hardware queues (4 by
+ * default) in creation order, and launches of streams that share one serialise: which library stream plays which role of the step's
+ * launch structure decides 0.52 vs 0.6+ ms per 65 536-scene step.  Up to round 4 the assignment was a table found by search on one
+ * box; since round 5 hope_env_create MEASURES it (pairs of ~100 us spin kernels: two streams on one queue take twice as long; < 5 ms
+ * once, HOPE_QUEUE_CHECK=0 skips it) and assigns the roles so that the streams a deferred / joined / sub-chain step keeps busy at
+ * the same time sit on different queues, whatever other streams the process created first.  queue_of_role[r]: hardware-queue class
+ * (0, 1, ...) of role r's stream, r = 1 .. 7 ([0]: the NULL stream, the usual caller's stream); -1 = not measured.
+ * Roles: 1 search chain of the small-tile class, 2 image side, 3 / 4 observation half of the large- / small-tile class, 5 chain of
+ * the large-tile class (deferred), 6 spare, 7 second sub-chain's observation.  *n_queues = distinct classes seen; *ms = what the
+ * measurement took.  Any pointer may be NULL. */
+int hope_env_queue_check(hope_env_t *h, int32_t *queue_of_role /*[8]*/, int32_t *n_queues, double *ms);
 
 /* With HOPE_F_PROFILE every kernel launch is bracketed by its own HIP event pair on the launch stream.
  * Returns the accumulated time (ms) and launch count per kernel since the last call with reset != 0:

@@ -312,6 +312,37 @@ def test_bench_as_eight_ranks_of_8192_scenes_sharing_the_gpu():
     assert d['host']['generator_threads'] == d['host']['cpus_this_rank']
 
 
+def test_bench_gpus_n_launches_its_own_ranks():
+    """VERDICT r4 #3b: `python bench.py --gpus 2` WITHOUT a launcher (the way the driver starts `--gpus 1`) must not stop at an error
+    line: it starts its own ranks under torch.distributed.run and rank 0's JSON line passes through.  On the 1-GPU box the two ranks
+    share the GPU over gloo (HOPE_BENCH_SHARE_GPU=1).  The line also carries the round-5 fields: the background pool refresh inside
+    the timed loop, the steady-state and joined-form figures next to the driver-timed value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HOPE_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--scenes', '8192', '--steps', '24', '--warmup', '4', '--preroll', '40',
+           '--no-cpu-baseline', '--witness', '0', '--repeat-passes', '1', '--repeat-steps', '40']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split('\n') if ln.startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    print(json.dumps({k: d.get(k) for k in ('value', 'value_steady', 'value_joined', 'ms_per_step', 'n_gpus', 'ranks', 'pool_refresh')}))
+    assert d['n_gpus'] == 2 and d['ranks'] == 2 and d['rccl_check']['ok'] and d['scaling'] == 'weak'
+    assert d['config']['scenes_per_gpu'] == 8192
+    assert abs(d['value'] - 2 * 8192 * 24 / (d['ms_per_step'] * 24 * 1e-3)) < 1e-3 * d['value']
+    assert d['value_steady'] > 0 and d['value_joined'] > 0
+    assert d['pool_refresh']['refresher_commits'] > 0 and d['pool_refresh']['every_steps'] == 8
+    # without the share hook a 1-GPU node must refuse loudly instead of putting two ranks on one device
+    if torch.cuda.device_count() < 2:
+        env.pop('HOPE_BENCH_SHARE_GPU')
+        r2 = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=300)
+        assert r2.returncode != 0 and 'HIP device' in (r2.stderr + r2.stdout)
+
+
 def test_graph_captured_policy_forward_equals_the_eager_one():
     """the rollout's inference forward replayed as one captured device graph (agents.enable_fast_policy)
     is the same fp32 arithmetic -- identical means for changing inputs, recapture on a new batch shape; the bf16-autocast variant

@@ -52,7 +52,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     L = _lib.load_library()
-    assert L.hope_abi_version() == _lib.ABI_VERSION == 7
+    assert L.hope_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback():

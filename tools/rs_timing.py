@@ -49,7 +49,7 @@ def main():
     waves = max(v[8], 1)
     names = ['prologue', 'word setup', 'sample generator', 'interpolate + transform', 'pose_hits: hull / union / cull',
              'pose_hits: candidate loop']
-    extra = {7: 'screen pass (up to 4 words at once)', 14: 'bad-sample bookkeeping', 15: 'carry'}
+    extra = {14: 'screen: wait for obstacle view + tables', 15: 'screen: samples, poses, cull', 7: 'screen: (sample, obstacle) pairs'}
     tot = v[6]
     print(f'searches (waves with work) per step: {waves / args.steps:.0f};  cycles per search: {tot / waves:.0f}')
     acc = 0
