@@ -225,7 +225,7 @@ def main():
         bench_refresher = None
         if gl and args.refresh_every > 0 and args.policy == 'none':
             from hope_amd.scene_gen import PoolRefresher
-            bench_refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5)
+            bench_refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5, relaxed=True)
 
         def one_step(i, defer_=None):  # noqa: F811
             # the new map is drawn inside the step kernel (HOPE_AUTO_REDRAW = step + redraw(done) + reset_obs(active=done))
@@ -243,7 +243,7 @@ def main():
         refresher = None
         if fresh and gl:                                              # the pool of generated lots is replaced in the background
             from hope_amd.scene_gen import PoolRefresher
-            refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5)
+            refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5, relaxed=True)
         if args.algo == 'ppo':
             agent = A.BatchedPPO(device=dev, use_img=args.image, mini_batch=args.mini_batch, mini_epoch=args.mini_epoch)
             trainer = PPOTrainer(env, agent, horizon=args.horizon, seed=args.seed + rank, fresh_scenes=fresh, pool_refresher=refresher,

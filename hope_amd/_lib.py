@@ -15,12 +15,12 @@ DEFER_RS = 0x200
 STAGE_IMG = 0x40
 IMG_SIZE, IMG_CHANNELS, TRAJ_RENDER_LEN = 64, 3, 20
 AUTO_RESET = 0x20
-KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_rs_compact', 'k_post', 'k_rs_segs')
+KERNELS = ('k_kinematics', 'k_env_step', 'k_rs_words', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_rs_compact', 'k_post', 'k_rs_segs', 'k_rs_screen')
 ABI_VERSION = 8
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',
            'hope_env_set_scenes', 'hope_env_step', 'hope_env_wait_rs', 'hope_env_last_step', 'hope_env_wait_rs_step', 'hope_env_download_n_obst', 'hope_env_queue_check', 'hope_env_reset_obs', 'hope_env_download_state',
-           'hope_env_upload_state', 'hope_env_restart', 'hope_env_set_pool', 'hope_env_pool_staging', 'hope_env_commit_pool', 'hope_env_pool_staging_ready', 'hope_env_pool_generation', 'hope_env_redraw', 'hope_env_set_redraw_seed', 'hope_env_download_pool_index', 'hope_env_set_dlp_cases', 'hope_env_pool_overflow', 'hope_env_set_draw_class', 'hope_env_download_scenes', 'hope_env_download_pool_state', 'hope_env_restore_maps', 'hope_env_kernel_ms', 'hope_env_kernel_union_ms', 'hope_env_profile_kernels', 'hope_debug_math', 'hope_debug_rs_prof', 'hope_debug_rs_log', 'hope_debug_rs_filter_stats', 'hope_debug_rs_filter_dump', 'hope_debug_step_prof', 'hope_debug_census', 'hope_scenegen_generate', 'hope_scenegen_default_threads', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
+           'hope_env_upload_state', 'hope_env_restart', 'hope_env_set_pool', 'hope_env_pool_staging', 'hope_env_commit_pool', 'hope_env_commit_pool_relaxed', 'hope_env_pool_staging_ready', 'hope_env_pool_generation', 'hope_env_redraw', 'hope_env_set_redraw_seed', 'hope_env_download_pool_index', 'hope_env_set_dlp_cases', 'hope_env_pool_overflow', 'hope_env_set_draw_class', 'hope_env_download_scenes', 'hope_env_download_pool_state', 'hope_env_restore_maps', 'hope_env_kernel_ms', 'hope_env_kernel_union_ms', 'hope_env_profile_kernels', 'hope_debug_math', 'hope_debug_rs_prof', 'hope_debug_rs_log', 'hope_debug_rs_filter_stats', 'hope_debug_rs_filter_dump', 'hope_debug_step_prof', 'hope_debug_census', 'hope_scenegen_generate', 'hope_scenegen_default_threads', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
 
 
 class HopeError(RuntimeError):
@@ -77,6 +77,7 @@ def load_library():
     L.hope_env_set_pool.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hope_env_pool_staging.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 5
     L.hope_env_commit_pool.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.hope_env_commit_pool_relaxed.argtypes = [C.c_void_p, C.c_int]
     L.hope_env_redraw.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.hope_env_set_redraw_seed.argtypes = [C.c_void_p, C.c_uint64]
     L.hope_env_download_pool_index.argtypes = [C.c_void_p, C.c_void_p]

@@ -138,9 +138,14 @@ class ParkingBatch:
         L.check(self.lib.hope_env_pool_generation(self.h, C.byref(g)), 'hope_env_pool_generation')
         return int(g.value)
 
-    def commit_pool(self, n_pool):
-        """asynchronous upload of the staged pool + swap: steps enqueued afterwards draw from it (no synchronisation)"""
-        L.check(self.lib.hope_env_commit_pool(self.h, int(n_pool), self._stream()), 'hope_env_commit_pool')
+    def commit_pool(self, n_pool, relaxed=False):
+        """asynchronous upload of the staged pool + swap: steps enqueued afterwards draw from it (no host synchronisation; the next
+        step's launch waits on its stream for the upload).  relaxed=True (hope_env_commit_pool_relaxed): the swap happens at the first
+        step enqueued after the upload has completed -- no step waits at all"""
+        if relaxed:
+            L.check(self.lib.hope_env_commit_pool_relaxed(self.h, int(n_pool)), 'hope_env_commit_pool_relaxed')
+        else:
+            L.check(self.lib.hope_env_commit_pool(self.h, int(n_pool), self._stream()), 'hope_env_commit_pool')
         self.pool_size = int(n_pool)
         return self
 

@@ -67,6 +67,8 @@ struct hope_env {
     std::vector<uint8_t> slot_cls_host;          // draw / launch class of every scene slot (0: <= 32 obstacles, 1: larger lots)
     uint8_t* slot_cls = nullptr;                 // the same on the device
     double* rs_rec = nullptr;
+    int32_t* rs_surv_count = nullptr;            // [MAX_CHAINS] two-kernel validation: searches k_rs_screen left a word of, per chain
+    int2* rs_surv = nullptr;                     // [2 n] (queue index, queue entry), laid out like rs_list
     uint8_t* active_snap = nullptr; // [n] the caller's `active` mask as the motion launch saw it (read by k_rs_compact, HOPE_DEFER_RS)
     // StepCold (rarely used kernel parameters) in device memory: a ring of immutable versions, uploaded stream-ordered on change
     static constexpr int COLD_RING = 8;
@@ -111,6 +113,8 @@ struct hope_env {
     hipStream_t pool_stream = nullptr;
     hipEvent_t ev_pool_ready = nullptr, ev_pool_copied = nullptr, ev_last_step = nullptr;
     bool pool_wait_pending = false;
+    // hope_env_commit_pool_relaxed: the uploaded set takes over once ev_pool_ready has passed (apply_pending_pool)
+    struct PendingPool { bool on = false; int set = 0, n_pool = 0, cls_n[2] = {0, 0}; uint64_t content = 0; std::vector<int32_t> nobst_host; } pend;
     int32_t* pool_cls[2] = {nullptr, nullptr};   // pool entries of each tile class
     int pool_cls_n[2] = {0, 0};
     std::vector<int32_t> pool_nobst_host;        // n_obst of the pool's complete scenes (class lists are rebuilt from it)
@@ -380,9 +384,11 @@ constexpr int COMPACT_THREADS = HOPE_COMPACT_THREADS;
 template <typename OT>
 __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list, int n, uint8_t* flag, const uint8_t* active,
                                                                  int32_t* out, int32_t* rs_count, const double* post,
-                                                                 const double* scene_c, int8_t* rs_word, void* rs_lengths, const int32_t* n_obst) {
+                                                                 const double* scene_c, int8_t* rs_word, void* rs_lengths, const int32_t* n_obst,
+                                                                 int32_t* surv_count) {
     __shared__ int wsum[COMPACT_THREADS / WAVE];
     __shared__ int base;
+    if (surv_count && blockIdx.x == 0 && threadIdx.x == 0) *surv_count = 0;    // k_rs_screen's queue of this chain (same stream, behind the last walk)
     const int i = blockIdx.x * COMPACT_THREADS + threadIdx.x;
     int s = -1;
     bool gate = false;
@@ -532,6 +538,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->cls_list[0], N * sizeof(int32_t));
     ALLOC(h->cls_list[1], N * sizeof(int32_t));
     ALLOC(h->rs_rec, N * rs_rec_bytes_per_scene());
+    ALLOC(h->rs_surv_count, hope_env::MAX_CHAINS * sizeof(int32_t));
+    ALLOC(h->rs_surv, 2 * N * sizeof(int2));
     ALLOC(h->cur_pool, N * sizeof(int32_t));
     ALLOC(h->episode, N * sizeof(uint32_t));
     ALLOC(h->pool_overflow, sizeof(int32_t));
@@ -566,6 +574,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->tstep, 0, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_count, 0, 2 * hope_env::MAX_CHAINS * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_flag, 0, N));
+    HIPCHK(hipMemset(h->rs_surv_count, 0, hope_env::MAX_CHAINS * sizeof(int32_t)));
+    HIPCHK(hipMemset(h->rs_surv, 0, 2 * N * sizeof(int2)));
     HIPCHK(hipMemset(h->rs_list, 0, 2 * N * sizeof(int32_t)));      // (k_rs_words / k_rs_segs read queue entries before they know the queue length)
     HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
@@ -757,7 +767,7 @@ static int destroy_impl(hope_env_t* h) {                   // (also the clean-up
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_surv_count, h->rs_surv, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -861,6 +871,7 @@ static int upload_scenes(hope_env_t* h, const int32_t* ids, int n, const double*
                          const double* verts, const int32_t* n_obst, double* d_scene_c, double* d_state, int32_t* d_t,
                          int32_t* d_nobst, double* d_verts, float4* d_obb, double* d_traj, int32_t* d_traj_len, int32_t* d_traj_valid,
                          int32_t* d_layer_valid);
+static int apply_pending_pool(hope_env_t* h, bool wait);
 
 // The dense per-class scene lists of the launch chains and the per-slot class byte (host mirror; reset-time only).  A slot's class
 // decides which launch chain steps it (LDS tile of 32 or max_obstacles obstacles) AND which pool entries it draws at episode
@@ -1142,9 +1153,9 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         {
             const dim3 cg((p.n_list + COMPACT_THREADS - 1) / COMPACT_THREADS);
             if (of64) hipLaunchKernelGGL(k_rs_compact<double>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
-                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst);
+                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst, h->rs_surv_count + i);
             else hipLaunchKernelGGL(k_rs_compact<float>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
-                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst);
+                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst, h->rs_surv_count + i);
         }
         if (tm) tm->end(sc);
         RsParams r;
@@ -1159,6 +1170,8 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         r.fverts = h->fverts; r.fbox = h->fbox; r.eflag = h->eflag;
         r.rs_count = counter; r.rs_list = qlist;
         r.rs_rec = h->rs_rec;
+        r.surv_count = h->rs_surv_count + i;
+        r.surv_list = h->rs_surv + (size_t)c * h->n + ch.a;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
         HIPCHK(launch_rs_search(r, sc, tm, pipe ? h->ev_segs[i] : nullptr));
     }
@@ -1246,6 +1259,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     hipStream_t s = (hipStream_t)stream;
     const bool prof = h->flags & HOPE_F_PROFILE;
     h->step_seq++;
+    { int rcp = apply_pending_pool(h, false); if (rcp != HOPE_OK) return rcp; }    // a relaxed commit whose upload has finished takes over here
     if (h->pool_wait_pending) {                             // a pool committed since the last launch: its upload orders before this step
         HIPCHK(hipStreamWaitEvent(s, h->ev_pool_ready, 0));
         h->pool_wait_pending = false;
@@ -1402,11 +1416,37 @@ int hope_env_pool_staging_ready(hope_env_t* h) {
 
 int hope_env_pool_generation(hope_env_t* h, uint64_t* generation) {
     if (!h || !generation) return fail(HOPE_EINVAL, "hope_env_pool_generation: null argument");
+    { DeviceGuard guard(h->device); int rcp = apply_pending_pool(h, true); if (rcp != HOPE_OK) return rcp; }
     *generation = h->pool_generation;
     return HOPE_OK;
 }
 
-int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
+// the swap of hope_env_commit_pool_relaxed, once its upload is complete (wait: block until it is)
+static int apply_pending_pool(hope_env_t* h, bool wait) {
+    if (!h->pend.on) return HOPE_OK;
+    if (wait) HIPCHK(hipEventSynchronize(h->ev_pool_ready));
+    else {
+        const hipError_t e = hipEventQuery(h->ev_pool_ready);
+        if (e == hipErrorNotReady) return HOPE_OK;
+        if (e != hipSuccess) return fail(HOPE_EHIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    }
+    hope_env::PoolSet& ps = h->pset[h->pend.set];
+    h->pool_verts = ps.verts; h->pool_c = ps.c; h->pool_nobst = ps.nobst;
+    h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
+    h->pool_cls_n[0] = h->pend.cls_n[0]; h->pool_cls_n[1] = h->pend.cls_n[1];
+    h->pool_n = h->pend.n_pool;
+    h->pool_nobst_host.swap(h->pend.nobst_host);
+    h->pactive = h->pend.set;
+    h->pend.on = false;
+    bump_pool_generation(h, h->pend.content);
+    return HOPE_OK;
+}
+
+static int commit_pool_impl(hope_env_t* h, int n_pool, bool relaxed);
+int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) { (void)stream; return commit_pool_impl(h, n_pool, false); }
+int hope_env_commit_pool_relaxed(hope_env_t* h, int n_pool) { return commit_pool_impl(h, n_pool, true); }
+
+static int commit_pool_impl(hope_env_t* h, int n_pool, bool relaxed) {
     // (no join of an unjoined Reeds-Shepp chain here: only the motion launches read the pool, and ev_last_step covers them)
     if (!h || n_pool <= 0) return fail(HOPE_EINVAL, "hope_env_commit_pool: bad argument");
     if (n_pool > h->pstage.cap) return fail(HOPE_ESTATE, "hope_env_commit_pool: more entries than hope_env_pool_staging provided");
@@ -1417,6 +1457,7 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
     std::vector<int32_t> l0, l1;
     build_pool_lists(h, h->pstage.nobst, n_pool, l0, l1);
     if ((int)(l0.size() + l1.size()) > h->pstage.cap + 4096) return fail(HOPE_EINVAL, "hope_env_commit_pool: too many Dragon-Lake cases for the list staging");
+    { int rcp = apply_pending_pool(h, true); if (rcp != HOPE_OK) return rcp; }     // (a relaxed swap still in flight: it comes first)
     const int t = h->pactive < 0 ? 0 : 1 - h->pactive;
     hope_env::PoolSet& ps = h->pset[t];
     // two commits without a hope_env_pool_staging call in between: the previous upload may still be reading the pinned arrays
@@ -1451,14 +1492,7 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
                        (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev_pool_ready, us));
-    // swap: every launch enqueued from now on reads the new set, after waiting (on its own stream) for the upload
-    h->pool_verts = ps.verts; h->pool_c = ps.c; h->pool_nobst = ps.nobst;
-    h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
-    h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
-    h->pool_n = n_pool;
-    h->pool_nobst_host.assign(h->pstage.nobst, h->pstage.nobst + n_pool);
-    h->pactive = t;
-    h->pool_wait_pending = true;
+    uint64_t content;
     {   // identity of the new pool: every scalar of every entry and two vertex words of each
         uint64_t c = hash_bytes(0x706f6f6cull, h->pstage.start, P * 24);
         c = hash_bytes(c, h->pstage.dest, P * 24);
@@ -1473,9 +1507,24 @@ int hope_env_commit_pool(hope_env_t* h, int n_pool, void* stream) {
             memcpy(&b1, h->pstage.verts + k * tile_words + nw - 1, 8);
             c = (c ^ b0) * 0x100000001B3ull; c = (c ^ b1) * 0x100000001B3ull; c ^= c >> 29;
         }
-        bump_pool_generation(h, c);
+        content = c;
     }
-    (void)stream;
+    if (relaxed && h->pactive >= 0) {
+        // the swap waits for the upload, not the steps for the swap: apply_pending_pool (launch_step / hope_env_redraw / the next commit)
+        h->pend.on = true; h->pend.set = t; h->pend.n_pool = n_pool;
+        h->pend.cls_n[0] = (int)l0.size(); h->pend.cls_n[1] = (int)l1.size(); h->pend.content = content;
+        h->pend.nobst_host.assign(h->pstage.nobst, h->pstage.nobst + n_pool);
+        return HOPE_OK;
+    }
+    // swap: every launch enqueued from now on reads the new set, after waiting (on its own stream) for the upload
+    h->pool_verts = ps.verts; h->pool_c = ps.c; h->pool_nobst = ps.nobst;
+    h->pool_cls[0] = ps.list[0]; h->pool_cls[1] = ps.list[1];
+    h->pool_cls_n[0] = (int)l0.size(); h->pool_cls_n[1] = (int)l1.size();
+    h->pool_n = n_pool;
+    h->pool_nobst_host.assign(h->pstage.nobst, h->pstage.nobst + n_pool);
+    h->pactive = t;
+    h->pool_wait_pending = true;
+    bump_pool_generation(h, content);
     return HOPE_OK;
 }
 
@@ -1620,6 +1669,7 @@ int hope_env_redraw(hope_env_t* h, const uint8_t* mask, uint64_t seed, void* str
     if (rc0 != HOPE_OK) return rc0;
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    { int rcp = apply_pending_pool(h, false); if (rcp != HOPE_OK) return rcp; }
     if (h->pool_wait_pending) { HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_pool_ready, 0)); h->pool_wait_pending = false; }
     hipLaunchKernelGGL(k_redraw, dim3(h->n), dim3(WAVE), 0, (hipStream_t)stream, h->max_obst, mask, seed, h->pool_cls[0],
                        h->pool_cls_n[0], h->pool_cls[1], h->pool_cls_n[1], h->pool_verts, h->pool_c, h->pool_nobst, h->verts,

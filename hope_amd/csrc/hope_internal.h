@@ -26,7 +26,7 @@ __host__ __device__ inline int rs_list_scene(int entry) { return (int)((unsigned
 __host__ __device__ inline int rs_list_n_obst(int entry) { return (int)((unsigned)entry & 0xFFu); }
 // Per-search record (float64 words):
 //   [0] int2 (scene, n_obst)   [1] int2 (kept words, words the stop rule :443 lets find_rs_path test)
-//   [2..4] pose x, y, heading  [5..8] map box xmin, xmax, ymin, ymax   [9] unused
+//   [2..4] pose x, y, heading  [5..8] map box xmin, xmax, ymin, ymax   [9] (two-kernel validation) mask of the words k_rs_screen condemned
 //   [10..15] the pop order: candidate slot (4 * family + reflection) of the k-th popped word, one byte each  -- k_rs_segs
 //   [16 + c]  key of candidate slot c: path.L / maxc when set_path kept the word, -1 otherwise               -- k_rs_words
 //   [64 + 8 c ..] the word of candidate slot c (RsWord)                                                       -- k_rs_words
@@ -63,6 +63,10 @@ struct RsParams {
     double* rs_rec;           // [n][RS_REC_DOUBLES] one record per queued scene (slot), see RS_REC_*
     int8_t* rs_word;          // [n][8]
     void* rs_lengths;         // real [n][5]
+    // two-kernel validation (round 5): k_rs_screen condemns words at 8 waves per SIMD and queues the searches that still have a word
+    // to walk (queue index, queue entry) for k_rs_validate_f; the counter is cleared by k_rs_compact.  Null: the one-kernel form
+    int32_t* surv_count;      // [1]
+    int2* surv_list;          // [max_queue]
 };
 
 // bird's-eye image observation (hope_bev.hip)
@@ -105,6 +109,7 @@ hipError_t rs_fstat_read(unsigned long long* out /*[16]*/, int reset);    // flo
 hipError_t rs_fdump_read(double* out /*[64][16]*/);
 hipError_t rs_log_read(int* out /*[cap][4]*/, int cap, int* n, int reset);   // HOPE_RS_TIMING per-search log
 size_t rs_lds_bytes(int max_obst);
+size_t rs_screen_lds_bytes(int max_obst);
 size_t rs_rec_bytes_per_scene();
 hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer* timer, hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr,
                             hipEvent_t ev_join = nullptr);   // side: stream for the static-layer rebuild (next to k_bev_prep), or null

@@ -1231,7 +1231,65 @@ __device__ __forceinline__ unsigned long long screen_words(int lane, int n_paths
     return condemned;
 }
 
-template <int OCC, bool TIMING, bool STATS>
+// ================================================================================================
+// Kernel B0 (round 5, HOPE_RS_SPLIT=1 only): the screen pass as a kernel of its own -- 8 waves per SIMD instead of the walk's 4
+// ================================================================================================
+// Four searches out of five end at the screen (every tested word condemned), and what the screen needs is small: the float32
+// obstacle view, four segment tables, a pair queue.  In the one-kernel form those searches occupied a 125-register wave slot of
+// k_rs_validate_f for their whole life -- most of it waiting for two memory round trips.  Here they run in a kernel that fits
+// 64 registers; it writes the mask of condemned words into the record's header and queues the searches that still have a word
+// to walk (queue index, queue entry) for k_rs_validate_f<..., PRE = true>, which then starts only for those.
+template <bool TIMING, int OCC = 8>
+__global__ __launch_bounds__(64, OCC) void k_rs_screen(RsParams p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    unsigned long long tsec[16] = {};
+    const int b_ = (int)blockIdx.x;
+    const int qidx = scene_of_block(b_, p.max_queue);     // (a bijection of the launch's blocks: independent of the queue length)
+    const int entry = p.rs_list[qidx];
+    const int count = *p.rs_count;
+    if (qidx >= count) return;
+    const int slot = p.slot_base + p.slot_dir * qidx;
+    const int scene = rs_list_scene(entry), n_obst = rs_list_n_obst(entry);
+    // LDS: float2 V[4 cap] | float4 box[cap] | four segment tables [200] | pair queue int[128] | int cand[cap] | edge flags[cap]
+    float2* fv = (float2*)lds;
+    float4* fbox = (float4*)(lds + 4 * p.tile_cap);
+    double* tabs = lds + 6 * p.tile_cap;
+    int* pq = (int*)(tabs + 4 * RS_SEG_TABLE);
+    int* cand = pq + 2 * WAVE;
+    unsigned char* eflag = (unsigned char*)(cand + ((p.tile_cap + 3) & ~3));
+    double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
+    const double r0 = lane < RS_REC_HDR ? rec[lane] : 0.0;
+    const double* tables = rec + RS_REC_SEGS;
+    {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const double2* t2 = (const double2*)tables;
+        __builtin_amdgcn_global_load_lds((const void*)(t2 + lane), (lds_ptr)tabs, 16, 0, 0);
+        if (lane < 2 * RS_SEG_TABLE - WAVE) __builtin_amdgcn_global_load_lds((const void*)(t2 + WAVE + lane), (lds_ptr)(tabs + 2 * WAVE), 16, 0, 0);
+        const float4* gfv = p.fverts + (size_t)scene * p.max_obst * 2;
+        const float4* gfb = p.fbox + (size_t)scene * p.max_obst;
+        const uint32_t* gfl = (const uint32_t*)(p.eflag + (size_t)scene * eflag_stride(p.max_obst));
+        float4* lfv = (float4*)fv;
+        for (int base = 0; base < 2 * n_obst; base += WAVE)
+            if (base + lane < 2 * n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfv + base + lane), (lds_ptr)(lfv + base), 16, 0, 0);
+        for (int base = 0; base < n_obst; base += WAVE)
+            if (base + lane < n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfb + base + lane), (lds_ptr)(fbox + base), 16, 0, 0);
+        for (int base = 0; 4 * base < n_obst; base += WAVE)
+            if (4 * (base + lane) < n_obst) __builtin_amdgcn_global_load_lds((const void*)(gfl + base + lane), (lds_ptr)((uint32_t*)eflag + base), 4, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // header, tables and obstacle view: one round trip (and no load into LDS in flight at an exit)
+    const int n_paths = __builtin_amdgcn_readlane(__double2hiint(r0), 1);
+    if (n_paths == 0) return;
+    const float fxmax = (float)(readlane_d(r0, 6) - readlane_d(r0, 5)), fymax = (float)(readlane_d(r0, 8) - readlane_d(r0, 7));
+    lsync();
+    const unsigned long long condemned = screen_words<TIMING>(lane, n_paths, n_obst, tables, tabs, pq, cand, fv, fbox, eflag, fxmax, fymax, tsec);
+    if (lane == 0) {
+        ((unsigned long long*)rec)[9] = condemned;
+        if (condemned != ((1ull << n_paths) - 1)) p.surv_list[atomicAdd(p.surv_count, 1)] = make_int2(qidx, entry);
+    }
+}
+
+template <int OCC, bool TIMING, bool STATS, bool PRE = false>
 __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f64) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -1247,17 +1305,24 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     // the queue length (a bijection of the launch's max_queue blocks; the length only decides who leaves), and the queue entry itself
     // carries the scene AND its obstacle count (k_rs_compact), so that the record's header, the segment tables and the obstacle view
     // are all requested at once -- the header used to be a round trip of its own in front of the tile.
+    int qidx, entry;
+    if (PRE) {                                             // two-kernel form: the searches k_rs_screen left a word of
+        const int2 sv = p.surv_list[b_];                   // (requested before the queue length is known: stale entries are harmless)
+        if (b_ >= *p.surv_count) return;
+        qidx = sv.x; entry = sv.y;
+    } else {
 #ifdef HOPE_RS_3TRIPS                                      // (A/B build: the round-4 order -- queue length, then header, then tile)
-    const int count = *p.rs_count;
-    if (b_ >= count) return;
-    const int qidx = scene_of_block(b_, count);
-    const int entry = p.rs_list[qidx];
+        const int count = *p.rs_count;
+        if (b_ >= count) return;
+        qidx = scene_of_block(b_, count);
+        entry = p.rs_list[qidx];
 #else
-    const int qidx = scene_of_block(b_, p.max_queue);
-    const int entry = p.rs_list[qidx];                   // (entries beyond the queue length are stale or zero: valid scenes, and we leave)
-    const int count = *p.rs_count;
-    if (qidx >= count) return;
+        qidx = scene_of_block(b_, p.max_queue);
+        entry = p.rs_list[qidx];                           // (entries beyond the queue length are stale or zero: valid scenes, and we leave)
+        const int count = *p.rs_count;
+        if (qidx >= count) return;
 #endif
+    }
     const int slot = p.slot_base + p.slot_dir * qidx;
 #ifndef HOPE_RS_HDR
     const int scene = rs_list_scene(entry);
@@ -1291,7 +1356,7 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     // the segment tables of the first FOUR words lie back to back behind the header (200 doubles; a record has room for 48 tables, so
     // the request never leaves it): all of them now, for the screen pass ...
     double tb = lane < RS_SEG_TABLE ? tables[lane] : 0.0;
-    {   // ... straight into the sample queue's LDS words (global_load_lds, 16 bytes per lane: no registers, nobody waits here)
+    if (!PRE) {   // ... straight into the sample queue's LDS words (global_load_lds, 16 bytes per lane: no registers, nobody waits here)
         typedef __attribute__((address_space(3))) void* lds_ptr;
         const double2* t2 = (const double2*)tables;
         __builtin_amdgcn_global_load_lds((const void*)(t2 + lane), (lds_ptr)qpd, 16, 0, 0);
@@ -1336,7 +1401,8 @@ __global__ __launch_bounds__(64, OCC) void k_rs_validate_f(RsParams p, int obs_f
     unsigned long long st_why[5] = {};
     // ---- screen pass (see screen_obstacle_hit above): up to four words per pass, certain float32 hits only ----
     unsigned long long condemned = 0;                      // bit k: the k-th popped word has a certainly colliding sample
-    if (!(obs_f64 & 0x20000)) {                            // (HOPE_RS_DEBUG=0x20000: no screen -- A/B and the parity tests)
+    if (PRE) condemned = (unsigned long long)__double_as_longlong(readlane_d(r0, 9));      // k_rs_screen's verdict (nothing of ours in LDS yet: no wait)
+    else if (!(obs_f64 & 0x20000)) {                       // (HOPE_RS_DEBUG=0x20000: no screen -- A/B and the parity tests)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the obstacle view's global_load_lds have landed
         tile_pending = false;
         condemned = screen_words<TIMING>(lane, n_paths, n_obst, tables, qpd, (int*)tabl /* pair queue: the sample table is loaded behind the screen */,
@@ -1690,6 +1756,9 @@ static size_t rs_lds_bytes_filter(int max_obst) {
     return (size_t)(6 * max_obst + RSB_WORDS_F) * 8 + (size_t)((max_obst + 3) & ~3) * 4 + RSB_QCAP + (size_t)((max_obst + 3) & ~3);
 }
 size_t rs_lds_bytes(int max_obst) { return std::max(rs_lds_bytes_exact(max_obst), rs_lds_bytes_filter(max_obst)); }
+size_t rs_screen_lds_bytes(int max_obst) {                // k_rs_screen: view 48 B / obstacle | four tables | pair queue | cand | edge flags
+    return (size_t)(6 * max_obst + 4 * RS_SEG_TABLE) * 8 + 2 * WAVE * 4 + (size_t)((max_obst + 3) & ~3) * 4 + (size_t)((max_obst + 3) & ~3);
+}
 size_t rs_rec_bytes_per_scene() { return sizeof(double) * RS_REC_DOUBLES; }
 
 hipError_t rs_prof_read(unsigned long long* out, int reset) {
@@ -1767,6 +1836,10 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
         const int wpc = w ? atoi(w) : (p.tile_cap > 32 ? 8 : 0);
         if (wpc > 0) lds = std::max(lds, (size_t)((158 * 1024 / wpc) & ~255));
     }
+    if (lds > 48 * 1024) {                                  // (the two-kernel form's walk kernel; k_rs_screen stays far below)
+        hipError_t e = hipFuncSetAttribute((const void*)k_rs_validate_f<RSF_OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     const void* vk = exact ? (timing ? (const void*)k_rs_validate<3, true> : occ != 4 ? (const void*)k_rs_validate<3, false> : (const void*)k_rs_validate<4, false>)
                            : (timing ? (const void*)k_rs_validate_f<RSF_OCC, true, false> : stats ? (const void*)k_rs_validate_f<RSF_OCC, false, true>
                               : occ == 5 ? (const void*)k_rs_validate_f<5, false, false>
@@ -1788,6 +1861,20 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
     if (timer) timer->end(stream);
     if (after_segs) { hipError_t e = hipEventRecord(after_segs, stream); if (e != hipSuccess) return e; }   // (pipelined steps: the next motion launch waits here)
     if (stop_after == 3) return hipGetLastError();
+    // two-kernel validation (HOPE_RS_SPLIT=1; measured and NOT adopted): k_rs_screen at 8 waves per SIMD, then the walk only for the
+    // searches it left a word of.  65 536 scenes, steady state, same box: 0.531 ms per step against 0.514 for the one-kernel form
+    // (profiles/r05_ab_two_kernel_validation.txt) -- the second launch over the whole queue, the survivors' second prologue and the
+    // extra link in the search chain cost more than the freed register slots give back.  Kept as a build that the tests compare.
+    const bool split = !exact && !timing && !stats && !(dbg & 0x20000) && p.surv_count && p.surv_list &&
+                       getenv("HOPE_RS_SPLIT") && atoi(getenv("HOPE_RS_SPLIT")) == 1;
+    if (split) {
+        if (timer) timer->begin(HOPE_K_RS_SCREEN, stream);
+        static const int socc = getenv("HOPE_RS_SCREEN_OCC") ? atoi(getenv("HOPE_RS_SCREEN_OCC")) : 8;      // (A/B: 7 = 72 registers, no spills)
+        if (socc == 7) hipLaunchKernelGGL((k_rs_screen<false, 7>), dim3(p.max_queue), dim3(WAVE), rs_screen_lds_bytes(p.tile_cap), stream, p);
+        else if (socc == 6) hipLaunchKernelGGL((k_rs_screen<false, 6>), dim3(p.max_queue), dim3(WAVE), rs_screen_lds_bytes(p.tile_cap), stream, p);
+        else hipLaunchKernelGGL((k_rs_screen<false, 8>), dim3(p.max_queue), dim3(WAVE), rs_screen_lds_bytes(p.tile_cap), stream, p);
+        if (timer) timer->end(stream);
+    }
     if (timer) timer->begin(HOPE_K_RS_VALIDATE, stream);
     static const bool no_prio = getenv("HOPE_RS_PRIO") && atoi(getenv("HOPE_RS_PRIO")) == 0;
     // only for the launch of the class with more scenes, i.e. the longer chain (both launches: 0.657 ms / steady 0.688; only the
@@ -1798,7 +1885,8 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
         if (timing) hipLaunchKernelGGL((k_rs_validate<3, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
         else if (occ != 4) hipLaunchKernelGGL((k_rs_validate<3, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
         else hipLaunchKernelGGL((k_rs_validate<4, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
-    } else if (timing) hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, true, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    } else if (split) hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, false, false, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
+    else if (timing) hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, true, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
     else if (stats) hipLaunchKernelGGL((k_rs_validate_f<RSF_OCC, false, true>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
     else if (occ == 5) hipLaunchKernelGGL((k_rs_validate_f<5, false, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);
     else if (occ == 3) hipLaunchKernelGGL((k_rs_validate_f<3, false, false>), dim3(p.max_queue), dim3(WAVE), lds, stream, p, flags);

@@ -230,6 +230,12 @@ int hope_env_set_pool(hope_env_t *h, int n_pool, const double *start, const doub
  * for the previous upload's copy to leave the staging).  Both must be called from the thread that owns the handle. */
 int hope_env_pool_staging(hope_env_t *h, int n_pool, double **start, double **dest, double **bbox, double **verts, int32_t **n_obst);
 int hope_env_commit_pool(hope_env_t *h, int n_pool, void *stream);
+/* (ABI 8) The same upload, with the swap RELAXED: the new pool takes over at the first step (or hope_env_redraw) enqueued after the
+ * upload has COMPLETED -- no step ever waits for an upload.  (hope_env_commit_pool swaps at once, so the next step's launch waits on
+ * its stream for the 67 MB of an 8 192-lot pool: 2-3 ms, five 65 536-scene steps.)  Which step that is depends on timing, like the
+ * moment a background refresher's fill finishes; a later commit of either kind, hope_env_set_pool and hope_env_pool_generation first
+ * wait for and apply a swap still pending.  What a rollout's background refresher should use (hope_amd.scene_gen.PoolRefresher). */
+int hope_env_commit_pool_relaxed(hope_env_t *h, int n_pool);
 /* 1 when hope_env_pool_staging would return without waiting (the previous commit's copies have left the pinned arrays), 0 when not
  * yet, < 0 on error: a background refresher polls this instead of blocking the thread that drives the step loop */
 int hope_env_pool_staging_ready(hope_env_t *h);
@@ -304,7 +310,8 @@ int hope_env_queue_check(hope_env_t *h, int32_t *queue_of_role /*[8]*/, int32_t 
 #define HOPE_K_RS_COMPACT 6    /* k_rs_compact   (Reeds-Shepp work queues from per-scene flags) */
 #define HOPE_K_POST 7           /* k_post         (reward + target arithmetic, one lane per scene; per tile class) */
 #define HOPE_K_RS_SEGS 8       /* k_rs_segs      (segment origins of the words to test, one lane per word; per tile class) */
-#define HOPE_N_KERNELS 9
+#define HOPE_K_RS_SCREEN 9     /* k_rs_screen    (ABI 8: coarse look at up to four words per pass, wave per queued scene; per tile class) */
+#define HOPE_N_KERNELS 10
 int hope_env_kernel_ms(hope_env_t *h, double *ms /*[HOPE_N_KERNELS]*/, int64_t *launches /*[HOPE_N_KERNELS]*/,
                        int reset);
 /* Same bookkeeping, per CALL instead of per launch: for every hope_env_step / hope_env_reset_obs call and kernel, the time

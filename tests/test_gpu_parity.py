@@ -959,6 +959,47 @@ def test_rs_float32_filter_equals_the_float64_kernel_and_never_contradicts_it():
     env.close()
 
 
+def test_two_kernel_validation_equals_the_one_kernel_form():
+    """Round 5: with HOPE_RS_SPLIT=1 k_rs_screen (8 waves per SIMD) condemns words and queues the searches that still have a word to
+    walk for k_rs_validate_f; the default one-kernel form runs the same screen inside the walk kernel (and is the faster one).  Same
+    rs_word / rs_lengths on the same states over a mixed rollout with found paths, whatever the order of the survivor queue's atomics."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import SceneSource
+    n, mo = 8192, 128
+    src = SceneSource(seed=171)
+    uniq = [src.draw() for _ in range(1024)]
+    rng = np.random.default_rng(172)
+    for k in range(0, len(uniq), 2):
+        s = uniq[k]
+        r, a = rng.uniform(0.0, 7.0), rng.uniform(0, 2 * np.pi)
+        s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.5])
+    env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
+    env.set_scenes(np.arange(n), [uniq[i % len(uniq)] for i in range(n)])
+    env.reset_obs()
+    g = torch.Generator(device=env.device).manual_seed(173)
+    found = 0
+    try:
+        for it in range(10):
+            act = torch.rand((n, 2), device=env.device, generator=g, dtype=torch.float64) * 2.4 - 1.2
+            pose, t, acc = env.download_state()
+            os.environ['HOPE_RS_SPLIT'] = '1'
+            env.step(act)
+            torch.cuda.synchronize()
+            ref = {k: getattr(env, k).clone() for k in ('rs_word', 'rs_lengths', 'status', 'reward')}
+            del os.environ['HOPE_RS_SPLIT']
+            env.upload_state(pose=pose, t=t, accum=acc)
+            env.step(act)
+            torch.cuda.synchronize()
+            for k, v in ref.items():
+                assert torch.equal(getattr(env, k), v), (it, k)
+            found += int((env.rs_word[:, 6] > 0).sum())
+    finally:
+        os.environ.pop('HOPE_RS_SPLIT', None)
+    assert found > 1000
+    env.close()
+
+
 def _ks2(a, b):
     a, b = np.sort(a), np.sort(b)
     allv = np.concatenate([a, b])
