@@ -50,12 +50,15 @@ def parse():
                          'device-resident pool of --pool generated scenes inside the step kernel (HOPE_AUTO_REDRAW)')
     ap.add_argument('--fresh-scenes', action='store_true', help='(the default now; kept for old command lines)')
     ap.add_argument('--pool', type=int, default=8192)
-    ap.add_argument('--refresh-every', type=int, default=8,
+    ap.add_argument('--refresh-every', type=int, default=-1,
                     help='the device-resident pool of generated lots is REPLACED in the background while the steps run, as a rollout does it '
                          '(scene_gen.PoolRefresher: the native generator fills pinned staging on host threads, an asynchronous upload swaps the '
-                         'pool in): the step loop polls it every this many steps, inside the timed region.  0 = a static pool')
+                         'pool in): the step loop polls it every this many steps, inside the timed region.  -1 (default) = at the rate the '
+                         'batch consumes the pool: about 0.45 %% of the scenes draw a generated lot per step, so a pool of P lots is used up '
+                         'after P / (0.0045 N) steps (28 steps at 65 536 scenes and 8 192 lots; never below 8); 0 = a static pool')
     ap.add_argument('--overlap', default='auto', choices=['auto', 'on', 'off'],
                     help='launch chains of the two tile classes on two streams (auto = on)')
+    ap.add_argument('--refresh-threads', type=int, default=2, help='worker threads of the background pool refill (native generator)')
     ap.add_argument('--max-obst', type=int, default=128)
     ap.add_argument('--mix', default='mixed', choices=['mixed', 'dlp', 'normal'])
     ap.add_argument('--stages', default='all', choices=['all', 'norss', 'motion'])
@@ -223,9 +226,11 @@ def main():
         env.set_redraw_seed(args.seed * 7919 + 1)
 
         bench_refresher = None
+        if args.refresh_every < 0:
+            args.refresh_every = max(8, int(args.pool / (0.0045 * N)))
         if gl and args.refresh_every > 0 and args.policy == 'none':
             from hope_amd.scene_gen import PoolRefresher
-            bench_refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5, relaxed=True)
+            bench_refresher = PoolRefresher(env, args.pool, levels=gl, seed=(args.seed + rank) * 31 + 5, relaxed=True, threads=args.refresh_threads)
 
         def one_step(i, defer_=None):  # noqa: F811
             # the new map is drawn inside the step kernel (HOPE_AUTO_REDRAW = step + redraw(done) + reset_obs(active=done))
@@ -274,14 +279,16 @@ def main():
             for i in range(args.preroll):
                 one_step(i)
             torch.cuda.synchronize(dev)
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize(dev)
-    # the maps resident NOW (the pre-roll redrew finished episodes on the device): SURVEY.md §8(d)'s E per scene from them
+    # the maps resident NOW (the pre-roll redrew finished episodes on the device): SURVEY.md §8(d)'s E per scene from them.  (Before the
+    # warm-up steps, not between them and the timed region: the download idles the GPU for milliseconds, and a 20-step window that
+    # starts on a GPU that has just idled ran 8 % slow.)
     edges = 4.0 * env.n_obst_now()
     bytes_per_launch = float(np.sum(808.0 + 16.0 * edges))
     if args.image:
         bytes_per_launch = float(np.sum(64.0 + 16.0 * edges + 3.0 * 64 * 64))
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize(dev)
     commits0 = bench_refresher.commits if bench_refresher is not None else 0
     env.kernel_union_ms(reset=True)
     env.kernel_ms(reset=True)

@@ -15,6 +15,9 @@
 #include <string.h>
 
 #include <pthread.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <new>
 
@@ -277,6 +280,10 @@ class WorkerPool {
     void loop(int index) {
         uint64_t seen = 0;
         int my_cpu = -1;
+        // lowest scheduling priority: a worker is pinned, and the thread that enqueues the env steps may sit on that very CPU (the job
+        // is posted by a background fill thread, whose CPU says nothing about the step loop's) -- measured: 20-step windows of the
+        // bench 0.52 .. 0.60 ms per step while a fill ran.  On an idle CPU a nice-19 thread runs at full speed.
+        setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 19);
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             cv_work_.wait(lk, [&] { return generation_ != seen; });
@@ -284,11 +291,13 @@ class WorkerPool {
             if (claimed_ >= want_) continue;                // more workers than this job wants
             claimed_++;
             const std::function<void()>* job = job_;
-            // Worker i sits on the i-th CPU of the mask, the caller's current CPU left out.  Without this a woken worker
+            // Worker i sits on the i-th CPU FROM THE END of the mask, the caller's current CPU left out.  Without this a woken worker
             // is queued on the CPU that woke it -- the caller's, which is busy with the job -- and waits for the periodic load
             // balancer: measured here, a 27 ms job on 2 .. 8 sleeping workers finished in 27 ms.  Re-pinned when the mask changed
             // (hope_amd.dist.pin_rank_to_cores runs after the first pool use in a multi-rank process).
-            const int cpu = cpus_.empty() ? -1 : cpus_[(size_t)index % cpus_.size()];
+            // ... counted from the END of the mask: the first CPUs are where interrupt handling and the runtime's own threads tend to
+            // live (on one of two boxes a refill pinned to CPUs 0 .. 7 cost the 20-step bench window 9 %, on the other nothing)
+            const int cpu = cpus_.empty() ? -1 : cpus_[cpus_.size() - 1 - (size_t)index % cpus_.size()];
             lk.unlock();
             if (cpu >= 0 && cpu != my_cpu) {
                 cpu_set_t one;

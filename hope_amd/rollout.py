@@ -148,6 +148,7 @@ class HopeRollout:
         self.seed = seed
         self.defer_rs = bool(defer_rs) and hasattr(env, 'wait_rs')
         self._plan_pending = False                    # the planner has not yet seen the last step's done / RS outputs
+        self._rs_step = None                          # hope_env_last_step() of the deferred step whose search the planner waits for
         dev = env.device
         self.ring = TransitionRing(env.n, horizon, agent.keys, dev)
         self.planner = G.BatchedRsPlanner(env.n, device=dev) if use_planner else None
@@ -177,7 +178,8 @@ class HopeRollout:
         if self._plan_pending:
             env = self.env
             if self.defer_rs:
-                env.wait_rs()
+                # the search of THE step whose words the planner is about to read (a newer step would have replaced them: HOPE_ESTATE)
+                env.wait_rs(step=self._rs_step) if self._rs_step is not None and hasattr(env, 'last_step') else env.wait_rs()
             self.planner.reset(env.done.bool())                     # ParkingAgent.reset at episode end
             self.planner.set_paths(env.rs_word, env.rs_lengths)     # info['path_to_dest'] -> set_planner_path
             self._plan_pending = False
@@ -211,6 +213,7 @@ class HopeRollout:
         self.successes += (env.status == 2).sum()
         self.reward_sum += env.reward.sum(dtype=torch.float64)
         self._plan_pending = self.planner is not None               # (its bookkeeping runs in _plan, before the next override)
+        self._rs_step = env.last_step() if (self.defer_rs and hasattr(env, 'last_step')) else None
         self.steps += 1
 
     def last_obs(self):

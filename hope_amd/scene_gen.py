@@ -57,9 +57,9 @@ class PoolRefresher:
     thread that owns the env, e.g. once per policy update -- commits a finished batch (asynchronous upload + swap,
     hope_env_commit_pool) and starts the next one.  Every batch is new: batch b of the run uses first_index = b * n_pool."""
 
-    def __init__(self, env, n_pool, levels=('Normal', 'Complex', 'Extrem'), seed=0, threads=8, relaxed=False):
-        # threads: 8 workers of the native generator's pool refill 8 192 lots in ~2 ms (4 M lots/s, profiles/r05_host_generator_threads.txt),
-        # a hundred times what 65 536 scenes consume; more would only compete with the thread that enqueues the steps.  0 = all CPUs
+    def __init__(self, env, n_pool, levels=('Normal', 'Complex', 'Extrem'), seed=0, threads=2, relaxed=False):
+        # threads: 2 workers of the native generator refill 8 192 lots in ~7 ms (1.2 M lots/s, profiles/r05_host_generator_threads.txt):
+        # 65 536 scenes consume 0.5 M lots/s; more threads only add ways to get in the way of the thread that enqueues the steps.  0 = all CPUs
         self.env, self.n, self.levels, self.seed, self.threads = env, int(n_pool), tuple(levels), int(seed), int(threads)
         # relaxed: commit with hope_env_commit_pool_relaxed -- the new pool takes over once its upload has finished, no step waits for it
         # (the strict commit makes the next step wait 2-3 ms for the 67 MB of an 8 192-lot pool); which step sees it depends on timing

@@ -324,7 +324,7 @@ def test_bench_gpus_n_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(HOPE_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--scenes', '8192', '--steps', '24', '--warmup', '4', '--preroll', '40',
-           '--no-cpu-baseline', '--witness', '0', '--repeat-passes', '1', '--repeat-steps', '40']
+           '--refresh-every', '8', '--no-cpu-baseline', '--witness', '0', '--repeat-passes', '1', '--repeat-steps', '40']
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().split('\n') if ln.startswith('{')]

@@ -1,17 +1,17 @@
 #!/bin/bash
 # Regenerates every file under profiles/ on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
 # Outputs land in gpurun_out/final/ (merged back by gpurun); copy them into profiles/ afterwards.
 # PMC counters are collected in their own passes, without any trace domain.  Every command runs under `timeout`.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 T="timeout 400"
 py() { $T python "$@" 2>>$O/stderr.log; }
-PRE="--preroll 100"     # profiled runs: a shorter pre-roll to the stationary episode population (the default run uses 300)
+PRE="--preroll 100 --refresh-every 0"     # profiled runs: a shorter pre-roll to the stationary episode population (the default run uses 300), static pool
 
 py $R/bench.py | tail -1 > $O/${TAG}_bench_default.json
 py $R/bench.py | tail -1 > $O/${TAG}_bench_default_2.json
@@ -24,7 +24,7 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_img -- pyth
 for V in "" "_image"; do
   FLAG=""; [ -n "$V" ] && FLAG="--image"
   for C in FETCH_SIZE WRITE_SIZE; do
-    $T rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --preroll 60 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+    $T rocprofv3 --pmc $C --output-format csv -d $O/pmc${V}_$C -- python $R/bench.py $FLAG --steps 6 --warmup 2 --preroll 60 --refresh-every 0 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
   done
 done
 # derived busy / utilisation metrics (list VALU-busy and LDS-bank-conflict next to the HBM fraction)
@@ -33,12 +33,12 @@ for V in "" "_image"; do
   I=0
   for C in "VALUBusy SALUBusy" "LDSBankConflict MemUnitBusy" "OccupancyPercent VALUUtilization"; do
     I=$((I+1))
-    $T rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --preroll 60 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+    $T rocprofv3 --pmc $C --output-format csv -d $O/busy${V}_$I -- python $R/bench.py $FLAG --steps 3 --warmup 12 --preroll 60 --refresh-every 0 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
   done
 done
 python $R/tools/reduce_profiles.py $O $TAG
 # raw SQ counters (instruction mix, wait / active quad-cycles) -> VALU-issue roofline of bench.py
-(cd $R && timeout 900 bash tools/pmc_sq.sh final/sq > /dev/null 2>&1)
+(cd $R && timeout 900 bash tools/pmc_sq.sh final/sq --refresh-every 0 > /dev/null 2>&1)
 cp $O/sq/sq_summary.txt $O/${TAG}_sq_summary.txt; cp $O/sq/sq_counters.json $O/${TAG}_sq_counters.json; rm -rf $O/sq
 py $R/tools/stage_times.py --scenes 32768 > $O/${TAG}_stage_times.txt
 py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
@@ -47,6 +47,8 @@ py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
   for NS in 4096 8192 16384 32768 65536 131072; do echo "== --scenes $NS"; py $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 2 --steps 40 --warmup 10 | tail -1; done
   echo "== --scenes 65536 --overlap off"; py $R/bench.py --overlap off --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
   echo "== --same-map"; py $R/bench.py --same-map --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 | tail -1
+  echo "== --refresh-every 0 (static pool)"; py $R/bench.py --refresh-every 0 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 | tail -1
+  echo "== HOPE_RS_DEBUG=0x20000 (no screen pass: round 4's validation kernel)"; HOPE_RS_DEBUG=0x20000 $T python $R/bench.py --refresh-every 0 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   echo "== HOPE_PIPE=0 (steps not pipelined: the round-3 launch structure with this round's kernels)"; HOPE_PIPE=0 $T python $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   echo "== config 2: --stages motion --scenes 4096"; py $R/bench.py --scenes 4096 --stages motion --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
   echo "== config 3: --scenes 16384 (full step)"; py $R/bench.py --scenes 16384 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 | tail -1

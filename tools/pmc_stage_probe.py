@@ -25,9 +25,10 @@ def reduce(seq_path, csv_path, counter):
     assert len(rows) == len(seq['launches']), (len(rows), len(seq['launches']))
     acc = collections.defaultdict(list)
     for r, (name, scenes) in zip(rows, seq['launches']):
-        acc[name].append(float(r['Counter_Value']) * 1024 / seq['scenes'])
+        acc[name].append(float(r['Counter_Value']) * (1 if counter.startswith('SQ_') else 1024) / seq['scenes'])
     for name, v in acc.items():
-        print(f'{counter:12s} {name:28s} {sum(v) / len(v):9.1f} B/scene  ({len(v)} launches)')
+        unit = 'wave-instructions/scene (per launch)' if counter.startswith('SQ_') else 'B/scene'
+        print(f'{counter:12s} {name:28s} {sum(v) / len(v):9.1f} {unit}  ({len(v)} launches)')
 
 
 def main():
@@ -35,6 +36,7 @@ def main():
     ap.add_argument('--scenes', type=int, default=32768)
     ap.add_argument('--seq', default='gpurun_out/probe_seq.json')
     ap.add_argument('--reduce', nargs=2)
+    ap.add_argument('--mix', default='normal', choices=['normal', 'mixed'], help='mixed: the bench scene mix (all four levels)')
     args = ap.parse_args()
     if args.reduce:
         return reduce(args.seq, *args.reduce)
@@ -42,7 +44,7 @@ def main():
     from hope_amd import ParkingBatch, _lib as L
     from hope_amd.scenes import SceneSource, pack_scenes
     N = args.scenes
-    src = SceneSource(levels=('Normal',), seed=3)
+    src = SceneSource(levels=('Normal',), seed=3) if args.mix == 'normal' else SceneSource(seed=3)
     uniq = [src.draw() for _ in range(512)]
     start, dest, bbox, verts, nob, nvert = pack_scenes(uniq, 128)
     reps = N // len(uniq)
