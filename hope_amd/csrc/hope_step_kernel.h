@@ -487,9 +487,10 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
     double raw_x = (b * f - 0.0 * e) / det;
     double raw_y = (0.0 * d - a * f) / det;
     const double tz = 1e-8;
-    bool ok = true;
-    if (i < NBEAM / 4 || i >= NBEAM / 4 * 3) ok = ok && !(raw_x < -tz); else ok = ok && !(raw_x > tz);
-    if (i < NBEAM / 2) ok = ok && !(raw_y < -tz); else ok = ok && !(raw_y > tz);
+    // the quadrant tests of :120-124 with the beam's signs as factors (a product with +-1 is exact, the compare flips with it; a NaN
+    // fails neither form): !(raw_x < -tz) for the beams looking towards +x, !(raw_x > tz) = !(-raw_x < -tz) for the others
+    const double sx = (i < NBEAM / 4 || i >= NBEAM / 4 * 3) ? 1.0 : -1.0, sy = (i < NBEAM / 2) ? 1.0 : -1.0;
+    bool ok = !(sx * raw_x < -tz) && !(sy * raw_y < -tz);
     ok = ok && !(raw_x > fmax(x1, x2)) && !(raw_x < fmin(x1, x2));
     ok = ok && !(raw_y > fmax(y1, y2)) && !(raw_y < fmin(y1, y2));
     return ok ? sqrt(raw_x * raw_x + raw_y * raw_y) : INFINITY;
@@ -1048,13 +1049,50 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         const int i = base + lane;
         const bool in = i < 4 * n_l;
         const int o = in ? llist[i >> 2] : 0;
+        // Almost every ring is decided WITHOUT GEOS's point-to-segment arithmetic (two divisions and three square roots per edge, ~90
+        // vector instructions per 64 edges; the step is VALU-issue bound) from squared quantities with 1e-9 of relative margin (the
+        // distance's own rounding is ~1e-15): an edge is certainly nearer than the range when one of its end points is (the
+        // segment's distance is at most the vertex's), certainly farther when even its LINE is, or when the foot of the perpendicular
+        // lies clearly beyond an end point that is farther; a foot clearly inside the segment makes the line's distance the
+        // segment's.  A ring is kept when one edge is certainly nearer, dropped when all four are certainly farther; anything else
+        // -- a value within the margin of the range or of a case boundary -- takes the exact path below (the tie census says: never on
+        // this workload; the exact path is what the instrumented build always runs).
         double dd = INFINITY;
-        if (in) {
-            const int e = 4 * o + (i & 3), e2 = 4 * o + ((i + 1) & 3);
-            dd = origin_seg_dist(tile[2 * e], tile[2 * e + 1], tile[2 * e2], tile[2 * e2 + 1]);
+        bool amb = in;
+        if (!TIMING) {
+            bool keep_c = false, drop_c = false;
+            if (in) {
+                const int e = 4 * o + (i & 3), e2 = 4 * o + ((i + 1) & 3);
+                const double ax = tile[2 * e], ay = tile[2 * e + 1], bx = tile[2 * e2], by = tile[2 * e2 + 1];
+                const double ddx = bx - ax, ddy = by - ay;
+                const double len2 = ddx * ddx + ddy * ddy;
+                const double dot = (0.0 - ax) * ddx + (0.0 - ay) * ddy;                       // r = dot / len2 (Distance::pointToSegment)
+                const double qa = ax * ax + ay * ay, qb = bx * bx + by * by;
+                const double num = ay * ddx - ax * ddy;                                       // s = num / len2, distance |s| sqrt(len2)
+                const double R2 = LIDAR_RANGE * LIDAR_RANGE, ETA = 1e-9;
+                const double lo = R2 * (1.0 - ETA), hi = R2 * (1.0 + ETA);
+                const double n2 = num * num;
+                const bool line_far = n2 > hi * len2, line_near = n2 < lo * len2;
+                const bool foot_in = dot > ETA * len2 && dot < (1.0 - ETA) * len2;             // 0 < r < 1, clearly
+                const bool foot_a = dot < -ETA * len2, foot_b = dot > (1.0 + ETA) * len2;      // r < 0 / r > 1, clearly
+                keep_c = qa < lo || qb < lo || (foot_in && line_near);
+                // (a triangle repeats its last vertex: that edge is the point itself)
+                drop_c = !keep_c && (len2 > 0.0 ? (line_far || (foot_a && qa > hi) || (foot_b && qb > hi)) : qa > hi);
+            }
+            const unsigned long long kb = __ballot(keep_c), db = __ballot(drop_c);
+            const int sh = lane & ~3;
+            const bool ring_keep = ((kb >> sh) & 0xF) != 0, ring_drop = ((db >> sh) & 0xF) == 0xF;
+            if (ring_keep) dd = 0.0;
+            amb = in && !ring_keep && !ring_drop;
         }
-        dd = fmin(dd, dpp_d<0xB1>(dd));                      // quad_perm [1,0,3,2]
-        dd = fmin(dd, dpp_d<0x4E>(dd));                      // quad_perm [2,3,0,1]
+        if (__any(amb)) {
+            if (amb) {
+                const int e = 4 * o + (i & 3), e2 = 4 * o + ((i + 1) & 3);
+                dd = origin_seg_dist(tile[2 * e], tile[2 * e + 1], tile[2 * e2], tile[2 * e2 + 1]);
+            }
+            dd = fmin(dd, dpp_d<0xB1>(dd));                  // quad_perm [1,0,3,2]
+            dd = fmin(dd, dpp_d<0x4E>(dd));                  // quad_perm [2,3,0,1]
+        }
         if (TIMING && in && (i & 3) == 0) { cen_ring_n += 1; cen_ring = fmin(cen_ring, fabs(dd - LIDAR_RANGE)); }
         const bool kq = in && (i & 3) == 0 && dd < LIDAR_RANGE;
         const unsigned long long km = __ballot(kq);
@@ -1119,7 +1157,10 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 const double dx1 = tile[2 * e], dy1 = tile[2 * e + 1], dx2 = tile[2 * e2], dy2 = tile[2 * e2 + 1];
                 const float x1 = (float)dx1, y1 = (float)dy1;
                 const float x2 = (float)dx2, y2 = (float)dy2;
-                const float t1 = atan2f(y1, x1), t2 = atan2f(y2, x2);
+                // (t2 is the NEXT vertex's t1: the same atan2f on the same floats, computed by the next lane of the ring's quad -- a
+                // quad rotation instead of a second ~30-instruction evaluation; the step is VALU-issue bound)
+                const float t1 = atan2f(y1, x1);
+                const float t2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t1), 0x39, 0xf, 0xf, true));   // quad_perm [1,2,3,0]
                 float dth = t2 - t1;
                 if (dth > 3.14159265f) dth -= 6.28318531f;
                 if (dth <= -3.14159265f) dth += 6.28318531f;
