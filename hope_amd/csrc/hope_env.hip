@@ -41,6 +41,7 @@ struct hope_env {
     int32_t* n_obst = nullptr;
     double* scene_c = nullptr;
     double* state = nullptr;
+    double* cs = nullptr;         // [n][2] cos / sin of state's heading (motion launch -> observation launch)
     int32_t* tstep = nullptr;
     double* tab = nullptr;
     double* pmax = nullptr;
@@ -525,6 +526,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->n_obst, N * sizeof(int32_t));
     ALLOC(h->scene_c, N * SC_WORDS * sizeof(double));
     ALLOC(h->state, N * ST_WORDS * sizeof(double));
+    ALLOC(h->cs, N * 2 * sizeof(double));
     ALLOC(h->tstep, N * sizeof(int32_t));
     ALLOC(h->tab, (size_t)NL * NITER * NACT * sizeof(double));
     ALLOC(h->pmax, NL * sizeof(double));
@@ -766,7 +768,7 @@ static int destroy_impl(hope_env_t* h) {                   // (also the clean-up
     for (hipEvent_t e : {h->ev_pool_ready, h->ev_pool_copied, h->ev_last_step}) if (e) hipEventDestroy(e);
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
-    void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->tstep, h->tab, h->pmax,
+    void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->cs, h->tstep, h->tab, h->pmax,
                     h->hull_base, h->beam_ab, h->rs_count, h->rs_surv_count, h->rs_surv, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -967,7 +969,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     static const uint32_t dbg_stages = getenv("HOPE_DEBUG_STAGES") ? (uint32_t)strtol(getenv("HOPE_DEBUG_STAGES"), nullptr, 0) : 0;   // profiling switches 0x1000 / 0x2000 (results invalid)
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages | dbg_stages; p.has_action = has_action;
     p.hflags = h->traj ? STEP_HF_TRAJ : 0;
-    p.verts = h->verts; p.obb = h->obb; p.eflag = h->eflag; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.tstep = h->tstep;
+    p.verts = h->verts; p.obb = h->obb; p.eflag = h->eflag; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.cs = h->cs; p.tstep = h->tstep;
     p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.post = h->post;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.lidar = out->lidar; p.action_mask = out->action_mask;

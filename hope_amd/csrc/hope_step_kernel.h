@@ -167,6 +167,7 @@ struct StepParams {
     const int32_t* n_obst;    // [n]
     const double* scene_c;    // [n][SC_WORDS]
     double* state;            // [n][ST_WORDS]
+    double* cs;               // [n][2] cos / sin of the heading the motion launch left in state (read by the observation launch)
     int32_t* tstep;           // [n]
     double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
     const uint8_t* active;    // [n] or null (the caller's mask: only read by launches the caller's stream is ordered after)
@@ -453,6 +454,27 @@ __device__ __forceinline__ bool detect_collision(double px, double py, double ct
     return false;
 }
 
+constexpr float SPAN_ANGLE_C[6] = {0.9999772310256958f, -0.33262282609939575f, 0.19354036450386047f,
+                                   -0.11642643809318542f, 0.05264730006456375f, -0.01171911507844925f};
+// Direction of (x, y) for the lidar's beam-span FILTER (not a reference quantity): atan2 to within 4e-6 rad -- a degree-11 odd
+// minimax polynomial of min/max (1.75e-6 in float32 over [0, 1], tests/test_lidar_span_angle.py) behind the hardware reciprocal,
+// ~17 vector instructions where the library's correctly-rounded-to-an-ulp atan2f takes ~40.  NaN for (0, 0).
+__device__ __forceinline__ float span_angle(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = t * t;
+    float q = __builtin_fmaf(s, SPAN_ANGLE_C[5], SPAN_ANGLE_C[4]);
+    q = __builtin_fmaf(q, s, SPAN_ANGLE_C[3]);
+    q = __builtin_fmaf(q, s, SPAN_ANGLE_C[2]);
+    q = __builtin_fmaf(q, s, SPAN_ANGLE_C[1]);
+    q = __builtin_fmaf(q, s, SPAN_ANGLE_C[0]);
+    float r = q * t;
+    if (ay > ax) r = 1.57079633f - r;
+    if (x < 0.0f) r = 3.14159265f - r;
+    return copysignf(r, y);
+}
+
 // GEOS Distance::pointToSegment from the origin
 __device__ __forceinline__ double origin_seg_dist(double ax, double ay, double bx, double by) {
     if (ax == bx && ay == by) return sqrt(ax * ax + ay * ay);
@@ -484,8 +506,10 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
                                             double d, double e, double f) {
     double det = a * e - b * d;
     if (det == 0) return INFINITY;
-    double raw_x = (b * f - 0.0 * e) / det;
-    double raw_y = (0.0 * d - a * f) / det;
+    // (b f - 0 e) / det and (0 d - a f) / det of :110-111 without the zero products: for finite coordinates they change at most the
+    // SIGN of a zero numerator, and nothing below looks at the sign of a zero
+    double raw_x = (b * f) / det;
+    double raw_y = (-(a * f)) / det;
     const double tz = 1e-8;
     // the quadrant tests of :120-124 with the beam's signs as factors (a product with +-1 is exact, the compare flips with it; a NaN
     // fails neither form): !(raw_x < -tz) for the beams looking towards +x, !(raw_x > tz) = !(-raw_x < -tz) for the others
@@ -508,6 +532,11 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
 // y[10], written through LDS with coalesced stores.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int KIN_SCENES_PER_BLOCK = WAVE / 4;
+
+// k / NITER for the action mask's step counts 0 .. NITER (the host compiler's IEEE quotients)
+__constant__ const double MASK_STEP_FRACTION[NITER + 1] = {0.0 / NITER, 1.0 / NITER, 2.0 / NITER, 3.0 / NITER, 4.0 / NITER, 5.0 / NITER,
+                                                           6.0 / NITER, 7.0 / NITER, 8.0 / NITER, 9.0 / NITER, 10.0 / NITER};
+static_assert(NITER == 10, "MASK_STEP_FRACTION lists NITER + 1 quotients");
 
 // inclusive prefix sum over the wave: Hillis-Steele inside each row of 16 (DPP row_shr), row totals by readlane
 __device__ __forceinline__ int wave_incl_scan_i(int x, int lane) {
@@ -742,13 +771,10 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     double x = st[0], y = st[1], h = st[2], accum = st[3];
     const double prev_x = x, prev_y = y, prev_h = h;      // prev_state (car_parking_base.py:255)
     int t = p.tstep[scene];
+    double ct = 0, sn = 0;       // cos/sin of the final heading
+    if (PART == 2) { ct = p.cs[2 * (size_t)scene]; sn = p.cs[2 * (size_t)scene + 1]; }   // hm_sincos(h) as the motion launch computed it
     wsync();
 
-    double ct = 0, sn = 0;       // cos/sin of the final heading
-    if (PART == 2) {             // the pose PART 1 left behind (after a turnover: the start pose)
-        hm_sincos(h, &sn, &ct);
-        if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;
-    }
     if (PART != 2) {
     bool arrive = false, moved = false;
     bool known_free = false;     // final pose already passed _detect_collision in the sub-step loop
@@ -767,7 +793,6 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     } else if (moving)
         n_near = stage_near(obb_s, src, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), tile, nlist, lane);
     else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
-    if (lane < UPS) scr[LDS_W2 + lane] = (double)lane / UPS;      // (j % 10) / 10 of _linear_interpolate
     wsync();
     ST_T(0);
 
@@ -992,6 +1017,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     // ---- write state + scalar outputs ---------------------------------------------------------------
     if (lane == 0) {
         st[0] = x; st[1] = y; st[2] = h; st[3] = accum;
+        if (PART == 1) { p.cs[2 * (size_t)scene] = ct; p.cs[2 * (size_t)scene + 1] = sn; }
         p.tstep[scene] = t;
         if (p.hflags & STEP_HF_TRAJ) {
             // vehicle.trajectory: of the sub-step states only the last kept one stays (car_parking_base.py:259-276,
@@ -1159,7 +1185,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 const float x2 = (float)dx2, y2 = (float)dy2;
                 // (t2 is the NEXT vertex's t1: the same atan2f on the same floats, computed by the next lane of the ring's quad -- a
                 // quad rotation instead of a second ~30-instruction evaluation; the step is VALU-issue bound)
-                const float t1 = atan2f(y1, x1);
+                const float t1 = span_angle(y1, x1);
                 const float t2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t1), 0x39, 0xf, 0xf, true));   // quad_perm [1,2,3,0]
                 float dth = t2 - t1;
                 if (dth > 3.14159265f) dth -= 6.28318531f;
@@ -1174,12 +1200,14 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                     if (ts < 0) ts += 6.28318531f;
                     // beams i with theta_i = i PITCH inside [ts - MARGIN, ts + span + MARGIN]; none when the edge is seen
                     // between two beams (float32 rounding of the quotients: ~1e-5 of a pitch, far inside the margin)
-                    const int ilo = (int)ceilf((ts - MARGIN) / PITCH);
-                    const int ihi = (int)floorf((ts + span + MARGIN) / PITCH);
+                    // (products with the rounded 1 / PITCH instead of quotients: one more ulp, 1e-5 of a pitch again)
+                    const int ilo = (int)ceilf((ts - MARGIN) * (1.0f / PITCH));
+                    const int ihi = (int)floorf((ts + span + MARGIN) * (1.0f / PITCH));
                     cnt = ihi - ilo + 1;
                     if (cnt < 0) cnt = 0;
                     if (cnt > NBEAM) cnt = NBEAM;
-                    lo = ((ilo % NBEAM) + NBEAM) % NBEAM;
+                    lo = ilo < 0 ? ilo + NBEAM : ilo >= NBEAM ? ilo - NBEAM : ilo;     // ts in [0, 2 pi]: ilo in [-1, NBEAM]
+                    if ((unsigned)lo >= (unsigned)NBEAM) { lo = 0; cnt = NBEAM; }       // (cannot happen; all beams if it does)
                 }
                 // ---- back-face cull.  A beam that crosses a BACK edge of a convex ring seen from outside has entered the ring
                 // through a front edge first, nearer to the sensor: if that nearer hit is certain to pass the reference's tests
@@ -1198,7 +1226,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
                 front = decisive && (left != ((fl & OBST_F_CCW) != 0));          // CCW ring: the inside is on the left
                 back = decisive && !front;
                 const float q1 = t1 * (1.0f / PITCH);
-                const bool near_beam = fabsf(q1 - rintf(q1)) * PITCH <= 2.0e-4f + 4e-6f;     // this edge's first vertex vs the beam directions
+                const bool near_beam = fabsf(q1 - rintf(q1)) * PITCH <= 2.0e-4f + 1e-5f;     // this edge's first vertex vs the beam directions
                 const bool thin = front && (fabs(dx2 - dx1) < 1e-4 || fabs(dy2 - dy1) < 1e-4);
                 risky = wild || !decisive || near_beam || thin || !(fl & OBST_F_CONVEX);
             }
@@ -1365,7 +1393,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
             bool act = false;
             if (l < NL) {
                 int i = l / UPS, j = l % UPS;
-                double w2 = scr[LDS_W2 + j], w1 = 1 - w2;
+                double w2 = (double)j / UPS, w1 = 1 - w2;      // (j % 10) / 10 of _linear_interpolate
                 dl = xs[i] * w1 + xs[i + 1] * w2;                 // _linear_interpolate (:161-162)
                 act = dl < p.pmax[l];
             }
@@ -1400,7 +1428,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
         mn = min(mn, o);
     }
     mn = max(0, min(NITER, mn));
-    double mo = (double)mn / NITER;
+    double mo = MASK_STEP_FRACTION[mn];                           // mn / n_iter (a float64 division per scene otherwise)
     unsigned long long nz = __ballot(lane < NACT && mn > 0);
     if (nz == 0) mo = clipd(mo, 0.01, 1);                          // all-zero -> 0.01 (:182-183)
     if (lane < NACT) ((OT*)p.action_mask)[(size_t)NACT * scene + lane] = (OT)mo;
