@@ -585,6 +585,7 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
                                                   const uint8_t* active, uint32_t stages, const double* scene_c, double* kin) {
     // n entries of scene_list (a tile class's dense list: the kinematics head each class's launch chain), or scenes 0..n-1
     __shared__ double buf[KIN_SCENES_PER_BLOCK * KIN_WORDS];
+    __shared__ double terms[MINI_ITER][2 * KIN_SCENES_PER_BLOCK];   // one round's displacement terms: [micro-step][2 scene + (x | y)]
     __shared__ int sid[KIN_SCENES_PER_BLOCK];
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
     const int idx = blockIdx.x * KIN_SCENES_PER_BLOCK + ls;
@@ -594,7 +595,14 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
     if (q == 0) sid[ls] = live ? scene : -1;
     const int sc_ = live ? scene : 0;
     const double* st = state + (size_t)sc_ * ST_WORDS;
-    double x = st[0], y = st[1], h = st[2];
+    double h = st[2];
+    // the position sums live one per lane: lane 2 s + c (< 32) owns x (c = 0) or y (c = 1) of the block's scene s
+    double acc = 0.0;
+    if (lane < 2 * KIN_SCENES_PER_BLOCK) {
+        const int idx2 = blockIdx.x * KIN_SCENES_PER_BLOCK + (lane >> 1);
+        const int sc2 = idx2 < n ? (scene_list ? scene_list[idx2] : idx2) : 0;
+        acc = state[(size_t)sc2 * ST_WORDS + (lane & 1)];
+    }
     const AT* act = (const AT*)actions;
     const double a0 = (double)act[2 * (size_t)sc_], a1 = (double)act[2 * (size_t)sc_ + 1];
     double steer = a0, speed = a1;
@@ -618,6 +626,10 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
     // ONE dependent sincos chain per round of four micro-steps, 50 rounds).  Same values, same order of every sum.  Measured:
     // 0.0759 -> 0.0731 ms per step for the two launches, the step itself unchanged -- with three waves per SIMD the class-0 launch
     // is bound by its ~5 500 vector instructions per wave (200 sincos per scene), not by their latency.
+    // The sums x += ..., y += ... (vehicle.py:90-91, strictly in micro-step order) are NOT formed in every lane of the quad from
+    // quad broadcasts (8 additions + 16 DPP moves per micro-step group and wave, a quarter of the kernel's vector instructions; the
+    // step is VALU-issue bound): the round's 20 x 2 terms per scene go through LDS and 32 lanes -- one per (scene, coordinate) --
+    // add them in order, 20 additions per round and wave.
     constexpr int KJ = MINI_ITER / 4;
     static_assert(MINI_ITER % 4 == 0, "micro-steps per lane and round");
 #pragma unroll 1
@@ -630,25 +642,27 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
         for (int j = 0; j < KJ; j++) hm_sincos(hj[j], &sj[j], &cj[j]);
         if (q == 0 && r > 0) {                               // lane 0 sits on a sub-step boundary: h_{20 r}
             const int k = r - 1;
-            out[k] = hj[0]; out[10 + k] = cj[0]; out[20 + k] = sj[0]; out[30 + k] = x; out[40 + k] = y;
+            out[k] = hj[0]; out[10 + k] = cj[0]; out[20 + k] = sj[0];
         }
 #pragma unroll
         for (int j = 0; j < KJ; j++) {
-            const double tx = div_by_20(speed * cj[j] * STEP_LENGTH);      // ... / MINI_ITER, correctly rounded (below)
-            const double ty = div_by_20(speed * sj[j] * STEP_LENGTH);
-            // x += ..., y += ... in micro-step order (vehicle.py:90-91): quad broadcasts through DPP (no LDS round trip)
-            x += quad_bcast<0>(tx); y += quad_bcast<0>(ty);
-            x += quad_bcast<1>(tx); y += quad_bcast<1>(ty);
-            x += quad_bcast<2>(tx); y += quad_bcast<2>(ty);
-            x += quad_bcast<3>(tx); y += quad_bcast<3>(ty);
+            terms[4 * j + q][2 * ls] = div_by_20(speed * cj[j] * STEP_LENGTH);      // ... / MINI_ITER, correctly rounded (below)
+            terms[4 * j + q][2 * ls + 1] = div_by_20(speed * sj[j] * STEP_LENGTH);
         }
+        wsync();
+        if (lane < 2 * KIN_SCENES_PER_BLOCK) {
+#pragma unroll
+            for (int m = 0; m < MINI_ITER; m++) acc += terms[m][lane];            // x += ..., y += ... in micro-step order
+            buf[(lane >> 1) * KIN_WORDS + 30 + 10 * (lane & 1) + r] = acc;        // the position after sub-step r + 1
+        }
+        wsync();
         h = hj[KJ - 1];
         h = h + dh; h = h + dh; h = h + dh; h = h + dh;      // four steps of the sequential chain
     }
     if (q == 0) {                                            // after micro-step 199: the 10th sub-step pose
         double s_, c_;
         hm_sincos(h, &s_, &c_);
-        out[9] = h; out[19] = c_; out[29] = s_; out[39] = x; out[49] = y;
+        out[9] = h; out[19] = c_; out[29] = s_;
     }
     __syncthreads();
     {   // the slab bound of the arrival test (arrival_possible) for the ten poses: lane q takes poses q, q + 4, q + 8.  In
