@@ -49,6 +49,7 @@ struct hope_env {
     double* beam_ab = nullptr;
     int32_t* rs_count = nullptr;
     int32_t* rs_list = nullptr;
+    double* rs_in = nullptr;      // [2 n][RS_IN_WORDS] search inputs by queue position (k_rs_compact -> k_rs_words / k_rs_segs)
     uint8_t* rs_flag = nullptr;
     double* kin = nullptr;
     double* post = nullptr;        // [n][POST_WORDS] k_env_step -> k_post hand-over
@@ -386,7 +387,7 @@ template <typename OT>
 __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* list, int n, uint8_t* flag, const uint8_t* active,
                                                                  int32_t* out, int32_t* rs_count, const double* post,
                                                                  const double* scene_c, int8_t* rs_word, void* rs_lengths, const int32_t* n_obst,
-                                                                 int32_t* surv_count) {
+                                                                 int32_t* surv_count, double* rs_in) {
     __shared__ int wsum[COMPACT_THREADS / WAVE];
     __shared__ int base;
     if (surv_count && blockIdx.x == 0 && threadIdx.x == 0) *surv_count = 0;    // k_rs_screen's queue of this chain (same stream, behind the last walk)
@@ -422,11 +423,18 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
     for (int w = 0; w < COMPACT_THREADS / WAVE; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
     if (threadIdx.x == 0) base = total ? atomicAdd(rs_count, total) : 0;
     __syncthreads();
-#ifdef HOPE_RS_NOPACK
-    if (gate) out[base + woff + before] = s;
-#else
-    if (gate) out[base + woff + before] = rs_list_pack(s, n_obst[s]);               // (hope_internal.h)
-#endif
+    if (gate) {
+        const int qpos = base + woff + before;
+        out[qpos] = rs_list_pack(s, n_obst[s]);                                     // (hope_internal.h)
+        // the search's inputs by queue position (RS_IN_WORDS): the pose is the finished step's final pose (CONTINUE: also what
+        // `state` holds), so nothing behind this kernel on the search stream reads `state` / `post` / the scene constants
+        const double* pr = post + (size_t)s * POST_WORDS;
+        const double* sc = scene_c + (size_t)s * SC_WORDS;
+        double* in = rs_in + (size_t)qpos * RS_IN_WORDS;
+        in[0] = pr[3]; in[1] = pr[4]; in[2] = pr[5];
+        in[3] = sc[SC_DEST]; in[4] = sc[SC_DEST + 1]; in[5] = sc[SC_DEST + 2];
+        in[6] = sc[SC_BBOX]; in[7] = sc[SC_BBOX + 1]; in[8] = sc[SC_BBOX + 2]; in[9] = sc[SC_BBOX + 3];
+    }
 }
 
 // one block per uploaded scene: copy its obstacle tile
@@ -534,6 +542,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
     ALLOC(h->rs_count, 2 * hope_env::MAX_CHAINS * sizeof(int32_t));
     ALLOC(h->rs_list, 2 * N * sizeof(int32_t));
+    ALLOC(h->rs_in, 2 * N * RS_IN_WORDS * sizeof(double));
     ALLOC(h->rs_flag, N);
     ALLOC(h->kin, N * KIN_WORDS * sizeof(double));
     ALLOC(h->post, N * POST_WORDS * sizeof(double));
@@ -578,6 +587,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipMemset(h->rs_flag, 0, N));
     HIPCHK(hipMemset(h->rs_surv_count, 0, hope_env::MAX_CHAINS * sizeof(int32_t)));
     HIPCHK(hipMemset(h->rs_surv, 0, 2 * N * sizeof(int2)));
+    HIPCHK(hipMemset(h->rs_in, 0, 2 * N * RS_IN_WORDS * sizeof(double)));
     HIPCHK(hipMemset(h->rs_list, 0, 2 * N * sizeof(int32_t)));      // (k_rs_words / k_rs_segs read queue entries before they know the queue length)
     HIPCHK(hipMemset(h->cur_pool, 0xFF, N * sizeof(int32_t)));
     HIPCHK(hipMemset(h->episode, 0, N * sizeof(uint32_t)));
@@ -769,7 +779,7 @@ static int destroy_impl(hope_env_t* h) {                   // (also the clean-up
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
     void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->cs, h->tstep, h->tab, h->pmax,
-                    h->hull_base, h->beam_ab, h->rs_count, h->rs_surv_count, h->rs_surv, h->rs_list, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
+                    h->hull_base, h->beam_ab, h->rs_count, h->rs_surv_count, h->rs_surv, h->rs_list, h->rs_in, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete h;
@@ -1151,15 +1161,22 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
             HIPCHK(hipEventRecord(h->ev_post[i], sc));
         }
         int32_t* qlist = h->rs_list + (size_t)c * h->n + ch.a;       // this chain's part of the class's queue storage
+        double* rs_in = h->rs_in + ((size_t)c * h->n + ch.a) * RS_IN_WORDS;      // ... and of the search inputs, same index
         if (tm) tm->begin(HOPE_K_RS_COMPACT, sc);
         {
             const dim3 cg((p.n_list + COMPACT_THREADS - 1) / COMPACT_THREADS);
             if (of64) hipLaunchKernelGGL(k_rs_compact<double>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
-                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst, h->rs_surv_count + i);
+                                         counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst, h->rs_surv_count + i, rs_in);
             else hipLaunchKernelGGL(k_rs_compact<float>, cg, dim3(COMPACT_THREADS), 0, sc, p.scene_list, p.n_list, h->rs_flag, active_rs, qlist,
-                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst, h->rs_surv_count + i);
+                                    counter, (const double*)h->post, (const double*)h->scene_c, out->rs_word, out->rs_lengths, (const int32_t*)h->n_obst, h->rs_surv_count + i, rs_in);
         }
         if (tm) tm->end(sc);
+        // pipelined steps: the next step's motion launch rewrites `state` / `post` (and, on an episode turnover, the scene constants),
+        // which k_post and k_rs_compact are the last to read -- k_rs_words / k_rs_segs work from k_rs_compact's rows (RS_IN_WORDS).
+        // (Rounds 4-5a waited for k_rs_segs: at small batches the step's critical cycle was motion -> compact -> words -> segs ->
+        // motion; HOPE_PIPE_AFTER=segs restores that for A/B runs.)
+        static const bool after_segs = getenv("HOPE_PIPE_AFTER") && !strcmp(getenv("HOPE_PIPE_AFTER"), "segs");
+        if (pipe && !after_segs) HIPCHK(hipEventRecord(h->ev_segs[i], sc));
         RsParams r;
         r.n = h->n; r.max_obst = h->max_obst; r.obs_f64 = of64;
         static const int prio_front = getenv("HOPE_PRIO_FRONT") ? atoi(getenv("HOPE_PRIO_FRONT")) : 0;
@@ -1170,12 +1187,12 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         r.slot_dir = (c == 0) ? 1 : -1;
         r.verts = h->verts; r.obb = h->obb; r.n_obst = h->n_obst; r.scene_c = h->scene_c; r.state = h->state;
         r.fverts = h->fverts; r.fbox = h->fbox; r.eflag = h->eflag;
-        r.rs_count = counter; r.rs_list = qlist;
+        r.rs_count = counter; r.rs_list = qlist; r.rs_in = rs_in;
         r.rs_rec = h->rs_rec;
         r.surv_count = h->rs_surv_count + i;
         r.surv_list = h->rs_surv + (size_t)c * h->n + ch.a;
         r.rs_word = out->rs_word; r.rs_lengths = out->rs_lengths;
-        HIPCHK(launch_rs_search(r, sc, tm, pipe ? h->ev_segs[i] : nullptr));
+        HIPCHK(launch_rs_search(r, sc, tm, (pipe && after_segs) ? h->ev_segs[i] : nullptr));
     }
     HIPCHK(hipGetLastError());
     if (stages & HOPE_STAGE_IMG) {

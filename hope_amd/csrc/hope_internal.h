@@ -35,6 +35,11 @@ __host__ __device__ inline int rs_list_n_obst(int entry) { return (int)((unsigne
 //       table 0 also carries cos / sin(-pose heading) in the spare words [15], [23];
 //       then 5 x 2 doubles = 5 x 4 floats for the float32 filter of k_rs_validate: per segment the origin in the frame
 //       "world minus (map box xmin, ymin)" [m] (the frame of the scene's float32 obstacle view) and cos / sin of the WORLD heading at the origin
+// Per queued search, written by k_rs_compact next to the queue entry (same index): everything k_rs_words / k_rs_segs need from the
+// step's state -- pose x, y, heading (the finished step's final pose), dest x, y, heading, map box xmin, xmax, ymin, ymax -- so that the
+// search chain behind k_rs_compact reads nothing the NEXT step's motion launch rewrites (`state`, `post`, and on an episode turnover the
+// scene constants): pipelined steps only wait for k_rs_compact, and the front kernels start without the queue entry -> scene round trip.
+constexpr int RS_IN_WORDS = 10;
 constexpr int RS_REC_HDR = 16;
 constexpr int RS_REC_ORDER = 10;
 constexpr int RS_REC_KEYS = RS_REC_HDR;
@@ -58,6 +63,7 @@ struct RsParams {
     const int32_t* n_obst;    // [n]
     const double* scene_c;    // [n][SC_WORDS]
     const double* state;      // [n][ST_WORDS]
+    const double* rs_in;      // [max_queue][RS_IN_WORDS] search inputs by queue position (k_rs_compact)
     const int32_t* rs_count;  // [1]
     const int32_t* rs_list;   // [n]
     double* rs_rec;           // [n][RS_REC_DOUBLES] one record per queued scene (slot), see RS_REC_*

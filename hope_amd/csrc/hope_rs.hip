@@ -393,17 +393,15 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     set_wave_prio(p.prio_front);
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
     const int qi = blockIdx.x * RSA_SCENES + ls;
-    // the queue entry is requested BEFORE the queue length is known (one memory round trip less): entries at or beyond the count
-    // are stale or zero (hope_env_create clears the list) -- valid scene numbers either way, and lanes without work store nothing
-    const int scene = rs_list_scene(p.rs_list[qi < p.max_queue ? qi : p.max_queue - 1]);      // (entry = scene << 8 | n_obst, k_rs_compact)
+    // the search's inputs are requested BEFORE the queue length is known (one memory round trip less): k_rs_compact wrote them by
+    // queue position, rows at or beyond the count are stale or zero (hope_env_create clears them) and lanes without work store nothing
+    const double* in = p.rs_in + (size_t)(qi < p.max_queue ? qi : p.max_queue - 1) * RS_IN_WORDS;
+    const double q0x = in[0], q0y = in[1], q0w = in[2];
+    const double gx = in[3], gy = in[4], gw = in[5];
     const int count = *p.rs_count;
     if ((int)blockIdx.x * RSA_SCENES >= count) return;
     const bool live = qi < count;
     const int slot = p.slot_base + p.slot_dir * (live ? qi : 0);
-    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
-    const double* st = p.state + (size_t)scene * ST_WORDS;
-    const double q0x = st[0], q0y = st[1], q0w = st[2];
-    const double gx = sc[SC_DEST], gy = sc[SC_DEST + 1], gw = sc[SC_DEST + 2];
 
     // ---- generate_path (:540-557): normalise the goal into the start frame ------------------------
     double X, Y, PHI;
@@ -534,13 +532,12 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     double keyv[RS_WORDS_PER_SCENE / 8];
 #pragma unroll
     for (int j = 0; j < RS_WORDS_PER_SCENE / 8; j++) keyv[j] = live ? rec[RS_REC_KEYS + 8 * j + k0] : -1.0;
-    const double* st = p.state + (size_t)scene * ST_WORDS;
-    // the header's inputs, requested now: they arrive while lane 0 replays the heap
-    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+    // the header's inputs (k_rs_compact's row of this queue position), requested now: they arrive while lane 0 replays the heap
+    const double* in = p.rs_in + (size_t)qs * RS_IN_WORDS;
     double hdr = 0.0;                                       // lanes k0 = 0 .. 6 of a search: pose x, y, heading, map box
     int hdr_n = 0;
-    if (k0 < 3) hdr = st[k0];
-    else if (k0 < 7) hdr = sc[SC_BBOX + k0 - 3];
+    if (k0 < 3) hdr = in[k0];
+    else if (k0 < 7) hdr = in[6 + k0 - 3];
     else hdr_n = rs_list_n_obst(entry);      // the obstacle count k_rs_compact read
     // the kept candidates of the search as a bit mask (bit c = candidate slot c): eight lanes x six keys, one ballot per stride
     unsigned long long keptm = 0;
