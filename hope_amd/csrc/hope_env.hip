@@ -462,12 +462,12 @@ __global__ void k_set_scene_tiles(const int32_t* ids, const int32_t* nob, const 
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-template <int PART>
+template <int PART, bool FKIN = false>
 static void launch_env_step(bool of64, bool af64, dim3 grid, dim3 block, size_t lds, hipStream_t sc, const StepParams& p) {
-    if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double, false, PART>), grid, block, lds, sc, p);
-    else if (of64) hipLaunchKernelGGL((k_env_step<double, float, false, PART>), grid, block, lds, sc, p);
-    else if (af64) hipLaunchKernelGGL((k_env_step<float, double, false, PART>), grid, block, lds, sc, p);
-    else hipLaunchKernelGGL((k_env_step<float, float, false, PART>), grid, block, lds, sc, p);
+    if (of64 && af64) hipLaunchKernelGGL((k_env_step<double, double, false, PART, FKIN>), grid, block, lds, sc, p);
+    else if (of64) hipLaunchKernelGGL((k_env_step<double, float, false, PART, FKIN>), grid, block, lds, sc, p);
+    else if (af64) hipLaunchKernelGGL((k_env_step<float, double, false, PART, FKIN>), grid, block, lds, sc, p);
+    else hipLaunchKernelGGL((k_env_step<float, float, false, PART, FKIN>), grid, block, lds, sc, p);
 }
 
 extern "C" {
@@ -613,6 +613,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         for (const void* f : {(const void*)k_env_step<float, float>, (const void*)k_env_step<float, float, true>,
                               (const void*)k_env_step<float, double>, (const void*)k_env_step<double, float>,
                               (const void*)k_env_step<double, double>,
+                              (const void*)k_env_step<float, float, false, 0, true>, (const void*)k_env_step<float, double, false, 0, true>,
+                              (const void*)k_env_step<double, float, false, 0, true>, (const void*)k_env_step<double, double, false, 0, true>,
                               (const void*)k_env_step<float, float, false, 1>, (const void*)k_env_step<float, double, false, 1>,
                               (const void*)k_env_step<double, float, false, 1>, (const void*)k_env_step<double, double, false, 1>,
                               (const void*)k_env_step<float, float, false, 2>, (const void*)k_env_step<float, double, false, 2>,
@@ -980,7 +982,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     p.n = h->n; p.max_obst = h->max_obst; p.stages = stages | dbg_stages; p.has_action = has_action;
     p.hflags = h->traj ? STEP_HF_TRAJ : 0;
     p.verts = h->verts; p.obb = h->obb; p.eflag = h->eflag; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.cs = h->cs; p.tstep = h->tstep;
-    p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.post = h->post;
+    p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.actions = actions; p.post = h->post;
     p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.lidar = out->lidar; p.action_mask = out->action_mask;
     p.cold = h->cold_dev + h->cold_idx;                     // (sync_cold ran on the caller's stream before any launch of this step)
@@ -1113,7 +1115,14 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         p.rs_count_zero = want_rs ? counter : nullptr;
         if (order_mode >= 2 && fork && n_chain == 2 && i == 1 && (split || (stages & HOPE_STAGE_IMG)))
             HIPCHK(hipStreamWaitEvent(sc, h->ev_step[0], 0));   // staggered: behind the first chain's motion launch
-        if ((stages & HOPE_STAGE_MOTION) && has_action) {       // this class's sub-step poses head its chain
+        // one-launch form (small batches): the step kernel's waves compute their scene's sub-step poses themselves -- the step is a
+        // chain of launch latencies there, and the kinematics launch cost the critical stream ~16 us plus a launch gap
+        // Only where the GPU is far from full: the wave-per-scene form spends ~2x the vector instructions of k_kinematics' four
+        // lanes per scene (measured, steady ms per step, fused / separate: 4 096 scenes 0.152 / 0.156, 8 192 0.186 / 0.176,
+        // 16 384 0.249 / 0.222).  HOPE_FUSE_KIN = largest batch that takes it (0: never).
+        static const int fuse_kin_max = getenv("HOPE_FUSE_KIN") ? atoi(getenv("HOPE_FUSE_KIN")) : 4096;
+        const bool fuse_kin = h->n <= fuse_kin_max && !split && !step_timing;
+        if ((stages & HOPE_STAGE_MOTION) && has_action && !fuse_kin) {       // this class's sub-step poses head its chain
             dim3 kg((p.n_list + KIN_SCENES_PER_BLOCK - 1) / KIN_SCENES_PER_BLOCK);
             if (tm) tm->begin(HOPE_K_KINEMATICS, sk);
             if (af64) hipLaunchKernelGGL((k_kinematics<double>), kg, block, 0, sk, p.n_list, p.scene_list, h->state, actions, active, stages, h->scene_c, h->kin);
@@ -1128,6 +1137,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (tm) tm->begin(HOPE_K_STEP, sk);
         if (split) launch_env_step<1>(of64, af64, grid, block, lds, sk, p);
         else if (step_timing && !of64 && !af64) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sk, p);
+        else if (fuse_kin) launch_env_step<0, true>(of64, af64, grid, block, lds, sk, p);
         else launch_env_step<0>(of64, af64, grid, block, lds, sk, p);
         if (tm) tm->end(sk);
         if (fork && n_chain == 2 && (split || pipe || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sk));   // poses final

@@ -169,6 +169,7 @@ struct StepParams {
     double* state;            // [n][ST_WORDS]
     double* cs;               // [n][2] cos / sin of the heading the motion launch left in state (read by the observation launch)
     int32_t* tstep;           // [n]
+    const void* actions;      // [n][2] (AT) this step's actions: read by the wave's own kinematics (FKIN), else by k_kinematics
     double* kin;              // [n][50] sub-step poses from k_kinematics: h[10] cos[10] sin[10] x[10] y[10]
     const uint8_t* active;    // [n] or null (the caller's mask: only read by launches the caller's stream is ordered after)
     uint8_t* active_out;      // [n] or null: the motion launch snapshots the mask here for the Reeds-Shepp chain (k_rs_compact), which
@@ -580,6 +581,28 @@ __device__ __forceinline__ double div_by_20(double x) {
     return copysign(fma(r, R, q0), x);                   // (the quotient has x's sign; the fma chain turns -0 into +0)
 }
 
+// action_rescale (env_wrapper.py:37-50) + KSModel's clip (vehicle.py:85-86): the speed and the heading increment per micro-step
+template <typename AT>
+__device__ __forceinline__ void kin_controls(const void* actions, int scene, uint32_t stages, double& speed, double& dh) {
+    const AT* act = (const AT*)actions;
+    const double a0 = (double)act[2 * (size_t)scene], a1 = (double)act[2 * (size_t)scene + 1];
+    double steer = a0;
+    speed = a1;
+    if (!(stages & HOPE_ACTION_PHYSICAL)) {
+        if (sizeof(AT) == 4 && (stages & HOPE_ACTION_RESCALE_F32)) {          // float32 Box arithmetic, term by term
+            const float f0 = fminf(fmaxf((float)a0, -1.0f), 1.0f), f1 = fminf(fmaxf((float)a1, -1.0f), 1.0f);
+            steer = (double)(f0 * ((float)STEER_HI - (float)STEER_LO) / 2.0f + ((float)STEER_HI + (float)STEER_LO) / 2.0f);
+            speed = (double)(f1 * ((float)SPEED_HI - (float)SPEED_LO) / 2.0f + ((float)SPEED_HI + (float)SPEED_LO) / 2.0f);
+        } else {
+            steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
+            speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
+        }
+    }
+    speed = clipd(speed, SPEED_LO, SPEED_HI);
+    steer = clipd(steer, STEER_LO, STEER_HI);
+    dh = speed * hm_tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
+}
+
 template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_list, const double* state, const void* actions,
                                                   const uint8_t* active, uint32_t stages, const double* scene_c, double* kin) {
@@ -603,22 +626,8 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
         const int sc2 = idx2 < n ? (scene_list ? scene_list[idx2] : idx2) : 0;
         acc = state[(size_t)sc2 * ST_WORDS + (lane & 1)];
     }
-    const AT* act = (const AT*)actions;
-    const double a0 = (double)act[2 * (size_t)sc_], a1 = (double)act[2 * (size_t)sc_ + 1];
-    double steer = a0, speed = a1;
-    if (!(stages & HOPE_ACTION_PHYSICAL)) {
-        if (sizeof(AT) == 4 && (stages & HOPE_ACTION_RESCALE_F32)) {          // float32 Box arithmetic, term by term
-            const float f0 = fminf(fmaxf((float)a0, -1.0f), 1.0f), f1 = fminf(fmaxf((float)a1, -1.0f), 1.0f);
-            steer = (double)(f0 * ((float)STEER_HI - (float)STEER_LO) / 2.0f + ((float)STEER_HI + (float)STEER_LO) / 2.0f);
-            speed = (double)(f1 * ((float)SPEED_HI - (float)SPEED_LO) / 2.0f + ((float)SPEED_HI + (float)SPEED_LO) / 2.0f);
-        } else {
-            steer = clipd(a0, -1, 1) * (STEER_HI - STEER_LO) / 2 + (STEER_HI + STEER_LO) / 2;
-            speed = clipd(a1, -1, 1) * (SPEED_HI - SPEED_LO) / 2 + (SPEED_HI + SPEED_LO) / 2;
-        }
-    }
-    speed = clipd(speed, SPEED_LO, SPEED_HI);
-    steer = clipd(steer, STEER_LO, STEER_HI);
-    const double dh = speed * hm_tan(steer) / WHEEL_BASE * STEP_LENGTH / MINI_ITER;
+    double speed, dh;
+    kin_controls<AT>(actions, sc_, stages, speed, dh);
     double* out = buf + ls * KIN_WORDS;
     for (int i = 0; i < q; i++) h = h + dh;                  // lane q starts at micro-step q
     // Round r = sub-step r: its 20 micro-steps 20 r + 4 j + q, j = 0 .. 4, FIVE per lane.  The five headings of a lane (four steps
@@ -701,6 +710,89 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same kinematics by the scene's OWN wave: the one-launch form of the step kernel at small batches (k_env_step<.., PART 0,
+// FKIN>), where the step is a chain of launch latencies and a separate kinematics launch costs the critical stream its ~16 us
+// plus the gap to the next launch.  Same values as k_kinematics, bit for bit: lane L walks the SAME sequential heading chain to the
+// micro-steps m = L + 64 i (i = 0 .. 3, m <= 200: 255 dependent additions, ~1 us, instead of 200 in each of 4 lanes), evaluates
+// sincos and the displacement terms of its (at most four) micro-steps, and lanes 0 / 1 add the x / y terms in micro-step order from
+// LDS (two phases of 128 and 72 micro-steps in region A).  The sub-step poses land where the motion part reads them
+// (scr[LDS_HB ..]: h cos sin x y of poses 0 .. 9); returns arrival_possible's bits and the box around the step's hulls.
+// ------------------------------------------------------------------------------------------------------------
+template <typename AT>
+__device__ __forceinline__ void wave_kinematics(const void* actions, int scene, uint32_t stages, double x0, double y0, double h0,
+                                                const double* sc, double* scr, int lane, int& apmask, double (&kb)[4]) {
+    double speed, dh;
+    kin_controls<AT>(actions, scene, stages, speed, dh);
+    constexpr int NM = NUM_STEP * MINI_ITER;             // 200 micro-steps; heading h_m is the one micro-step m starts from
+    constexpr int NJ = (NM + WAVE) / WAVE;               // micro-steps per lane (the last one also covers m = NM, the final heading)
+    static_assert(NJ == 4 && NM % WAVE < WAVE, "lane L owns micro-steps L + 64 i");
+    double hm[NJ], sm[NJ], cm[NJ];
+    {
+        double hh = h0;
+        for (int i = 0; i < lane; i++) hh = hh + dh;      // h_L
+        hm[0] = hh;
+#pragma unroll
+        for (int j = 1; j < NJ; j++) {
+#pragma unroll 8
+            for (int i = 0; i < WAVE; i++) hh = hh + dh;
+            hm[j] = hh;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) hm_sincos(hm[j], &sm[j], &cm[j]);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {                        // the sub-step boundaries m = 20 (k + 1): pose k's heading, cos, sin
+        const int m = lane + WAVE * j;
+        if (m >= MINI_ITER && m <= NM && m % MINI_ITER == 0) {
+            const int k = m / MINI_ITER - 1;
+            scr[LDS_HB + k] = hm[j]; scr[LDS_CB + k] = cm[j]; scr[LDS_SB + k] = sm[j];
+        }
+    }
+    double acc = lane == 0 ? x0 : y0;                     // lane 0: x, lane 1: y
+#pragma unroll
+    for (int ph = 0; ph < 2; ph++) {                      // micro-steps [0, 128) and [128, 200): 2 x 128 doubles of region A
+        wsync();
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int j = 2 * ph + jj, m = lane + WAVE * j;
+            if (m < NM) {
+                scr[2 * (m - 2 * WAVE * ph)] = div_by_20(speed * cm[j] * STEP_LENGTH);       // ... / MINI_ITER, correctly rounded
+                scr[2 * (m - 2 * WAVE * ph) + 1] = div_by_20(speed * sm[j] * STEP_LENGTH);
+            }
+        }
+        wsync();
+        if (lane < 2) {
+            const int m_end = ph == 0 ? 2 * WAVE : NM;
+#pragma unroll 4
+            for (int m = 2 * WAVE * ph; m < m_end; m++) {
+                acc += scr[2 * (m - 2 * WAVE * ph) + lane];                                   // x += ..., y += ... (vehicle.py:90-91)
+                if ((m + 1) % MINI_ITER == 0) scr[LDS_PX + NUM_STEP * lane + (m + 1) / MINI_ITER - 1] = acc;
+            }
+        }
+    }
+    wsync();
+    // arrival_possible of the ten poses, the box around the hulls of the start pose and the ten poses: lane k = pose k, lane 10 = start
+    const double c_0 = readlane_d(cm[0], 0), s_0 = readlane_d(sm[0], 0);                      // heading h_0 = the start heading
+    const bool pose = lane < NUM_STEP;
+    const int kk = pose ? lane : 0;
+    const double px = pose ? scr[LDS_PX + kk] : x0, py = pose ? scr[LDS_PY + kk] : y0;
+    const double pc = pose ? scr[LDS_CB + kk] : c_0, ps = pose ? scr[LDS_SB + kk] : s_0;
+    const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
+    apmask = (int)(__ballot(pose && arrival_possible(px, py, pc, ps, dcx, dcy, dcd, dsd)) & ((1ull << NUM_STEP) - 1));
+    const Box b = make_box(px, py, pc, ps);
+    const bool in = lane <= NUM_STEP;
+    double bx0 = in ? fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3])) : INFINITY, bx1 = in ? fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3])) : -INFINITY;
+    double by0 = in ? fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3])) : INFINITY, by1 = in ? fmax(fmax(b.y[0], b.y[1]), fmax(b.y[2], b.y[3])) : -INFINITY;
+    // lanes 0 .. 15: quad, then the row's halves and the mirrored row (DPP)
+    bx0 = fmin(bx0, dpp_d<0xB1>(bx0)); bx0 = fmin(bx0, dpp_d<0x4E>(bx0)); bx0 = fmin(bx0, dpp_d<0x141>(bx0)); bx0 = fmin(bx0, dpp_d<0x140>(bx0));
+    bx1 = fmax(bx1, dpp_d<0xB1>(bx1)); bx1 = fmax(bx1, dpp_d<0x4E>(bx1)); bx1 = fmax(bx1, dpp_d<0x141>(bx1)); bx1 = fmax(bx1, dpp_d<0x140>(bx1));
+    by0 = fmin(by0, dpp_d<0xB1>(by0)); by0 = fmin(by0, dpp_d<0x4E>(by0)); by0 = fmin(by0, dpp_d<0x141>(by0)); by0 = fmin(by0, dpp_d<0x140>(by0));
+    by1 = fmax(by1, dpp_d<0xB1>(by1)); by1 = fmax(by1, dpp_d<0x4E>(by1)); by1 = fmax(by1, dpp_d<0x141>(by1)); by1 = fmax(by1, dpp_d<0x140>(by1));
+    kb[0] = readlane_d(bx0, 0); kb[1] = readlane_d(bx1, 0); kb[2] = readlane_d(by0, 0); kb[3] = readlane_d(by1, 0);
+    wsync();
+}
+
 // Cycle accounting of the step kernel (the <float, float, true> instantiation, launched when HOPE_STEP_TIMING is set;
 // tools/step_timing.py): [0] staging + near list [1] sub-step loop [2] status, reward, turnover, outputs, target
 // [3] lidar: ego transform + ring keep [4] lidar: per-edge beam ranges [5] lidar: enqueue [6] lidar: exact pairs (drain)
@@ -730,8 +822,9 @@ __device__ unsigned long long g_census[64 * 16];
 // wait for); 2 = the observation only (lidar + action mask) of the pose PART 1 left in `state`.  With HOPE_F_OVERLAP the
 // library launches 1 and 2 separately so that the observation runs NEXT TO the Reeds-Shepp kernels of the same tile class
 // (k_rs_compact / k_rs_words / k_rs_segs are short on parallelism and left the GPU half empty when they ran alone).
-template <typename OT, typename AT, bool TIMING = false, int PART = 0>
+template <typename OT, typename AT, bool TIMING = false, int PART = 0, bool FKIN = false>
 __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
+    static_assert(!FKIN || PART == 0, "the wave's own kinematics: one-launch form only");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= p.n_list) return;
@@ -751,7 +844,7 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     int n_obst = p.n_obst[scene];
     // the sub-step poses of this step (k_kinematics), requested together with everything else the scene needs
     const bool moving = PART != 2 && (p.stages & HOPE_STAGE_MOTION) && p.has_action;
-    const double kinv = (moving && lane < KIN_WORDS) ? p.kin[(size_t)scene * KIN_WORDS + lane] : 0.0;
+    const double kinv = (moving && !FKIN && lane < KIN_WORDS) ? p.kin[(size_t)scene * KIN_WORDS + lane] : 0.0;
 
     double* tile = lds;
     double* scr = lds + 8 * p.tile_cap;
@@ -788,6 +881,11 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     double ct = 0, sn = 0;       // cos/sin of the final heading
     if (PART == 2) { ct = p.cs[2 * (size_t)scene]; sn = p.cs[2 * (size_t)scene + 1]; }   // hm_sincos(h) as the motion launch computed it
     wsync();
+    // the sub-step poses: from k_kinematics' record, or (small batches, FKIN) by this wave itself while the tile's loads are in flight
+    int apmask_k = 0;
+    double kb[4] = {0.0, 0.0, 0.0, 0.0};                 // box around the step's hulls
+    if (FKIN && moving) wave_kinematics<AT>(p.actions, scene, p.stages, x, y, h, sc, scr, lane, apmask_k, kb);
+    else if (moving) { kb[0] = readlane_d(kinv, 52); kb[1] = readlane_d(kinv, 53); kb[2] = readlane_d(kinv, 54); kb[3] = readlane_d(kinv, 55); }
 
     if (PART != 2) {
     bool arrive = false, moved = false;
@@ -802,10 +900,10 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     int n_near;
     if (PART == 0) {
         if (moving)
-            n_near = build_near_list_box(tile, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), nlist, lane);
+            n_near = build_near_list_box(tile, n_obst, kb[0], kb[1], kb[2], kb[3], nlist, lane);
         else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
     } else if (moving)
-        n_near = stage_near(obb_s, src, n_obst, readlane_d(kinv, 52), readlane_d(kinv, 53), readlane_d(kinv, 54), readlane_d(kinv, 55), tile, nlist, lane);
+        n_near = stage_near(obb_s, src, n_obst, kb[0], kb[1], kb[2], kb[3], tile, nlist, lane);
     else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
     wsync();
     ST_T(0);
@@ -813,8 +911,8 @@ __global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
     if (moving) {
         // the ten sub-step poses (x, y, heading, cos, sin) were produced by k_kinematics (one THREAD per scene):
         // they do not depend on the collision outcome, only where we stop does
-        if (lane < 50) scr[LDS_HB + lane] = kinv;
-        apmask = __builtin_amdgcn_readlane(__double2loint(kinv), 50);        // arrival_possible of the ten poses (k_kinematics)
+        if (!FKIN && lane < 50) scr[LDS_HB + lane] = kinv;
+        apmask = FKIN ? apmask_k : __builtin_amdgcn_readlane(__double2loint(kinv), 50);        // arrival_possible of the ten poses (k_kinematics)
         wsync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------

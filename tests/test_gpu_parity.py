@@ -200,8 +200,10 @@ def test_restart_and_profile_api():
     assert np.array_equal(pose2[1::3], pose[1::3]) and (t2[1::3] == 6).all()
     km = env.kernel_ms()
     # 1 reset_obs + 5 steps + 1 masked reset_obs; max_obstacles 128 > 32 -> two tile-class launches each
-    assert km['k_kinematics'][1] in (5, 10) and km['k_env_step'][1] in (7, 14, 28)  # (28: the step kernel's motion and observation halves are launched separately)
-    assert km['k_rs_validate'][1] in (7, 14) and km['k_rs_words'][1] in (7, 14) and all(v[0] > 0 for k, v in km.items() if not k.startswith('k_bev') and k != 'k_rs_screen')   # (k_rs_screen: only with HOPE_RS_SPLIT=1)
+    # (k_kinematics: 0 launches in the one-launch form of small batches, where the step kernel's waves compute the sub-step poses
+    #  themselves; 28: the step kernel's motion and observation halves are launched separately)
+    assert km['k_kinematics'][1] in (0, 5, 10) and km['k_env_step'][1] in (7, 14, 28)
+    assert km['k_rs_validate'][1] in (7, 14) and km['k_rs_words'][1] in (7, 14) and all(v[0] > 0 for k, v in km.items() if not k.startswith('k_bev') and k not in ('k_rs_screen', 'k_kinematics'))   # (k_rs_screen: only with HOPE_RS_SPLIT=1)
     assert km['k_bev_image'] == (0.0, 0) and km['k_bev_prep'] == (0.0, 0)      # handle created without image=True
     assert km['k_rs_compact'][1] == 14                                         # one queue-compaction launch per call and tile class
     assert all(v == (0.0, 0) for v in env.kernel_ms().values())
