@@ -15,6 +15,10 @@
 // L2/MALL resident.  No MFMA: this is geometry, not a contraction.
 #pragma once
 #include "hope_dev.h"
+#ifndef HOPE_PART0_OCC
+#define HOPE_PART0_OCC 4     // waves per SIMD the one-launch form of the step kernel is compiled for.  3 = 137 VGPRs, no scratch, no VGPR spills -- and slower
+                            // from 4 096 scenes on (16 384: 0.235 vs 0.222 ms, profiles/r05_ab_part0_occupancy.txt): 4 with its 4 spilled VGPRs (12 B) stays
+#endif
 #ifndef HOPE_MASK_MG
 #define HOPE_MASK_MG 4      // action-mask rows probed together (A/B builds: -DHOPE_MASK_MG=8 measured 1.3 % slower)
 #endif
@@ -823,7 +827,7 @@ __device__ unsigned long long g_census[64 * 16];
 // library launches 1 and 2 separately so that the observation runs NEXT TO the Reeds-Shepp kernels of the same tile class
 // (k_rs_compact / k_rs_words / k_rs_segs are short on parallelism and left the GPU half empty when they ran alone).
 template <typename OT, typename AT, bool TIMING = false, int PART = 0, bool FKIN = false>
-__global__ __launch_bounds__(64, 4) void k_env_step(StepParams p) {
+__global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) void k_env_step(StepParams p) {
     static_assert(!FKIN || PART == 0, "the wave's own kinematics: one-launch form only");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
