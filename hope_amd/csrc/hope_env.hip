@@ -431,9 +431,20 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_rs_compact(const int32_t* l
         const double* pr = post + (size_t)s * POST_WORDS;
         const double* sc = scene_c + (size_t)s * SC_WORDS;
         double* in = rs_in + (size_t)qpos * RS_IN_WORDS;
-        in[0] = pr[3]; in[1] = pr[4]; in[2] = pr[5];
-        in[3] = sc[SC_DEST]; in[4] = sc[SC_DEST + 1]; in[5] = sc[SC_DEST + 2];
-        in[6] = sc[SC_BBOX]; in[7] = sc[SC_BBOX + 1]; in[8] = sc[SC_BBOX + 2]; in[9] = sc[SC_BBOX + 3];
+        const double q0x = pr[3], q0y = pr[4], q0w = pr[5];
+        in[0] = q0x; in[1] = q0y; in[2] = q0w;
+        in[3] = sc[SC_BBOX]; in[4] = sc[SC_BBOX + 1]; in[5] = sc[SC_BBOX + 2]; in[6] = sc[SC_BBOX + 3];
+        // generate_path (reeds_shepp.py:540-557): the goal in the start frame, scaled by the maximum curvature
+        const double dx = sc[SC_DEST] - q0x, dy = sc[SC_DEST + 1] - q0y;
+        const double PHI = sc[SC_DEST + 2] - q0w;
+        const double c = hm_cos(q0w), sn = hm_sin(q0w);
+        const double X = (c * dx + sn * dy) * RS_MAXC;
+        const double Y = (-sn * dx + c * dy) * RS_MAXC;
+        double sPHI, cPHI;                                    // hm_sincos is exactly odd / even: serves -PHI too
+        hm_sincos(PHI, &sPHI, &cPHI);
+        in[7] = X; in[8] = Y; in[9] = PHI; in[10] = sPHI; in[11] = cPHI;
+        in[12] = X * cPHI + Y * sPHI;                         // "backwards" (:206-207, :376-377)
+        in[13] = X * sPHI - Y * cPHI;
     }
 }
 

@@ -36,10 +36,13 @@ __host__ __device__ inline int rs_list_n_obst(int entry) { return (int)((unsigne
 //       then 5 x 2 doubles = 5 x 4 floats for the float32 filter of k_rs_validate: per segment the origin in the frame
 //       "world minus (map box xmin, ymin)" [m] (the frame of the scene's float32 obstacle view) and cos / sin of the WORLD heading at the origin
 // Per queued search, written by k_rs_compact next to the queue entry (same index): everything k_rs_words / k_rs_segs need from the
-// step's state -- pose x, y, heading (the finished step's final pose), dest x, y, heading, map box xmin, xmax, ymin, ymax -- so that the
+// step's state -- [0..2] pose x, y, heading (the finished step's final pose), [3..6] map box xmin, xmax, ymin, ymax, [7..13] the goal
+// normalised into the start frame (generate_path, reeds_shepp.py:540-557): X, Y, PHI, sin PHI, cos PHI and the "backwards" pair XB, YB
+// (:206-207), computed ONCE per search by k_rs_compact's lane instead of by each of k_rs_words' four family-group waves -- so that the
 // search chain behind k_rs_compact reads nothing the NEXT step's motion launch rewrites (`state`, `post`, and on an episode turnover the
 // scene constants): pipelined steps only wait for k_rs_compact, and the front kernels start without the queue entry -> scene round trip.
-constexpr int RS_IN_WORDS = 10;
+constexpr int RS_IN_WORDS = 14;
+constexpr double RS_MAXC = 0.3327130214085973;      // math.hm_tan(VALID_STEER[-1]) / WHEEL_BASE  (car_parking_base.py:422)
 constexpr int RS_REC_HDR = 16;
 constexpr int RS_REC_ORDER = 10;
 constexpr int RS_REC_KEYS = RS_REC_HDR;

@@ -30,7 +30,7 @@ namespace hope {
 
 namespace {
 
-constexpr double MAXC = 0.3327130214085973;      // math.hm_tan(VALID_STEER[-1]) / WHEEL_BASE  (car_parking_base.py:422)
+constexpr double MAXC = RS_MAXC;                 // math.hm_tan(VALID_STEER[-1]) / WHEEL_BASE  (car_parking_base.py:422)
 constexpr double RS_STEP = 0.1;                  // step_size passed by find_rs_path (:424)
 constexpr double MAX_LENGTH = 1000.0;            // reeds_shepp.py:6
 constexpr int NCAND = 46;
@@ -396,26 +396,13 @@ __global__ __launch_bounds__(64) void k_rs_words(RsParams p) {
     // the search's inputs are requested BEFORE the queue length is known (one memory round trip less): k_rs_compact wrote them by
     // queue position, rows at or beyond the count are stale or zero (hope_env_create clears them) and lanes without work store nothing
     const double* in = p.rs_in + (size_t)(qi < p.max_queue ? qi : p.max_queue - 1) * RS_IN_WORDS;
-    const double q0x = in[0], q0y = in[1], q0w = in[2];
-    const double gx = in[3], gy = in[4], gw = in[5];
+    // generate_path's goal in the start frame (:540-557), normalised by k_rs_compact (one lane per search; RS_IN_WORDS)
+    const double X = in[7], Y = in[8], PHI = in[9], sPHI = in[10], cPHI = in[11];
+    const double XB = in[12], YB = in[13];                    // "backwards" (:206-207, :376-377)
     const int count = *p.rs_count;
     if ((int)blockIdx.x * RSA_SCENES >= count) return;
     const bool live = qi < count;
     const int slot = p.slot_base + p.slot_dir * (live ? qi : 0);
-
-    // ---- generate_path (:540-557): normalise the goal into the start frame ------------------------
-    double X, Y, PHI;
-    {
-        double dx = gx - q0x, dy = gy - q0y;
-        PHI = gw - q0w;
-        double c = hm_cos(q0w), s = hm_sin(q0w);
-        X = (c * dx + s * dy) * MAXC;
-        Y = (-s * dx + c * dy) * MAXC;
-    }
-    double sPHI, cPHI;                                        // hm_sincos is exactly odd / even: serves -PHI too
-    hm_sincos(PHI, &sPHI, &cPHI);
-    const double XB = X * cPHI + Y * sPHI;                    // "backwards" (:206-207, :376-377)
-    const double YB = X * sPHI - Y * cPHI;
 
     double* rec = p.rs_rec + (size_t)slot * RS_REC_DOUBLES;
     RsWord* words = (RsWord*)(rec + RS_REC_WORDS);            // stored by candidate slot 4 g + q (= path order)
@@ -537,7 +524,7 @@ __global__ __launch_bounds__(64) void k_rs_segs(RsParams p) {
     double hdr = 0.0;                                       // lanes k0 = 0 .. 6 of a search: pose x, y, heading, map box
     int hdr_n = 0;
     if (k0 < 3) hdr = in[k0];
-    else if (k0 < 7) hdr = in[6 + k0 - 3];
+    else if (k0 < 7) hdr = in[k0];
     else hdr_n = rs_list_n_obst(entry);      // the obstacle count k_rs_compact read
     // the kept candidates of the search as a bit mask (bit c = candidate slot c): eight lanes x six keys, one ballot per stride
     unsigned long long keptm = 0;
