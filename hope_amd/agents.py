@@ -80,6 +80,16 @@ class _AgentCommon:
         policy's numerics, never the env's.  Updates keep the plain fp32 path."""
         self._fast = {'graph': bool(graph), 'amp': bool(amp), 'g': None, 'in': None, 'out': None, 'replays': 0, 'captures': 0}
 
+    def disable_fast_policy(self):
+        """drop the levers and the captured graph (call it, or `enable_fast_policy` again, after anything that replaces the actor
+        wholesale; a load_state_dict / `.to()` that re-materialises parameters is also detected: the graph is keyed on their storage)."""
+        self._fast = None
+
+    def _actor_key(self):
+        """what a captured graph bakes in besides the input shapes: the actor object and the storage of every parameter / buffer."""
+        ts = list(self.actor.parameters()) + list(self.actor.buffers())
+        return (id(self.actor), tuple(t.data_ptr() for t in ts))
+
     def _actor_infer(self, nobs):
         f = getattr(self, '_fast', None)
         if f is not None and f['amp'] and next(self.actor.parameters()).is_cuda:
@@ -92,20 +102,29 @@ class _AgentCommon:
         f = getattr(self, '_fast', None)
         if f is None or not f['graph'] or not nobs['lidar'].is_cuda:
             return torch.clamp(self._actor_infer(nobs), -1, 1)                   # ppo_agent.py:137
-        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in nobs.items())
-        if f['g'] is None or f['sig'] != sig:                                    # (re)capture for this batch shape
+        # the graph replays against the parameter storage it was captured with: the signature holds the input shapes AND the actor's
+        # storage, so re-materialised weights (load_state_dict(assign=True), .to(), a swapped module) recapture instead of replaying
+        # against freed memory; in-place updates (optimizer steps, load_state_dict's copy) keep the addresses and the graph
+        sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in nobs.items()), self._actor_key())
+        if f['g'] is None or f['sig'] != sig:                                    # (re)capture for this batch shape / these weights
             f['in'] = {k: torch.empty_like(v) for k, v in nobs.items()}
             for k, v in nobs.items():
                 f['in'][k].copy_(v)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):                                               # warm-up outside the capture (lazy inits)
-                    torch.clamp(self._actor_infer(f['in']), -1, 1)
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                f['out'] = torch.clamp(self._actor_infer(f['in']), -1, 1)
+            # inference semantics whatever mode the caller left the actor in (a train-mode dropout / batch-norm must not be baked in)
+            was_training = self.actor.training
+            self.actor.eval()
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):                                           # warm-up outside the capture (lazy inits)
+                        torch.clamp(self._actor_infer(f['in']), -1, 1)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    f['out'] = torch.clamp(self._actor_infer(f['in']), -1, 1)
+            finally:
+                self.actor.train(was_training)
             f['g'], f['sig'] = g, sig
             f['captures'] += 1
         for k, v in nobs.items():

@@ -363,3 +363,35 @@ def test_graph_captured_policy_forward_equals_the_eager_one():
     ag.enable_fast_policy(graph=True, amp=True)
     a = ag.policy_mean(nobs)
     assert float((a - b).abs().max()) < 0.05 and not torch.equal(a, b)
+
+
+def test_graph_captured_policy_follows_the_weights():
+    """the captured graph bakes in parameter ADDRESSES.  In-place updates (an optimizer step, load_state_dict's copy)
+    are seen by the replay; weights that are re-materialised (load_state_dict(assign=True)) change the signature and recapture
+    instead of replaying against the old storage; a train-mode actor is captured with inference semantics and handed back in
+    train mode; disable_fast_policy drops the graph."""
+    from hope_amd import agents as A
+    torch.manual_seed(3)
+    ag = A.BatchedPPO(device='cuda', use_img=False)
+    ref = A.BatchedPPO(device='cuda', use_img=False)
+    ref.actor.load_state_dict(ag.actor.state_dict())
+    g = torch.Generator(device='cuda').manual_seed(4)
+    nobs = {'lidar': torch.rand((64, 120), device='cuda', generator=g), 'target': torch.rand((64, 5), device='cuda', generator=g),
+            'action_mask': torch.rand((64, 42), device='cuda', generator=g)}
+    ag.actor.train()
+    ref.actor.eval()
+    ag.enable_fast_policy(graph=True, amp=False)
+    assert torch.equal(ag.policy_mean(nobs), ref.policy_mean(nobs)) and ag._fast['captures'] == 1
+    assert ag.actor.training                                   # handed back as it was
+    # in-place change of the weights: same storage, same graph, new values
+    with torch.no_grad():
+        for p_, q_ in zip(ag.actor.parameters(), ref.actor.parameters()):
+            p_.mul_(1.01); q_.mul_(1.01)
+    assert torch.equal(ag.policy_mean(nobs), ref.policy_mean(nobs)) and ag._fast['captures'] == 1
+    # re-materialised weights: new storage -> recapture
+    sd = {k: (v * 0.5).clone() for k, v in ag.actor.state_dict().items()}
+    ag.actor.load_state_dict(sd, assign=True)
+    ref.actor.load_state_dict(sd)
+    assert torch.equal(ag.policy_mean(nobs), ref.policy_mean(nobs)) and ag._fast['captures'] == 2
+    ag.disable_fast_policy()
+    assert torch.equal(ag.policy_mean(nobs), ref.policy_mean(nobs)) and ag._fast is None
