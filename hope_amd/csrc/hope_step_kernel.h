@@ -506,7 +506,8 @@ __device__ __forceinline__ bool beam_may_hit(double a, double b, double x1, doub
     return true;
 }
 
-// one (beam, edge) pair of _fast_calc_lidar_obs (lidar_simulator.py:98-133); returns range or +inf
+// one (beam, edge) pair of _fast_calc_lidar_obs (lidar_simulator.py:98-133); returns the SQUARE of the range (raw_x^2 + raw_y^2 as :131
+// forms it) or +inf: the square root is monotone, so the beam's minimum is taken over the squares and rooted once per beam
 __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1, double y1, double x2, double y2,
                                             double d, double e, double f) {
     double det = a * e - b * d;
@@ -522,7 +523,7 @@ __device__ __forceinline__ double beam_edge(int i, double a, double b, double x1
     bool ok = !(sx * raw_x < -tz) && !(sy * raw_y < -tz);
     ok = ok && !(raw_x > fmax(x1, x2)) && !(raw_x < fmin(x1, x2));
     ok = ok && !(raw_y > fmax(y1, y2)) && !(raw_y < fmin(y1, y2));
-    return ok ? sqrt(raw_x * raw_x + raw_y * raw_y) : INFINITY;
+    return ok ? raw_x * raw_x + raw_y * raw_y : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1400,8 +1401,8 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     }
     const double pm0 = p.pmax[UPS * i0], pm1 = has1 ? p.pmax[UPS * i1] : 0.0;   // for the mask stage: in flight during the drain
     if (qn > 0) drain();
-    const double best0 = __longlong_as_double((long long)best[i0]);
-    const double best1 = has1 ? __longlong_as_double((long long)best[i1]) : INFINITY;
+    const double best0 = sqrt(__longlong_as_double((long long)best[i0]));                     // min of the roots = root of the min
+    const double best1 = has1 ? sqrt(__longlong_as_double((long long)best[i1])) : INFINITY;
     const double base0 = p.hull_base[i0], base1 = has1 ? p.hull_base[i1] : 0.0;
     const double lid0 = clipd(best0, 0, LIDAR_RANGE) - base0;      // get_observation :46
     const double lid1 = clipd(best1, 0, LIDAR_RANGE) - base1;
