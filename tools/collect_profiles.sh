@@ -50,6 +50,10 @@ py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
   echo "== --refresh-every 0 (static pool)"; py $R/bench.py --refresh-every 0 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 | tail -1
   echo "== HOPE_RS_DEBUG=0x20000 (no screen pass: round 4's validation kernel)"; HOPE_RS_DEBUG=0x20000 $T python $R/bench.py --refresh-every 0 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   echo "== HOPE_PIPE=0 (steps not pipelined: the round-3 launch structure with this round's kernels)"; HOPE_PIPE=0 $T python $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
+  for NS in 4096 8192 16384; do echo "== --scenes $NS HOPE_RS_DEBUG=0x20000 (no screen pass)"; HOPE_RS_DEBUG=0x20000 $T python $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 2 --steps 40 --warmup 10 2>/dev/null | tail -1; done
+  echo "== the driver's exact form: --steps 20 --warmup 5"; py $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1
+  echo "== the driver's exact form, second run"; py $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1
+  echo "== the driver's exact form, third run"; py $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1
   echo "== config 2: --stages motion --scenes 4096"; py $R/bench.py --scenes 4096 --stages motion --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 0 --witness 0 | tail -1
   echo "== config 3: --scenes 16384 (full step)"; py $R/bench.py --scenes 16384 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 | tail -1
   echo "== config 4 share: --policy hope --algo rollout --scenes 8192 --image"; py $R/bench.py --policy hope --algo rollout --scenes 8192 --image --no-cpu-baseline | tail -1
@@ -77,5 +81,25 @@ $T python $R/tools/rs_filter_stats.py 2>/dev/null | head -3 > $O/${TAG}_rs_filte
 $T python $R/tools/rs_bench.py > $O/${TAG}_rs_bench.txt 2>/dev/null
 timeout 900 python $R/tools/soak.py --seeds 10 --scenes 4096 --steps 12 > $O/${TAG}_soak.txt 2>/dev/null
 $T python $R/tools/tie_census.py --scene-steps 2e8 > $O/${TAG}_tie_census.txt 2>/dev/null
+$T python $R/tools/config1_latency.py > $O/${TAG}_config1_latency.txt 2>/dev/null
+# vector instructions of k_env_step by stage (SQ_INSTS_VALU of launches with stages switched off)
+rm -rf /tmp/pp_valu
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pp_valu -- python $R/tools/pmc_stage_probe.py --mix mixed --scenes 16384 --seq $O/probe_seq.json > /dev/null 2>&1
+python $R/tools/pmc_stage_probe.py --seq $O/probe_seq.json --reduce $(find /tmp/pp_valu -name "*counter_collection.csv" | head -1) SQ_INSTS_VALU > $O/${TAG}_env_step_insts_by_stage.txt 2>&1
+rm -f $O/probe_seq.json
+# one line per bench-modes entry
+python - > $O/${TAG}_bench_modes_summary.txt <<P
+import json
+lab = None
+for l in open('$O/${TAG}_bench_modes.txt'):
+    l = l.rstrip()
+    if l.startswith('=='):
+        lab = l
+        continue
+    if l.startswith('{'):
+        d = json.loads(l); r = d.get('repeat') or {}
+        print(lab, '|', round(d['value'] / 1e6, 2), 'M', round(d['ms_per_step'], 4), 'ms | steady', r.get('median') and round(r['median'], 4), '| joined',
+              r.get('joined_ms_per_step') and round(r['joined_ms_per_step'], 4), '| refresh', (d.get('pool_refresh') or {}).get('every_steps'), (d.get('pool_refresh') or {}).get('refresher_commits'))
+P
 rm -rf $O/kstats $O/kstats_img $O/pmc_* $O/pmc*_FETCH_SIZE $O/pmc*_WRITE_SIZE $O/busy*
 ls -la $O
