@@ -19,6 +19,11 @@
 #define HOPE_PART0_OCC 4     // waves per SIMD the one-launch form of the step kernel is compiled for.  3 = 137 VGPRs, no scratch, no VGPR spills -- and slower
                             // from 4 096 scenes on (16 384: 0.235 vs 0.222 ms, profiles/r05_ab_part0_occupancy.txt): 4 with its 4 spilled VGPRs (12 B) stays
 #endif
+#ifndef HOPE_KIN_PRIO
+#define HOPE_KIN_PRIO 3       // wave priority (s_setprio) of k_kinematics: it heads the step's critical chain (kinematics -> motion -> observation of
+                            // the larger class) and shares its SIMDs with the previous step's observation / validation waves: 0.4967 -> 0.4937 ms
+                            // (profiles/r05_ab_wave_priority.txt; priorities for the motion / observation launches on top of it: nothing)
+#endif
 #ifndef HOPE_MASK_MG
 #define HOPE_MASK_MG 4      // action-mask rows probed together (A/B builds: -DHOPE_MASK_MG=8 measured 1.3 % slower)
 #endif
@@ -612,6 +617,7 @@ template <typename AT>
 __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_list, const double* state, const void* actions,
                                                   const uint8_t* active, uint32_t stages, const double* scene_c, double* kin) {
     // n entries of scene_list (a tile class's dense list: the kinematics head each class's launch chain), or scenes 0..n-1
+    if (HOPE_KIN_PRIO) __builtin_amdgcn_s_setprio(HOPE_KIN_PRIO);
     __shared__ double buf[KIN_SCENES_PER_BLOCK * KIN_WORDS];
     __shared__ double terms[MINI_ITER][2 * KIN_SCENES_PER_BLOCK];   // one round's displacement terms: [micro-step][2 scene + (x | y)]
     __shared__ int sid[KIN_SCENES_PER_BLOCK];
