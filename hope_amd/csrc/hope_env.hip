@@ -1516,7 +1516,17 @@ static int commit_pool_impl(hope_env_t* h, int n_pool, bool relaxed) {
     if (h->pactive >= 0) HIPCHK(hipStreamWaitEvent(us, h->ev_last_step, 0));
     const size_t P = (size_t)n_pool;
     char* dv = (char*)h->pstage_dev;
-    HIPCHK(hipMemcpyAsync(ps.verts, h->pstage.verts, P * h->max_obst * 8 * sizeof(double), hipMemcpyHostToDevice, us));
+    {   // only the used prefix of every entry's obstacle tile travels (a 2-D copy: one row per entry): generated lots hold ~7 obstacles of
+        // the 128 slots, and the full 67 MB of an 8 192-entry pool took ~1 ms on the hardware queue the upload stream shares with one of
+        // the step's streams -- the step enqueued right after a commit took 1.52 ms instead of 0.49, now 0.65 (tools/commit_cost.py; the
+        // excess scaled with the pool size; moving k_set_scene_consts off the upload stream did not change it).  The tail of a row
+        // keeps the previous generation's bytes; nothing reads beyond n_obst.
+        int maxn = 1;
+        for (int k = 0; k < n_pool; k++) maxn = std::max(maxn, (int)h->pstage.nobst[k]);
+        const size_t pitch = (size_t)h->max_obst * 8 * sizeof(double), width = (size_t)maxn * 8 * sizeof(double);
+        if (2 * width <= pitch) HIPCHK(hipMemcpy2DAsync(ps.verts, pitch, h->pstage.verts, pitch, width, P, hipMemcpyHostToDevice, us));
+        else HIPCHK(hipMemcpyAsync(ps.verts, h->pstage.verts, P * pitch, hipMemcpyHostToDevice, us));
+    }
     HIPCHK(hipMemcpyAsync(ps.nobst, h->pstage.nobst, P * sizeof(int32_t), hipMemcpyHostToDevice, us));
     HIPCHK(hipMemcpyAsync(dv, h->pstage.start, P * 24, hipMemcpyHostToDevice, us));
     HIPCHK(hipMemcpyAsync(dv + P * 24, h->pstage.dest, P * 24, hipMemcpyHostToDevice, us));
