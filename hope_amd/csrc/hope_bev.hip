@@ -50,7 +50,7 @@ constexpr int FB_BYTES = FB_DIM * FB_STRIDE;
 constexpr int SL_ROWS = 16, SL_STRIDE = 516;   // 500 pixels + pad: 129 dwords (odd)
 constexpr int SL_BYTES = SL_ROWS * SL_STRIDE;
 constexpr int SL_SLOT = (SL_BYTES + 72 + 15) / 16 * 16;
-constexpr int SL_PARTS = 8;                    // workgroups per rebuilt scene (x 4 waves = the 32 bands of 16 rows: one band per wave)
+constexpr int SL_BANDS = (WIN + SL_ROWS - 1) / SL_ROWS;   // bands of 16 rows per scene: one single-wave workgroup each
 constexpr int FB_SLOT = (FB_BYTES + 72 + 15) / 16 * 16;   // window + 64 dummy bytes, 16-byte aligned
 constexpr int BEV_WAVES = 4;                   // waves per workgroup = per scene (they share the span tables)
 constexpr double RENDER_K = 12.0;              // K  configs.py:103
@@ -314,69 +314,9 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
     const double* newest = ring + 3 * ((traj_len - 1 + BEV_TRAJ_LEN) % BEV_TRAJ_LEN);
     const bool veh_hidden = traj_len > 1 && newest[0] == px_ && newest[1] == py_ && newest[2] == ph;
 
-    // ---- the crop -> world map --------------------------------------------------------------------------------------
-    {
-        int mv[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) mv[i] = 0;
-        double sh, ch;
-        hm_sincos(ph, &sh, &ch);
-        const Box vb = make_box(px_, py_, ch, sh);
-        // LinearRing.centroid (GEOS Centroid::addLineSegments)
-        double len = 0, sx = 0, sy = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int i2 = (i + 1) & 3;
-            const double ex = vb.x[i] - vb.x[i2], ey = vb.y[i] - vb.y[i2];
-            const double seg = sqrt(ex * ex + ey * ey);
-            if (seg == 0.0) continue;
-            len += seg;
-            sx += seg * ((vb.x[i] + vb.x[i2]) / 2);
-            sy += seg * ((vb.y[i] + vb.y[i2]) / 2);
-        }
-        const double ccx = sx / len, ccy = sy / len;
-        const double vcx = RENDER_K * ccx + 0.0 * ccy + offx, vcy = 0.0 * ccx + RENDER_K * ccy + offy;
-        const double ddx = (vcx - WIN / 2) * ch + (vcy - WIN / 2) * sh;
-        const double ddy = -(vcx - WIN / 2) * sh + (vcy - WIN / 2) * ch;
-        const int ox = (int)(-ddx), oy = (int)(-ddy);                         // observation.blit(rotate, (int(-dx), int(-dy)))
-        const int rox = CROP_OFF - ox, roy = CROP_OFF - oy;                   // subsurface origin :343-344
-        int dxx, dxy, dx0, dyx, dyy, dy0;                                     // source position as a function of (rx, ry)
-        const float angle = (float)(ph * (180.0 / 3.141592653589793));        // np.rad2deg -> C float argument
-        if (hm_fmod((double)angle, 90.0) == 0.0) {                            // transform.c rotate90
-            int t = ((int)angle / 90) % 4;
-            if (t < 0) t += 4;
-            const int one = 1 << 16, last = (WIN - 1) << 16;
-            if (t == 0) { dxx = one; dxy = 0; dx0 = 0; dyx = 0; dyy = one; dy0 = 0; }                    // (rx, ry)
-            else if (t == 1) { dxx = 0; dxy = -one; dx0 = last; dyx = one; dyy = 0; dy0 = 0; }            // (499 - ry, rx)
-            else if (t == 2) { dxx = -one; dxy = 0; dx0 = last; dyx = 0; dyy = -one; dy0 = last; }        // (499 - rx, 499 - ry)
-            else { dxx = 0; dxy = one; dx0 = 0; dyx = -one; dyy = 0; dy0 = last; }                        // (ry, 499 - rx)
-        } else {                                                              // transform.c surf_rotate + rotate()
-            const double radangle = angle * .01745329251994329;
-            double sangle, cangle;
-            hm_sincos(radangle, &sangle, &cangle);
-            const double cx = cangle * WIN, cy = cangle * WIN, sxx = sangle * WIN, syy = sangle * WIN;
-            const int nw = (int)fmax(fmax(fmax(fabs(cx + syy), fabs(cx - syy)), fabs(-cx + syy)), fabs(-cx - syy));
-            const int nh = (int)fmax(fmax(fmax(fabs(sxx + cy), fabs(sxx - cy)), fabs(-sxx + cy)), fabs(-sxx - cy));
-            const int rcy = nh / 2;
-            const int xd = (WIN - nw) * 32768, yd = (WIN - nh) * 32768;
-            const int isin = (int)(sangle * 65536), icos = (int)(cangle * 65536);
-            const int ax = (nw * 32768) - (int)(cangle * ((nw - 1) * 32768));
-            const int ay = (nh * 32768) - (int)(sangle * ((nw - 1) * 32768));
-            const int x0 = WIN / 2 - (nw >> 1), y0 = WIN / 2 - (nh >> 1);     // capture.get_rect(center=(250, 250))
-            // capture pixel (X, Y) = (rx - x0, ry - y0):  dx = ax + isin (rcy - Y) + xd + icos X,  dy = ay - icos (rcy - Y) + yd + isin X
-            dxx = icos; dxy = -isin; dx0 = ax + xd + isin * (rcy + y0) - icos * x0;
-            dyx = isin; dyy = icos; dy0 = ay + yd - icos * (rcy + y0) - isin * x0;
-        }
-        mv[M_DXX] = dxx; mv[M_DXY] = dxy; mv[M_DX0] = dx0 + dxx * rox + dxy * roy;
-        mv[M_DYX] = dyx; mv[M_DYY] = dyy; mv[M_DY0] = dy0 + dyx * rox + dyy * roy;
-        mv[M_ROX] = rox; mv[M_ROY] = roy;
-        mv[M_VEH_HIDDEN] = veh_hidden;
-        int v = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) v = lane == i ? mv[i] : v;
-        if (lane < 16) out[OFF_MAP + lane] = v;
-    }
-
+    // (the crop -> world map of the scene is made by k_bev_map, one LANE per scene: as wave-uniform arithmetic here -- two sincos, the
+    // ring centroid's four square roots and divisions, the 16.16 rotation set-up -- it was ~60 % of this kernel's vector instructions,
+    // and the kernel sits in front of the image launch on the step's critical path)
     // ---- boxes that are new this step: lane = box slot ---------------------------------------------------------------
     int vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0};
     bool need = false;
@@ -490,11 +430,91 @@ __global__ __launch_bounds__(64) void k_bev_prep(BevParams p) {
 }
 
 // ====================================================================================================================
+// k_bev_map: the crop -> world-surface map of every scene (Mapping, scratch words OFF_MAP + M_DXX .. M_VEH_HIDDEN), one lane per scene
+// ====================================================================================================================
+__global__ __launch_bounds__(64) void k_bev_map(BevParams p) {
+    const int scene = blockIdx.x * WAVE + threadIdx.x;
+    if (scene >= p.n) return;
+    if (p.active && !p.active[scene]) return;
+    int* out = p.scratch + (size_t)scene * BEV_SCENE_INTS;
+    const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
+    const double* st = p.state + (size_t)scene * ST_WORDS;
+    const double px_ = st[0], py_ = st[1], ph = st[2];
+    // coord_transform_matrix (car_parking_base.py:139-147)
+    const double offx = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 1] + sc[SC_BBOX])), offy = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 3] + sc[SC_BBOX + 2]));
+    const int traj_len = p.traj_len[scene];
+    const double* ring = p.traj + (size_t)scene * BEV_TRAJ_LEN * 3;
+    const double* newest = ring + 3 * ((traj_len - 1 + BEV_TRAJ_LEN) % BEV_TRAJ_LEN);
+    const bool veh_hidden = traj_len > 1 && newest[0] == px_ && newest[1] == py_ && newest[2] == ph;
+    {
+        int mv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) mv[i] = 0;
+        double sh, ch;
+        hm_sincos(ph, &sh, &ch);
+        const Box vb = make_box(px_, py_, ch, sh);
+        // LinearRing.centroid (GEOS Centroid::addLineSegments)
+        double len = 0, sx = 0, sy = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int i2 = (i + 1) & 3;
+            const double ex = vb.x[i] - vb.x[i2], ey = vb.y[i] - vb.y[i2];
+            const double seg = sqrt(ex * ex + ey * ey);
+            if (seg == 0.0) continue;
+            len += seg;
+            sx += seg * ((vb.x[i] + vb.x[i2]) / 2);
+            sy += seg * ((vb.y[i] + vb.y[i2]) / 2);
+        }
+        const double ccx = sx / len, ccy = sy / len;
+        const double vcx = RENDER_K * ccx + 0.0 * ccy + offx, vcy = 0.0 * ccx + RENDER_K * ccy + offy;
+        const double ddx = (vcx - WIN / 2) * ch + (vcy - WIN / 2) * sh;
+        const double ddy = -(vcx - WIN / 2) * sh + (vcy - WIN / 2) * ch;
+        const int ox = (int)(-ddx), oy = (int)(-ddy);                         // observation.blit(rotate, (int(-dx), int(-dy)))
+        const int rox = CROP_OFF - ox, roy = CROP_OFF - oy;                   // subsurface origin :343-344
+        int dxx, dxy, dx0, dyx, dyy, dy0;                                     // source position as a function of (rx, ry)
+        const float angle = (float)(ph * (180.0 / 3.141592653589793));        // np.rad2deg -> C float argument
+        if (hm_fmod((double)angle, 90.0) == 0.0) {                            // transform.c rotate90
+            int t = ((int)angle / 90) % 4;
+            if (t < 0) t += 4;
+            const int one = 1 << 16, last = (WIN - 1) << 16;
+            if (t == 0) { dxx = one; dxy = 0; dx0 = 0; dyx = 0; dyy = one; dy0 = 0; }                    // (rx, ry)
+            else if (t == 1) { dxx = 0; dxy = -one; dx0 = last; dyx = one; dyy = 0; dy0 = 0; }            // (499 - ry, rx)
+            else if (t == 2) { dxx = -one; dxy = 0; dx0 = last; dyx = 0; dyy = -one; dy0 = last; }        // (499 - rx, 499 - ry)
+            else { dxx = 0; dxy = one; dx0 = 0; dyx = -one; dyy = 0; dy0 = last; }                        // (ry, 499 - rx)
+        } else {                                                              // transform.c surf_rotate + rotate()
+            const double radangle = angle * .01745329251994329;
+            double sangle, cangle;
+            hm_sincos(radangle, &sangle, &cangle);
+            const double cx = cangle * WIN, cy = cangle * WIN, sxx = sangle * WIN, syy = sangle * WIN;
+            const int nw = (int)fmax(fmax(fmax(fabs(cx + syy), fabs(cx - syy)), fabs(-cx + syy)), fabs(-cx - syy));
+            const int nh = (int)fmax(fmax(fmax(fabs(sxx + cy), fabs(sxx - cy)), fabs(-sxx + cy)), fabs(-sxx - cy));
+            const int rcy = nh / 2;
+            const int xd = (WIN - nw) * 32768, yd = (WIN - nh) * 32768;
+            const int isin = (int)(sangle * 65536), icos = (int)(cangle * 65536);
+            const int ax = (nw * 32768) - (int)(cangle * ((nw - 1) * 32768));
+            const int ay = (nh * 32768) - (int)(sangle * ((nw - 1) * 32768));
+            const int x0 = WIN / 2 - (nw >> 1), y0 = WIN / 2 - (nh >> 1);     // capture.get_rect(center=(250, 250))
+            // capture pixel (X, Y) = (rx - x0, ry - y0):  dx = ax + isin (rcy - Y) + xd + icos X,  dy = ay - icos (rcy - Y) + yd + isin X
+            dxx = icos; dxy = -isin; dx0 = ax + xd + isin * (rcy + y0) - icos * x0;
+            dyx = isin; dyy = icos; dy0 = ay + yd - icos * (rcy + y0) - isin * x0;
+        }
+        mv[M_DXX] = dxx; mv[M_DXY] = dxy; mv[M_DX0] = dx0 + dxx * rox + dxy * roy;
+        mv[M_DYX] = dyx; mv[M_DYY] = dyy; mv[M_DY0] = dy0 + dyx * rox + dyy * roy;
+        mv[M_ROX] = rox; mv[M_ROY] = roy;
+        mv[M_VEH_HIDDEN] = veh_hidden;
+#pragma unroll
+        for (int i = 0; i <= M_VEH_HIDDEN; i++) out[OFF_MAP + i] = mv[i];
+    }
+}
+
+// ====================================================================================================================
 // k_bev_list: the scenes whose map is newer than their static layer (layer_valid == 0: set_scenes, the step kernel's episode turnover,
 // a device-side draw) are queued for k_bev_static -- one lane per scene.  Its own launch, so that the rebuild of the layers does not
 // wait for k_bev_prep (the two run side by side on two streams when the step is pipelined; launch_bev_image).
 // ====================================================================================================================
-__global__ __launch_bounds__(256) void k_bev_list(BevParams p) {
+// (one wave per workgroup: a 4-wave workgroup needs four free wave slots on ONE CU at once, and next to the observation / k_bev_prep
+// launches -- single-wave workgroups that take every slot as it frees up -- this 5 us kernel waited 220 us for them: timeline, round 5)
+__global__ __launch_bounds__(64) void k_bev_list(BevParams p) {
     const int scene = blockIdx.x * blockDim.x + threadIdx.x;
     if (scene >= p.n) return;
     if (p.active && !p.active[scene]) return;
@@ -511,14 +531,17 @@ __global__ __launch_bounds__(256) void k_bev_list(BevParams p) {
 // step.  Four waves per scene, each taking every fourth band of SL_ROWS rows: band in LDS (one byte per pixel), then packed.
 // Scenes come from the list k_bev_prep made; the grid is fixed and strides over it.
 // ====================================================================================================================
-__global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_static(BevParams p) {
+__global__ __launch_bounds__(64) void k_bev_static(BevParams p) {
     extern __shared__ __align__(16) uint8_t lds_raw[];
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    uint8_t* fb = lds_raw + wave * SL_SLOT;
+    const int lane = threadIdx.x;
+    uint8_t* fb = lds_raw;
     const int count = p.rebuild[0];
-    // SL_PARTS workgroups per scene, each a quarter of the bands: a rebuilt scene is on the image's critical path
-    for (int it = blockIdx.x; it < SL_PARTS * count; it += gridDim.x) {
-        const int scene = p.rebuild[1 + it / SL_PARTS], part = it % SL_PARTS;
+    // One single-wave workgroup per (scene, band of 16 rows): SL_BANDS of them per rebuilt scene -- a rebuilt scene is on the image's
+    // critical path.  (Round 5: it was four waves per workgroup, a band each.  A 4-wave workgroup needs four wave slots and 33 KB of
+    // LDS free on ONE CU at once; next to the observation and k_bev_prep launches, whose single-wave workgroups take every slot as it
+    // frees up, the launch waited for them to drain: 130 us of work ended 350 us after its start.)
+    for (int it = blockIdx.x; it < SL_BANDS * count; it += gridDim.x) {
+        const int scene = p.rebuild[1 + it / SL_BANDS], band = it % SL_BANDS;
         const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
         const double offx = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 1] + sc[SC_BBOX])), offy = 0.5 * (WIN - RENDER_K * (sc[SC_BBOX + 3] + sc[SC_BBOX + 2]));
         const int n_obst = p.n_obst[scene];
@@ -540,8 +563,32 @@ __global__ __launch_bounds__(BEV_WAVES * 64) void k_bev_static(BevParams p) {
         }
         sx[4] = sx[0]; sy[4] = sy[0]; dx[4] = dx[0]; dy[4] = dy[0];
         const int n_chunks = (n_obst + WAVE - 1) / WAVE;
-        for (int band = part * BEV_WAVES + wave; band * SL_ROWS < WIN; band += SL_PARTS * BEV_WAVES) {
+        {
             const Window cw = {0, band * SL_ROWS, WIN - 1, min(band * SL_ROWS + SL_ROWS, WIN) - 1};
+            {   // A band nothing is drawn into (most bands of a generated lot: ~7 obstacles on 500 rows) is background: its 16 layer
+                // blocks are one contiguous 2 KB run -- zeroed directly, without the LDS band, the raster calls and the packing.
+                // (Rows of the boxes' vertex ranges: every pygame routine used here draws inside its polygon's / line's y range.)
+                bool any = false;
+                for (int c = 0; c < n_chunks; c++) {
+                    const int o = WAVE * c + lane;
+                    if (o < n_obst) {
+                        const double* v = p.verts + ((size_t)scene * p.max_obst + o) * 8;
+                        int y0 = INT_MAX, y1 = INT_MIN;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const int vy_ = to_px(v[2 * k], v[2 * k + 1], 0.0, RENDER_K, offy); y0 = min(y0, vy_); y1 = max(y1, vy_); }
+                        any = any || !(y1 < cw.y0 || y0 > cw.y1);
+                    }
+                }
+                const int s0 = min(min(sy[0], sy[1]), min(sy[2], sy[3])), s1 = max(max(sy[0], sy[1]), max(sy[2], sy[3]));
+                const int d0 = min(min(dy[0], dy[1]), min(dy[2], dy[3])), d1 = max(max(dy[0], dy[1]), max(dy[2], dy[3]));
+                const bool shapes = __any(any) || !(s1 < cw.y0 || s0 > cw.y1) || !(d1 < cw.y0 || d0 > cw.y1);
+                if (!shapes && !(p.debug & 1024)) {
+                    static_assert(SL_ROWS == 16 && BEV_LAYER_STRIDE == 128, "one band = one row of 16 layer blocks = 2 KB");
+                    uint4* z = (uint4*)(layer + (size_t)band * 16 * 128);
+                    z[lane] = make_uint4(0, 0, 0, 0); z[lane + WAVE] = make_uint4(0, 0, 0, 0);
+                    continue;
+                }
+            }
             wave_phase();
             {   // surface.fill(BG_COLOR)
                 uint4* f4 = (uint4*)fb;
@@ -1109,7 +1156,7 @@ hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer*
     // the usual step has a fraction of a per cent of the scenes in it, the first one all of them) depend on the maps only, the crop
     // maps / span tables / trajectory layer of k_bev_prep on the poses only: with a `side` stream the two run side by side (both are
     // short latency-bound launches on the critical path of a step with the image), joined in front of the image launches.
-    const size_t lds_static = (size_t)BEV_WAVES * SL_SLOT;
+    const size_t lds_static = (size_t)SL_SLOT;
     static bool attr_done = false;
     if (!attr_done && lds_static > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)k_bev_static, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_static);
@@ -1122,8 +1169,9 @@ hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer*
         if ((e = hipStreamWaitEvent(side, ev_fork, 0)) != hipSuccess) return e;
     }
     // (p.rebuild[0], the length of the list of stale layers, is zero here: hope_env_create clears it and k_bev_image resets it)
-    hipLaunchKernelGGL(k_bev_list, dim3((p.n + 255) / 256), dim3(256), 0, ss, p);
-    hipLaunchKernelGGL(k_bev_static, dim3(std::min(SL_PARTS * p.n, 4096)), dim3(BEV_WAVES * WAVE), lds_static, ss, p);
+    hipLaunchKernelGGL(k_bev_map, dim3((p.n + WAVE - 1) / WAVE), dim3(WAVE), 0, ss, p);      // (joined in front of the image with the layers)
+    hipLaunchKernelGGL(k_bev_list, dim3((p.n + WAVE - 1) / WAVE), dim3(WAVE), 0, ss, p);
+    hipLaunchKernelGGL(k_bev_static, dim3(std::min(SL_BANDS * p.n, 16384)), dim3(WAVE), lds_static, ss, p);
     if (side && (e = hipEventRecord(ev_join, side)) != hipSuccess) return e;
     if (timer) timer->begin(HOPE_K_IMAGE_PREP, stream);
     hipLaunchKernelGGL(k_bev_prep, dim3(p.n), dim3(WAVE), 0, stream, p);
