@@ -682,7 +682,7 @@ constexpr int CACHE_ROWS = 7, CACHE_SLOT = CACHE_ROWS * 4 * 128;   // layer bloc
 #endif
 constexpr int WAVE_LDS = 32 * 4 + TAB_ROWS * 4 + BEV_SLOTS * CACHE_SLOT;         // raster-free launch, per wave: palette, vehicle span table, two cache slots
 template <bool LEGACY>
-__device__ __forceinline__ void bev_render_scene(const BevParams& p, const int scene, uint8_t* lds_raw) {
+__device__ __forceinline__ void bev_render_scene(const BevParams& p, const int scene, uint8_t* lds_raw, const int wave_in = -1) {
     // LDS.  LEGACY: palette (128 B) | all span tables, shared by the workgroup's waves (5.6 KB) | per wave the window (8.3 KB + 72).
     // Else nothing is shared and the waves never meet at a barrier: per wave palette | vehicle span table (256 B) | two block-cache slots.
     // wave-uniform values are moved to scalar registers explicitly (readfirstlane / readlane): the scratch is written by other kernels
@@ -690,8 +690,9 @@ __device__ __forceinline__ void bev_render_scene(const BevParams& p, const int s
     // windows, the box tests, the per-sample offsets of the affine map (32-bit multiplies: quarter rate on the vector unit) -- stayed
     // on the vector unit too
     auto uni = [](int x) -> int { return __builtin_amdgcn_readfirstlane(x); };
-    const int lane = threadIdx.x & (WAVE - 1), wave = uni(threadIdx.x / WAVE);
-    uint32_t* const pal = (uint32_t*)(LEGACY ? lds_raw : lds_raw + wave * WAVE_LDS);
+    // wave_in >= 0: a single-wave workgroup renders the tiles of the scene's wave `wave_in` (its LDS slice is the workgroup's own)
+    const int lane = threadIdx.x & (WAVE - 1), wave = wave_in >= 0 ? wave_in : uni(threadIdx.x / WAVE);
+    uint32_t* const pal = (uint32_t*)((LEGACY || wave_in >= 0) ? lds_raw : lds_raw + wave * WAVE_LDS);
     uint32_t* const tabs = pal + 32;                                         // LEGACY: [N_TAB][TAB_ROWS]
     uint32_t* const vtab = LEGACY ? tabs + TAB_ROWS : pal + 32;              // the vehicle's span table
     uint8_t* const fb0 = LEGACY ? lds_raw + 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + wave * FB_SLOT   // (+ 64 dummy bytes, fill_span)
@@ -1145,6 +1146,18 @@ __global__ __launch_bounds__(BEV_WAVES * 64, LEGACY ? 4 : BEV_OCC) void k_bev_im
 
 }  // namespace
 
+// The raster-free launch as SINGLE-WAVE workgroups, four per scene (the scene's four waves share nothing): a 4-wave workgroup needs
+// four wave slots and its LDS free on one CU at once, which next to the observation launch's single-wave workgroups costs it slots.
+// Workgroup b runs on XCD b % 8: the four waves of a scene are b, b + 8, b + 16, b + 24 of a group of 32 workgroups -- one XCD, one L2.
+__global__ __launch_bounds__(64, BEV_OCC) void k_bev_image_w(BevParams p) {
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { p.rebuild[0] = 0; p.legacy_list[0] = 0; }
+    const int g = blockIdx.x >> 5, r = blockIdx.x & 31;
+    const int sb = (g << 3) | (r & 7);                                       // the scene's block index in the 4-wave launch's numbering
+    if (sb >= p.n) return;
+    bev_render_scene<false>(p, scene_of_block(sb, p.n), lds_raw, r >> 3);
+}
+
 size_t bev_lds_bytes(bool legacy) {
     return legacy ? 32 * sizeof(uint32_t) + N_TAB * TAB_ROWS * sizeof(uint32_t) + BEV_WAVES * FB_SLOT
                   : (size_t)BEV_WAVES * WAVE_LDS;
@@ -1182,7 +1195,9 @@ hipError_t launch_bev_image(const BevParams& p, hipStream_t stream, LaunchTimer*
     // (scenes with a box that is not a plain car box, or whose drawn boxes outgrew the trajectory torus: none in practice; first,
     // because the other launch empties the list)
     hipLaunchKernelGGL(k_bev_image<true>, dim3(std::min(p.n, 1024)), block, bev_lds_bytes(true), stream, p);
-    hipLaunchKernelGGL(k_bev_image<false>, grid, block, bev_lds_bytes(false), stream, p);
+    static const bool one_wave = !(getenv("HOPE_BEV_WG") && atoi(getenv("HOPE_BEV_WG")) == 4);     // (A/B: 4 = four waves per workgroup)
+    if (one_wave) hipLaunchKernelGGL(k_bev_image_w, dim3(((p.n + 7) / 8) * 32), dim3(WAVE), (size_t)WAVE_LDS, stream, p);
+    else hipLaunchKernelGGL(k_bev_image<false>, grid, block, bev_lds_bytes(false), stream, p);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
