@@ -1817,7 +1817,7 @@ hipError_t launch_rs_search(const RsParams& p, hipStream_t stream, LaunchTimer* 
         // 0.692 ms per step with 4 .. 8 waves per CU, 0.705 with 10, 0.73 with the 13 its 9.5 KB of LDS would allow -- the step
         // kernel's waves are the better use of the wave slots.  The small-tile launch must not be limited (8 per CU: 0.92 ms).
         const char* w = getenv(p.tile_cap > 32 ? "HOPE_RS_WPC1" : "HOPE_RS_WPC0");
-        const int wpc = w ? atoi(w) : (p.tile_cap > 32 ? 8 : 0);
+        const int wpc = w ? atoi(w) : (p.tile_cap > 32 ? 6 : 0);       // (round 5, with the screen pass: 6 -> 0.4930 ms, 8 -> 0.4958, 12 -> 0.500, unlimited 0.503)
         if (wpc > 0) lds = std::max(lds, (size_t)((158 * 1024 / wpc) & ~255));
     }
     if (lds > 48 * 1024) {                                  // (the two-kernel form's walk kernel; k_rs_screen stays far below)
