@@ -392,13 +392,14 @@ __device__ __forceinline__ int build_near_list_box(const double* tile, int n_obs
 // copied to LDS, compacted: tile slot i = i-th such obstacle, list[i] = i.  Returns their number.
 __device__ __forceinline__ int stage_near(const float4* obb, const double2* src, int n_obst, double bx0, double bx1,
                                           double by0, double by1, double* tile, int* list, int lane,
-                                          const uint8_t* gflags = nullptr, uint8_t* lflags = nullptr) {
+                                          const uint8_t* gflags = nullptr, uint8_t* lflags = nullptr, const float4* pre = nullptr) {
+    // pre: the box of obstacle `lane` (the first chunk), requested by the caller together with the scene's first loads
     int cnt = 0;
     for (int base = 0; base < n_obst; base += WAVE) {
         const int o = base + lane;
         bool near = false;
         if (o < n_obst) {
-            const float4 bb = obb[o];
+            const float4 bb = (pre && base == 0) ? *pre : obb[o];
             near = !((double)bb.x > bx1 || (double)bb.y < bx0 || (double)bb.z > by1 || (double)bb.w < by0);
         }
         const unsigned long long m = __ballot(near);
@@ -881,6 +882,10 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         const uint32_t* gf = (const uint32_t*)(p.eflag + (size_t)scene * eflag_stride(p.max_obst));
         for (int i = lane; 4 * i < n_obst; i += WAVE) ((uint32_t*)cfl)[i] = gf[i];
     }
+    // the first chunk of obstacle boxes of the near-obstacle scan (stage_near), requested NOW with the scene's other first loads: only
+    // the launch's tile capacity of them (the small-tile class: 32 slots = 512 B; slots beyond n_obst belong to the scene, unused)
+    float4 obb_pre = make_float4(0, 0, 0, 0);
+    if (PART != 0 && lane < min(p.tile_cap, WAVE)) obb_pre = obb_s[lane];
     double* dbox = scr + LDS_DBOX;
     double* xl = scr + LDS_ROBUST;                       // work area of the robust collision path (one lane at a time)
     if (PART != 2 && lane < 8) dbox[lane] = sc[SC_DBOX + lane];
@@ -914,8 +919,8 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
             n_near = build_near_list_box(tile, n_obst, kb[0], kb[1], kb[2], kb[3], nlist, lane);
         else n_near = build_near_list(tile, n_obst, x, y, 3.9, nlist, lane);
     } else if (moving)
-        n_near = stage_near(obb_s, src, n_obst, kb[0], kb[1], kb[2], kb[3], tile, nlist, lane);
-    else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
+        n_near = stage_near(obb_s, src, n_obst, kb[0], kb[1], kb[2], kb[3], tile, nlist, lane, nullptr, nullptr, &obb_pre);
+    else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane, nullptr, nullptr, &obb_pre);
     wsync();
     ST_T(0);
 
@@ -1177,7 +1182,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     wsync();                                                  // the near list (same words) is dead
     const double lr = LIDAR_RANGE + 1e-6;
     const uint8_t* eflag_s = p.eflag + (size_t)scene * eflag_stride(p.max_obst);
-    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane, eflag_s, cfl)
+    const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane, eflag_s, cfl, &obb_pre)
                               : build_near_list(tile, n_obst, x, y, lr, llist, lane);
     wsync();
     {
