@@ -15,6 +15,7 @@
 #include "hope_env.h"
 #include "hope_internal.h"
 #include "hope_step_kernel.h"
+#include "hope_obs_pair.h"
 
 using namespace hope;
 
@@ -267,9 +268,13 @@ __global__ void k_set_scene_consts(int n, const int32_t* ids, const double* star
 }
 
 // hope_env_create's hardware-queue measurement: one wave that idles for `ticks` of the 100 MHz real-time counter
-__global__ void k_spin(long long ticks) {
+// and reports when it ran (stamps[0] = first, stamps[1] = last reading of the counter, which all queues share): two spins on streams of
+// DIFFERENT hardware queues overlap in time, two on the same queue cannot -- decided on the GPU's own clock, not the host's
+__global__ void k_spin(long long ticks, long long* stamps) {
     const long long t0 = (long long)wall_clock64();
-    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    long long t1 = t0;
+    while (t1 - t0 < ticks) { __builtin_amdgcn_s_sleep(16); t1 = (long long)wall_clock64(); }
+    if (stamps && threadIdx.x == 0) { stamps[0] = t0; stamps[1] = t1; }
 }
 
 __global__ void k_debug_math(int fn, int n, const double* a, const double* b, double* out) {
@@ -289,6 +294,7 @@ __global__ void k_debug_math(int fn, int n, const double* a, const double* b, do
         case 9: r = hm_exp(x); break;
         case 10: r = sqrt(x); break;
         case 12: r = div_by_20(x); break;                  // k_kinematics' division by MINI_ITER (hope_step_kernel.h)
+        case 13: r = mask_fraction((int)x); break;         // the action mask's k / n_iter (hope_step_kernel.h)
         default: r = x / y; break;
     }
     out[i] = r;
@@ -520,8 +526,13 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
     size_t lds = step_lds_bytes(max_obstacles);
     size_t lds_rs = rs_lds_bytes(max_obstacles);
-    if (lds > 160 * 1024 || lds_rs > 160 * 1024 || max_obstacles > 255 || n_scenes >= RS_LIST_MAX_SCENES)
-        return fail(HOPE_EINVAL, "hope_env_create: max_obstacles too large for the 160 KiB LDS tile (or > 255), or more than 2^24 - 1 scenes per handle");
+    if (max_obstacles > HOPE_MAX_OBSTACLES)
+        return fail(HOPE_EINVAL, "hope_env_create: max_obstacles " + std::to_string(max_obstacles) + " exceeds HOPE_MAX_OBSTACLES (" +
+                                 std::to_string(HOPE_MAX_OBSTACLES) + "): the Reeds-Shepp queue entry carries the obstacle count in 8 bits");
+    if (lds > 160 * 1024 || lds_rs > 160 * 1024)
+        return fail(HOPE_EINVAL, "hope_env_create: max_obstacles " + std::to_string(max_obstacles) + " does not fit the 160 KiB LDS tile of the step / search kernels");
+    if (n_scenes >= RS_LIST_MAX_SCENES)
+        return fail(HOPE_EINVAL, "hope_env_create: more than 2^24 - 1 scenes per handle");
     hope_env* h = new (std::nothrow) hope_env();
     if (!h) return fail(HOPE_ENOMEM, "hope_env_create: host allocation failed");
     h->n = n_scenes; h->max_obst = max_obstacles; h->device = device_id; h->flags = flags;
@@ -699,30 +710,39 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         if (!no_check) {
             const auto t_begin = std::chrono::steady_clock::now();
             const long long ticks = 10000;                    // 100 us at 100 MHz
-            auto pair_ms = [&](hipStream_t a, hipStream_t b) -> double {   // both spinning "at once": ~0.1 ms on two queues, ~0.2 ms on one
-                hipStreamSynchronize(a); hipStreamSynchronize(b);
-                const auto t0 = std::chrono::steady_clock::now();
-                hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
-                hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
-                hipStreamSynchronize(a); hipStreamSynchronize(b);
-                return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            // Two spin kernels, one per stream: they OVERLAP on the GPU's clock iff the streams sit on different hardware queues.  An overlap
+            // is proof of two queues; its absence may be a late second launch (a loaded host), so a pair that did not overlap is tried up to
+            // three times before it counts as one queue (the host's wall clock with fixed thresholds misread pairs on a busy box).
+            long long* stamps = nullptr;                      // [2][2], host-visible
+            if (hipHostMalloc((void**)&stamps, 4 * sizeof(long long), hipHostMallocDefault) != hipSuccess) stamps = nullptr;
+            bool ok = stamps != nullptr;
+            auto pair_overlaps = [&](hipStream_t a, hipStream_t b) -> int {   // 1 / 0, -1: the measurement is not to be trusted
+                for (int rep_ = 0; rep_ < 3; rep_++) {
+                    hipStreamSynchronize(a); hipStreamSynchronize(b);
+                    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, stamps);
+                    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks, stamps + 2);
+                    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+                    const long long lo = std::max(stamps[0], stamps[2]), hi = std::min(stamps[1], stamps[3]);
+                    if (hi - lo > ticks / 4) return 1;        // ran side by side for > 25 us
+                    if (std::max(stamps[1], stamps[3]) - std::min(stamps[0], stamps[2]) > 20 * ticks) return -1;   // > 2 ms: the GPU is shared
+                }
+                return 0;
             };
             created[0] = nullptr;
-            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, created[1], 100LL);      // (first launch of the kernel: module load, not measured)
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, created[1], 100LL, (long long*)nullptr);      // (first launch of the kernel: module load, not measured)
             hipStreamSynchronize(created[1]);
             int rep[hope_env::MAX_CHAINS], n_cls = 0;
-            bool ok = true;
             for (int c = 0; c < hope_env::MAX_CHAINS && ok; c++) {
                 int found = -1;
-                for (int k = 0; k < n_cls && found < 0; k++) {
-                    double t = pair_ms(created[rep[k]], created[c]);
-                    if (t > 0.15 && t < 0.19) t = std::min(t, pair_ms(created[rep[k]], created[c]));   // near the threshold: once more
-                    if (t >= 0.17) found = k;                 // serialised: the same hardware queue
-                    if (t > 2.0) ok = false;                  // something else is using the GPU: do not trust any of it
+                for (int k = 0; k < n_cls && found < 0 && ok; k++) {
+                    const int ov = pair_overlaps(created[rep[k]], created[c]);
+                    if (ov < 0) ok = false;                   // something else is using the GPU: do not trust any of it
+                    else if (ov == 0) found = k;              // serialised: the same hardware queue
                 }
                 if (found < 0) { rep[n_cls] = c; found = n_cls++; }
                 cls[c] = found;
             }
+            if (stamps) hipHostFree(stamps);
             HIPCHK(hipGetLastError());
             h->queue_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
             if (!ok) { for (int c = 0; c < hope_env::MAX_CHAINS; c++) cls[c] = -1; n_cls = 0; }
@@ -756,6 +776,11 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
                 }
                 for (int r = 1; r < hope_env::MAX_CHAINS; r++) perm[r] = newperm[r];
             }
+        }
+        if (getenv("HOPE_DEBUG")) {
+            fprintf(stderr, "hope_env_create: stream of role 1..7 =");
+            for (int r = 1; r < hope_env::MAX_CHAINS; r++) fprintf(stderr, " %d(q%d)", perm[r], cls[perm[r]]);
+            fprintf(stderr, "; caller q%d; queue check %.2f ms\n", cls[0], h->queue_check_ms);
         }
         for (int r = 1; r < hope_env::MAX_CHAINS; r++) h->side[r] = created[perm[r]];
         h->queue_of_role[0] = cls[0];
@@ -1167,6 +1192,14 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (split) {
             if (tm) tm->begin(HOPE_K_STEP, so);
             const size_t lds_obs = obs_wpc[i & 1] > 0 ? std::max(lds, (size_t)((158 * 1024 / obs_wpc[i & 1]) & ~255)) : lds;
+            // small-tile class: two scenes per wave (hope_obs_pair.h; HOPE_OBS_PAIR=0: the one-scene kernel, its reference)
+            static const bool obs_pair = !(getenv("HOPE_OBS_PAIR") && atoi(getenv("HOPE_OBS_PAIR")) == 0);
+            if (obs_pair && p.tile_cap == SMALL_TILE && !(stages & 0x8000)) {          // (0x8000: A/B switch of the tests, one-scene kernel)
+                const dim3 pgrid((p.n_list + 1) / 2);
+                const size_t lds_pair = obs_wpc[i & 1] > 0 ? std::max(OP_LDS_BYTES, (size_t)((158 * 1024 / obs_wpc[i & 1]) & ~255)) : OP_LDS_BYTES;
+                if (of64) hipLaunchKernelGGL((k_obs_pair<double>), pgrid, block, lds_pair, so, p);
+                else hipLaunchKernelGGL((k_obs_pair<float>), pgrid, block, lds_pair, so, p);
+            } else
             launch_env_step<2>(of64, af64, grid, block, lds_obs, so, p);
             if (tm) tm->end(so);
             if (post_last && !post_rs) launch_post();
@@ -1627,6 +1660,9 @@ int hope_env_set_dlp_cases(hope_env_t* h, int n_cases, const double* dest, const
     }
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    // a relaxed commit still pending takes over FIRST: its class lists were built with the old cases, and refresh_pool_lists_sync
+    // below rebuilds the lists of the set that is active when it runs
+    { int rcp = apply_pending_pool(h, true); if (rcp != HOPE_OK) return rcp; }
     HIPCHK(hipDeviceSynchronize());
     for (void*& q : h->dlp_mem) { if (q) hipFree(q); q = nullptr; }
     h->dlp = DlpCases{};
@@ -1738,6 +1774,7 @@ int hope_env_download_pool_state(hope_env_t* h, int32_t* pool_index, uint32_t* e
     if (!h) return fail(HOPE_EINVAL, "hope_env_download_pool_state: null handle");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    { int rcp = apply_pending_pool(h, true); if (rcp != HOPE_OK) return rcp; }     // the snapshot belongs to the pool the next step draws from
     HIPCHK(hipDeviceSynchronize());
     if (pool_index) HIPCHK(hipMemcpy(pool_index, h->cur_pool, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (episode) HIPCHK(hipMemcpy(episode, h->episode, (size_t)h->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1748,6 +1785,7 @@ int hope_env_restore_maps(hope_env_t* h, const uint8_t* drawn /* host [N]: the s
                           uint64_t pool_generation) {
     { int rcs = settle_rs(h); if (rcs != HOPE_OK) return rcs; }
     if (!h || !drawn || !episode) return fail(HOPE_EINVAL, "hope_env_restore_maps: null argument");
+    { DeviceGuard guard0(h->device); int rcp = apply_pending_pool(h, true); if (rcp != HOPE_OK) return rcp; }   // (compare generations after a pending swap)
     if (h->pool_n <= 0 && h->dlp.n_cases <= 0) return fail(HOPE_ESTATE, "hope_env_restore_maps: no scene pool");
     if (pool_generation != 0 && pool_generation != h->pool_generation)
         return fail(HOPE_ESTATE, "hope_env_restore_maps: the scene pool has been replaced since the snapshot (pool generation " +

@@ -16,8 +16,8 @@ struct RsWord {
 };
 constexpr int RS_WORDS_PER_SCENE = 48;   // >= the 46 candidate words of generate_path
 // A Reeds-Shepp queue entry (rs_list, written by k_rs_compact): scene << 8 | obstacle count -- the validation kernel requests the
-// scene's obstacle view with the record's header instead of behind it (n_obst <= 255: the 160 KiB LDS tile bounds max_obstacles far
-// below; < 2^24 scenes per handle).  The scene sits in the HIGH bits and comes out by a shift on purpose: with `entry & 0xFFFFFF`
+// scene's obstacle view with the record's header instead of behind it (n_obst <= HOPE_MAX_OBSTACLES = 255, enforced by
+// hope_env_create -- the LDS formulas alone would allow more --; < 2^24 scenes per handle).  The scene sits in the HIGH bits and comes out by a shift on purpose: with `entry & 0xFFFFFF`
 // the AMDGPU backend (ROCm 7.2) selected a 24-bit multiply for the `scene * SC_WORDS` address, dropped the mask as redundant for
 // it, and then widened the multiply back to v_mad_u64_u32 on the UNMASKED register -- k_rs_words faulted on the first packed entry.
 constexpr int RS_LIST_MAX_SCENES = 1 << 24;

@@ -1118,7 +1118,9 @@ __device__ __forceinline__ unsigned long long screen_words(int lane, int n_paths
                     double j = ceil((a - c - u0) * inv_step);
                     j = j < 0.0 ? 0.0 : j;
                     const double u = u0 + j * step;
-                    si = (u > SCREEN_EPS && u < al - SCREEN_EPS) ? i : 5;           // 5: no usable sample for this lane
+                    // (a segment shorter than the remainder a cusp carries into it, |u0| > |l|, has NO lattice samples at all --
+                    // reeds_shepp.py:488, n_i = 0 below --: u = u0 + j step inside it would be a pose the reference never visits)
+                    si = (fabs(u0) <= al && u > SCREEN_EPS && u < al - SCREEN_EPS) ? i : 5;   // 5: no usable sample for this lane
                     pdv = l > 0.0 ? u : -u;
                 }
                 const double n = fabs(u0) > al ? 0.0 : floor((al - u0) * inv_step) + 1.0;

@@ -28,8 +28,35 @@
 #define HOPE_MASK_MG 4      // action-mask rows probed together (A/B builds: -DHOPE_MASK_MG=8 measured 1.3 % slower)
 #endif
 #include "hope_env.h"
+#ifndef HOPE_STEP_SYNC_FULL
+#define HOPE_STEP_SYNC_FULL 0   // 1: every LDS synchronisation point of the step kernel is a __syncthreads() (rounds 1-5)
+#endif
+#ifndef HOPE_MASK_FRAC_TABLE
+#define HOPE_MASK_FRAC_TABLE 0  // 1: the mask's k / n_iter from a table in constant memory (round 5: a dependent load at the kernel's very end)
+#endif
 
 namespace hope {
+
+// LDS ordering inside the ONE wave of a step-kernel workgroup.  A __syncthreads() is a workgroup-scope fence: the compiler puts
+// s_waitcnt vmcnt(0) in front of it, so EVERY synchronisation point also waited for the wave's outstanding global loads and stores --
+// the table / constant loads requested early "to be in flight" during the LDS phases, and (gfx9 counts stores in vmcnt too) the
+// acknowledgement of stores just issued, e.g. the lidar row in front of the mask stage: hidden memory round trips in a kernel whose
+// waves spend most of their life waiting.  LDS instructions of one wave execute in order, so LDS write -> read across lanes only
+// needs the compiler not to reorder them (and the returned data: lgkmcnt).  No lane of these kernels reads GLOBAL memory another lane
+// of the same launch wrote.
+__device__ __forceinline__ void ssync() {
+    if (HOPE_STEP_SYNC_FULL) __syncthreads();
+    else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+}
+
+// k / 10 as IEEE division rounds it, without a table lookup or a division (the argument of div_by_20 below, checked for all eleven
+// k in tests/test_math.py): q0 = RN(k R) with R = RN(0.1), the remainder k - 10 q0 exactly by fma, the correction by a second fma
+__device__ __forceinline__ double mask_fraction(int k) {
+    const double x = (double)k, R = 0.1;
+    const double q0 = x * R;
+    const double r = fma(-q0, 10.0, x);
+    return fma(r, R, q0);
+}
 
 // Dragon-Lake-Parking cases resident on the device (hope_env_set_dlp_cases): what ParkingMapDLP.reset draws from
 // (src/env/parking_map_dlp.py:38-86).  A pool list entry j <= -2 names case -2 - j.
@@ -406,13 +433,13 @@ __device__ __forceinline__ int stage_near(const float4* obb, const double2* src,
         if (near) list[cnt + __popcll(m & ((1ull << lane) - 1))] = o;
         cnt += __popcll(m);
     }
-    wsync();
+    ssync();
     double2* dst = (double2*)tile;
     for (int i = lane; i < 4 * cnt; i += WAVE) {
         dst[i] = src[4 * list[i >> 2] + (i & 3)];
         if (gflags && (i & 3) == 0) lflags[i >> 2] = gflags[list[i >> 2]];       // the staged obstacles' shape flags (lidar cull)
     }
-    wsync();
+    ssync();
     for (int i = lane; i < cnt; i += WAVE) list[i] = i;
     return cnt;
 }
@@ -670,13 +697,13 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
             terms[4 * j + q][2 * ls] = div_by_20(speed * cj[j] * STEP_LENGTH);      // ... / MINI_ITER, correctly rounded (below)
             terms[4 * j + q][2 * ls + 1] = div_by_20(speed * sj[j] * STEP_LENGTH);
         }
-        wsync();
+        ssync();
         if (lane < 2 * KIN_SCENES_PER_BLOCK) {
 #pragma unroll
             for (int m = 0; m < MINI_ITER; m++) acc += terms[m][lane];            // x += ..., y += ... in micro-step order
             buf[(lane >> 1) * KIN_WORDS + 30 + 10 * (lane & 1) + r] = acc;        // the position after sub-step r + 1
         }
-        wsync();
+        ssync();
         h = hj[KJ - 1];
         h = h + dh; h = h + dh; h = h + dh; h = h + dh;      // four steps of the sequential chain
     }
@@ -764,7 +791,7 @@ __device__ __forceinline__ void wave_kinematics(const void* actions, int scene, 
     double acc = lane == 0 ? x0 : y0;                     // lane 0: x, lane 1: y
 #pragma unroll
     for (int ph = 0; ph < 2; ph++) {                      // micro-steps [0, 128) and [128, 200): 2 x 128 doubles of region A
-        wsync();
+        ssync();
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
             const int j = 2 * ph + jj, m = lane + WAVE * j;
@@ -773,7 +800,7 @@ __device__ __forceinline__ void wave_kinematics(const void* actions, int scene, 
                 scr[2 * (m - 2 * WAVE * ph) + 1] = div_by_20(speed * sm[j] * STEP_LENGTH);
             }
         }
-        wsync();
+        ssync();
         if (lane < 2) {
             const int m_end = ph == 0 ? 2 * WAVE : NM;
 #pragma unroll 4
@@ -783,7 +810,7 @@ __device__ __forceinline__ void wave_kinematics(const void* actions, int scene, 
             }
         }
     }
-    wsync();
+    ssync();
     // arrival_possible of the ten poses, the box around the hulls of the start pose and the ten poses: lane k = pose k, lane 10 = start
     const double c_0 = readlane_d(cm[0], 0), s_0 = readlane_d(sm[0], 0);                      // heading h_0 = the start heading
     const bool pose = lane < NUM_STEP;
@@ -802,7 +829,7 @@ __device__ __forceinline__ void wave_kinematics(const void* actions, int scene, 
     by0 = fmin(by0, dpp_d<0xB1>(by0)); by0 = fmin(by0, dpp_d<0x4E>(by0)); by0 = fmin(by0, dpp_d<0x141>(by0)); by0 = fmin(by0, dpp_d<0x140>(by0));
     by1 = fmax(by1, dpp_d<0xB1>(by1)); by1 = fmax(by1, dpp_d<0x4E>(by1)); by1 = fmax(by1, dpp_d<0x141>(by1)); by1 = fmax(by1, dpp_d<0x140>(by1));
     kb[0] = readlane_d(bx0, 0); kb[1] = readlane_d(bx1, 0); kb[2] = readlane_d(by0, 0); kb[3] = readlane_d(by1, 0);
-    wsync();
+    ssync();
 }
 
 // Cycle accounting of the step kernel (the <float, float, true> instantiation, launched when HOPE_STEP_TIMING is set;
@@ -896,7 +923,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     int t = p.tstep[scene];
     double ct = 0, sn = 0;       // cos/sin of the final heading
     if (PART == 2) { ct = p.cs[2 * (size_t)scene]; sn = p.cs[2 * (size_t)scene + 1]; }   // hm_sincos(h) as the motion launch computed it
-    wsync();
+    ssync();
     // the sub-step poses: from k_kinematics' record, or (small batches, FKIN) by this wave itself while the tile's loads are in flight
     int apmask_k = 0;
     double kb[4] = {0.0, 0.0, 0.0, 0.0};                 // box around the step's hulls
@@ -921,7 +948,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     } else if (moving)
         n_near = stage_near(obb_s, src, n_obst, kb[0], kb[1], kb[2], kb[3], tile, nlist, lane, nullptr, nullptr, &obb_pre);
     else n_near = stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane, nullptr, nullptr, &obb_pre);
-    wsync();
+    ssync();
     ST_T(0);
 
     if (moving) {
@@ -929,7 +956,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         // they do not depend on the collision outcome, only where we stop does
         if (!FKIN && lane < 50) scr[LDS_HB + lane] = kinv;
         apmask = FKIN ? apmask_k : __builtin_amdgcn_readlane(__double2loint(kinv), 50);        // arrival_possible of the ten poses (k_kinematics)
-        wsync();
+        ssync();
 
         // ---- sub-step loop (car_parking_base.py:259-271) ------------------------------------------
         // The ten poses are known, so several sub-steps can be examined per pass when the near list is short:
@@ -1078,7 +1105,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
                 float4* gobb = const_cast<float4*>(p.obb) + (size_t)scene * p.max_obst;
                 double* gsc = const_cast<double*>(p.scene_c) + (size_t)scene * SC_WORDS;
                 int nob;
-                wsync();
+                ssync();
                 if (j >= 0) {                                           // a complete scene of the pool
                     nob = cp->pool_nobst[j];
                     const double* pv = cp->pool_verts + (size_t)j * p.max_obst * 8;
@@ -1103,7 +1130,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
                     nob = draw_dlp_case(cp->dlp, -2 - j, mix64(key ^ 0xD1B54A32D192ED03ull), p.max_obst, (double*)gdst, gobb,
                                         cp->fverts + (size_t)scene * p.max_obst * 2, cp->fbox + (size_t)scene * p.max_obst,
                                         cp->eflag + (size_t)scene * eflag_stride(p.max_obst), c24, tile, cp->pool_overflow, lane);
-                    wsync();
+                    ssync();
                     if (lane < SC_WORDS) gsc[lane] = c24[lane];
                     sc = c24;
                 }
@@ -1118,7 +1145,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
                 // (one-launch form: the staged shape flags belong to the old map; without them the new episode's first lidar scan
                 // simply runs without the back-face cull)
                 if (PART == 0) for (int i_ = lane; 4 * i_ < nob; i_ += WAVE) ((uint32_t*)cfl)[i_] = 0;
-                wsync();
+                ssync();
             }
         }
         x = sc[SC_START]; y = sc[SC_START + 1]; h = sc[SC_START + 2];
@@ -1126,10 +1153,10 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         t = 1;                                                          // reset: t = 0, then step() -> t = 1
         hm_sincos(h, &sn, &ct);
         // the action-less step's status decides whether _get_reward runs (it only touches accum_arrive_reward)
-        wsync();
+        ssync();
         const int n_near0 = (PART == 0 || redrawn) ? build_near_list(tile, n_obst, x, y, 3.9, nlist, lane)
                                                    : stage_near(obb_s, src, n_obst, x - 3.9, x + 3.9, y - 3.9, y + 3.9, tile, nlist, lane);
-        wsync();
+        ssync();
         const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
         bool cont = !detect_collision(x, y, ct, sn, tile, nlist, n_near0, xl, lane, TIMING ? &cen_und : nullptr) && !(x > xmax || x < xmin || y > ymax || y < ymin);
         if (cont) {
@@ -1179,12 +1206,12 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     // its box; 1e-6 m of slack against the rounding of the ego transform), so only those are transformed and measured:
     // a lot of 100 obstacles has a dozen within 10 m.  llist: their indices, then (compacted in place) the kept rings'.
     int* llist = keep;
-    wsync();                                                  // the near list (same words) is dead
+    ssync();                                                  // the near list (same words) is dead
     const double lr = LIDAR_RANGE + 1e-6;
     const uint8_t* eflag_s = p.eflag + (size_t)scene * eflag_stride(p.max_obst);
     const int n_l = PART == 2 ? stage_near(obb_s, src, n_obst, x - lr, x + lr, y - lr, y + lr, tile, llist, lane, eflag_s, cfl, &obb_pre)
                               : build_near_list(tile, n_obst, x, y, lr, llist, lane);
-    wsync();
+    ssync();
     {
         const double a = ct, b = sn;
         const double x_off = -x * a - y * b;
@@ -1196,7 +1223,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
             tile[2 * v + 1] = (-b) * px + a * py + y_off;
         }
     }
-    wsync();
+    ssync();
     // ring kept iff distance(ring, origin) < lidar_range (:69); 4 consecutive lanes = one ring
     int n_k = 0;
     for (int base = 0; base < 4 * n_l; base += WAVE) {
@@ -1253,7 +1280,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         if (kq) llist[n_k + __popcll(km & ((1ull << lane) - 1))] = o;   // in place: writes stay below the next chunk's reads
         n_k += __popcll(km);
     }
-    wsync();
+    ssync();
     const int n_kslots = 4 * n_k;
     ST_T(3);
     // beams: lane l owns beams l and l+64.  Two passes (SIMT pays for the union of lanes, and every edge is
@@ -1271,11 +1298,11 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     constexpr int LQ = 384;
     best[lane] = 0x7ff0000000000000ull;                                      // +inf
     best[lane + 64] = 0x7ff0000000000000ull;
-    wsync();
+    ssync();
     int qn = 0;
     auto drain = [&]() {
         const unsigned long long td_ = TIMING ? __builtin_readcyclecounter() : 0;
-        wsync();
+        ssync();
         for (int q0 = 0; q0 < qn; q0 += WAVE) {
             int q = q0 + lane;
             if (q < qn) {
@@ -1290,7 +1317,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
                 if (r < INFINITY) atomicMin(&best[bi], (unsigned long long)__double_as_longlong(r));
             }
         }
-        wsync();
+        ssync();
         qn = 0;
         if (TIMING) { const unsigned long long dt_ = __builtin_readcyclecounter() - td_; tsec[6] += dt_; t0_ += dt_; }
     };
@@ -1426,13 +1453,13 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     if (!p.action_mask || (p.stages & 0x2000)) { ST_FLUSH(); return; }    // 0x2000: internal profiling switch
 
     // ---- action mask (action_mask.py:166-196) ----------------------------------------------------------
-    wsync();                                                      // region A: best[]/queue[] are dead from here
+    ssync();                                                      // region A: best[]/queue[] are dead from here
     double* xs = scr + LDS_X;                                     // lidar_obs = clip(raw,0,10) + base (:170)
     xs[i0] = clipd(lid0, 0, 10) + base0;
     if (has1) xs[i1] = clipd(lid1, 0, 10) + base1;
-    wsync();
+    ssync();
     if (lane == 0) xs[NBEAM] = xs[0];                             // circular (:158)
-    wsync();
+    ssync();
     // step_len[a] = min over the 1200 upsampled beams l of cnt(l,a) = #{k : tab[l][k][a] <= d_l} (tab is prefix-maxed
     // over k, so the count IS the first-exceed index of :176-177).
     //
@@ -1556,7 +1583,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         mn = min(mn, o);
     }
     mn = max(0, min(NITER, mn));
-    double mo = MASK_STEP_FRACTION[mn];                           // mn / n_iter (a float64 division per scene otherwise)
+    double mo = HOPE_MASK_FRAC_TABLE ? MASK_STEP_FRACTION[mn] : mask_fraction(mn);   // mn / n_iter (a float64 division per scene otherwise)
     unsigned long long nz = __ballot(lane < NACT && mn > 0);
     if (nz == 0) mo = clipd(mo, 0.01, 1);                          // all-zero -> 0.01 (:182-183)
     if (lane < NACT) ((OT*)p.action_mask)[(size_t)NACT * scene + lane] = (OT)mo;

@@ -159,7 +159,11 @@ typedef struct hope_step_out {
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Replaces CarParking.__init__ (car_parking_base.py:48-115) for n_scenes parallel environments.
- * max_obstacles bounds the obstacle count of any scene (LDS tile = 64 B x max_obstacles per wave). */
+ * max_obstacles bounds the obstacle count of any scene (LDS tile = 64 B x max_obstacles per wave).  It is limited to
+ * HOPE_MAX_OBSTACLES: the Reeds-Shepp queue entry carries a scene's obstacle count in 8 bits (the LDS formulas alone would admit
+ * over a thousand; the reference's largest map, a Dragon-Lake case after its +-20 m cull, holds 125).  A larger value -- or one
+ * whose tile does not fit the 160 KiB LDS of a CU, or n_scenes >= 2^24 -- fails with HOPE_EINVAL and a message naming the limit. */
+#define HOPE_MAX_OBSTACLES 255
 int hope_env_create(hope_env_t **out, int n_scenes, int max_obstacles, int device_id, uint32_t flags);
 int hope_env_destroy(hope_env_t *h);                       /* CarParking.close (:536) */
 const char *hope_last_error(void);

@@ -78,8 +78,11 @@ def test_create_rejects_bad_arguments_and_removed_flags():
     assert lib.hope_env_create(C.byref(h), 16, 0, 0, 0) == EINVAL
     assert lib.hope_env_create(C.byref(h), 16, 16, 99, 0) == EINVAL and 'device_id' in _err()
     assert lib.hope_env_create(C.byref(h), 16, 16, 0, 0x20) == EINVAL and 'ABI 7' in _err()          # hipGraph replay: removed
-    assert lib.hope_env_create(C.byref(h), 16, 100000, 0, 0) == EINVAL and 'LDS' in _err()
-    assert lib.hope_env_create(C.byref(h), 16, 300, 0, 0) == EINVAL
+    # each limit is named on its own: the 8-bit obstacle count of the Reeds-Shepp queue entry, not the LDS tile,
+    # is what bounds max_obstacles
+    assert lib.hope_env_create(C.byref(h), 16, 100000, 0, 0) == EINVAL and 'HOPE_MAX_OBSTACLES (255)' in _err()
+    assert lib.hope_env_create(C.byref(h), 16, 300, 0, 0) == EINVAL and 'HOPE_MAX_OBSTACLES' in _err() and 'LDS' not in _err()
+    assert lib.hope_env_create(C.byref(h), 1 << 24, 16, 0, 0) == EINVAL and '2^24' in _err()
     assert not h.value
 
 

@@ -1260,6 +1260,59 @@ def test_pool_refresh_in_the_background_keeps_up_and_matches_the_synchronous_upl
     a.close(); b.close()
 
 
+def test_relaxed_pool_commit_followed_by_new_dlp_cases():
+    """hope_env_set_dlp_cases (and the snapshot calls) must first apply a hope_env_commit_pool_relaxed swap still
+    pending -- its class lists were built with the OLD cases.  Env a: relaxed commit of a new pool, then at once a (smaller) set of
+    Dragon-Lake cases; env b: the same pool with the synchronous hope_env_set_pool, then the same cases.  Same generation, same
+    draws, same outputs; a snapshot of a restores on b."""
+    from hope_amd import ParkingBatch
+    from hope_amd.scenes import DlpScenePool
+    from hope_amd.scene_gen import mixed_arrays, generate_arrays
+    n, mo, P = 2048, 128, 300
+    init = mixed_arrays(n, seed=191, max_obst=mo)
+    first = generate_arrays('Complex', P, seed=192, max_obst=mo)[:5]
+    second = generate_arrays('Extrem', P, seed=193, max_obst=mo)[:5]
+    full = DlpScenePool()
+    few = DlpScenePool()                                            # the first 40 cases only: every list entry <= -2 must stay < 40
+    few.case_set, few.dest = full.case_set[:40].copy(), full.dest[:40].copy()
+    few.start_off = full.start_off[:41].copy()
+    few.starts = full.starts[:int(few.start_off[-1])].copy()
+    a = ParkingBatch(n, mo, obs_dtype=torch.float64)
+    b = ParkingBatch(n, mo, obs_dtype=torch.float64)
+    rng = np.random.default_rng(194)
+    t0 = rng.integers(188, 200, n)
+    for e in (a, b):
+        e.set_scene_arrays(np.arange(n), *init[:5])
+        e.set_draw_class(np.arange(3, n, 4), 1)
+        e.set_dlp_cases(full)
+        e.set_pool(first + (None,))
+        e.reset_obs()
+        e.upload_state(t=t0)
+        e.set_redraw_seed(41)
+    stage = a.pool_staging(P)
+    for dst, src_ in zip(stage, second):
+        dst[...] = src_
+    a.commit_pool(P, relaxed=True)
+    a.set_dlp_cases(few)                                           # applies the pending swap first
+    b.set_pool(second + (None,))
+    b.set_dlp_cases(few)
+    assert a.pool_generation() == b.pool_generation()
+    g = torch.Generator(device='cuda').manual_seed(19)
+    names = ('lidar', 'action_mask', 'target', 'reward', 'status', 'done', 'pose', 'rs_word')
+    for it in range(14):
+        act = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+        a.step(act, auto_reset=True, fresh=True)
+        b.step(act, auto_reset=True, fresh=True)
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(getattr(a, k), getattr(b, k)), (it, k)
+        assert np.array_equal(a.pool_index(), b.pool_index())
+    ia = a.pool_index()
+    assert int((ia <= -2).sum()) > 50 and int((ia >= 0).sum()) > 200 and (-2 - ia[ia <= -2]).max() < 40
+    assert a.pool_overflow() == 0
+    a.close(); b.close()
+
+
 def test_tie_census_no_decision_of_the_geos_slice_comes_near_a_tie():
     """the three predicates whose arithmetic the reference delegates to GEOS -- LinearRing.intersects
     (car_parking_base.py:153-158), Polygon.intersection().area / area > 0.95 (:164-170), LinearRing.distance(origin) < 10
@@ -1321,6 +1374,59 @@ def test_lidar_back_face_cull_changes_no_bit():
                 e.close()
         finally:
             os.environ.pop('HOPE_SPLIT_MIN', None)
+
+
+@pytest.mark.parametrize('f64', [True, False])
+def test_two_scenes_per_wave_observation_equals_the_one_scene_kernel(f64):
+    """Round 6: the observation launch of the small-tile class runs TWO scenes per wavefront (k_obs_pair, hope_obs_pair.h).  Against
+    the one-scene kernel (stage bit 0x8000 selects it) every lidar value and every mask entry must be the same bit: an odd number
+    of small-tile scenes (the last wave's second half is empty), lots of every level incl. Dragon-Lake lots that fit the small
+    tile, episode turnover on new maps, a caller's `active` mask that silences one scene of many pairs, float64 and float32
+    observations.  (The oracle comparisons of this file run the pair kernel wherever they use the two-launch form.)"""
+    import os
+    from hope_amd import ParkingBatch, _lib as L
+    from hope_amd.scene_gen import mixed_arrays, generate_arrays
+    os.environ['HOPE_SPLIT_MIN'] = '1'
+    try:
+        n = 6001
+        arrs = mixed_arrays(n, seed=61, max_obst=128)
+        small = int((arrs[4] <= 32).sum())
+        parts = [generate_arrays(lv, 256, seed=63 + j, max_obst=128) for j, lv in enumerate(('Normal', 'Complex', 'Extrem'))]
+        pool = tuple(np.concatenate([p_[j] for p_ in parts]) for j in range(6))
+        dt = torch.float64 if f64 else torch.float32
+        envs = [ParkingBatch(n, 128, obs_dtype=dt, overlap=True) for _ in range(2)]
+        for e in envs:
+            e.set_scene_arrays(np.arange(n), *arrs[:5])
+            e.set_pool(pool)
+            e.set_dlp_cases()
+            e.set_redraw_seed(5)
+            e.reset_obs()
+            e.upload_state(t=np.random.default_rng(62).integers(150, 200, n))
+        g = torch.Generator(device='cuda').manual_seed(23)
+        rng = np.random.default_rng(64)
+        masked = 0
+        for it in range(36):
+            a = torch.rand((n, 2), device='cuda', generator=g) * 2 - 1
+            act = None
+            if it % 3 == 2:
+                m = rng.random(n) < 0.7
+                act = torch.from_numpy(m.astype(np.uint8)).cuda()
+                masked += int((~m).sum())
+            envs[0].step(a, active=act, auto_reset=True, fresh=True, defer_rs=bool(it % 2))
+            envs[1].step(a, active=act, stages=L.STAGE_ALL | 0x8000, auto_reset=True, fresh=True, defer_rs=bool(it % 2))
+            for e in envs:
+                e.wait_rs()
+            torch.cuda.synchronize()
+            for k in ('lidar', 'action_mask', 'status', 'pose', 'reward', 'rs_word'):
+                assert torch.equal(getattr(envs[0], k), getattr(envs[1], k)), (f64, it, k)
+        lid = envs[0].lidar.cpu().numpy()
+        assert small % 2 == 1
+        assert masked > 5000 and float(lid.min()) < 1.0 and float(lid.max()) > 5.0
+        print('pair kernel vs one-scene kernel: small-tile scenes', small, 'steps 36, masked scene-steps', masked)
+        for e in envs:
+            e.close()
+    finally:
+        os.environ.pop('HOPE_SPLIT_MIN', None)
 
 
 @pytest.mark.parametrize('which', ['generated', 'dragon_lake'])

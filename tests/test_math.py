@@ -98,3 +98,19 @@ def test_kinematics_division_by_20_is_the_ieee_quotient():
     dev, host = out.cpu().numpy(), x / 20.0
     same = dev.view(np.int64) == host.view(np.int64)
     assert same.all(), (int((~same).sum()), x[~same][:3], dev[~same][:3], host[~same][:3])
+
+
+@pytest.mark.gpu
+def test_mask_step_fraction_is_the_ieee_quotient():
+    """the action mask's k / n_iter (action_mask.py:196) is formed without a division or a table: q0 = k R, r = fma(-q0, 10, k),
+    q = fma(r, R, q0) with R = RN(0.1) (hope_step_kernel.h mask_fraction): all eleven values against numpy's quotients"""
+    torch = pytest.importorskip('torch')
+    from hope_amd import _lib as L
+    lib = L.load_library()
+    x = np.arange(0, 11, dtype=np.float64)
+    ta = torch.from_numpy(x).cuda()
+    out = torch.empty_like(ta)
+    L.check(lib.hope_debug_math(13, ta.numel(), C.c_void_p(ta.data_ptr()), None, C.c_void_p(out.data_ptr()), None), 'hope_debug_math')
+    torch.cuda.synchronize()
+    dev, host = out.cpu().numpy(), x / 10.0
+    assert (dev.view(np.int64) == host.view(np.int64)).all(), (dev, host)

@@ -45,7 +45,7 @@ def screen_samples(lengths, lanes):
             if si < 0 and a < c + al:
                 j = max(math.ceil((a - c - u0) * inv), 0.0)
                 u = u0 + j * STEP
-                si = i if (EPS < u < al - EPS) else 5
+                si = i if (abs(u0) <= al and EPS < u < al - EPS) else 5
                 pdv = u if l > 0.0 else -u
             n = 0.0 if abs(u0) > al else math.floor((al - u0) * inv) + 1.0
             r = u0 + n * STEP - al
@@ -105,3 +105,17 @@ def test_screen_samples_survive_ties_at_segment_ends():
                             ln = [float(l1), s2 * n2 * STEP, -s2 * 1.37, s1 * 0.05 * STEP, 2.2]
                             used += check_word(ln)
     assert used > 10000
+
+
+def test_screen_skips_a_short_segment_behind_a_cusp_with_a_large_remainder():
+    """|l_i| < |u0_i| = the remainder the cusp carries in: generate_local_course takes NO lattice sample on that segment
+    (reeds_shepp.py:488), so neither may the screen (it selected pd = 0.15 step on segment 2 of the first word)"""
+    used = 0
+    used += check_word([10.9 * STEP, -5.05 * STEP, 0.3 * STEP])
+    for big in (10.9, 3.95, 7.5, 20.05):
+        for mid in (-5.05, -0.4, -2.95, 4.05):
+            for short in (0.3, -0.3, 0.6, -0.85, 0.05):
+                for tail in ((), (6.3,), (-4.2, 9.1)):
+                    used += check_word([big * STEP, mid * STEP, short * STEP] + [t * STEP for t in tail])
+                    used += check_word([-big * STEP, -mid * STEP, -short * STEP] + [-t * STEP for t in tail])
+    assert used > 1000
