@@ -133,6 +133,8 @@ struct hope_env {
     bool sub_chains_auto = true;                            // HOPE_CHAINS not given: hope_env_step picks (single-class batches, see there)
     hipStream_t side[MAX_CHAINS] = {};                     // [0] unused: chain 0 runs on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAX_CHAINS] = {}, ev_step[2] = {}, ev_segs[2] = {}, ev_post[2] = {};
+    hipEvent_t ev_collect = nullptr;                        // round 6: ONE join point for the caller's stream (the library stream of the other chain's observation collects the rest)
+    bool last_via_steps = false;                            // the last step recorded ev_step[0 / 1] behind both motion launches (the pool's only readers)
     hipEvent_t ev_bev[2] = {};                              // image: fork / join of the static-layer rebuild next to k_bev_prep
     int rs_parity = 0;                                      // which of the two queue counters of a chain this step uses (pipelined steps)
     int queue_of_role[MAX_CHAINS] = {-1, -1, -1, -1, -1, -1, -1, -1};   // measured hardware-queue class of role r's stream ([0]: the NULL stream)
@@ -648,6 +650,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         h->sub_chains = ch ? std::max(1, std::min(hope_env::MAX_CHAINS / 2, atoi(ch))) : 1;
         h->sub_chains_auto = ch == nullptr;
         HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_collect, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_bev[i], hipEventDisableTiming));
         for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&h->ev_step[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_segs[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming)); }
         // HOPE_PRIO=1 (experiment, rejected): highest stream priority for the launch chains (the critical path), lowest for
@@ -805,7 +808,7 @@ static int destroy_impl(hope_env_t* h) {                   // (also the clean-up
     DeviceGuard guard(h->device);
     drain_events(h);
     hipDeviceSynchronize();
-    for (hipEvent_t e : {h->ev_bev[0], h->ev_bev[1], h->ev_fork, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_collect, h->ev_bev[0], h->ev_bev[1], h->ev_fork, h->ev_step[0], h->ev_step[1], h->ev_segs[0], h->ev_segs[1], h->ev_post[0], h->ev_post[1]}) if (e) hipEventDestroy(e);
     for (int i = 0; i < hope_env::MAX_CHAINS; i++) {
         if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
         if (h->side[i]) hipStreamDestroy(h->side[i]);
@@ -1117,6 +1120,10 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         if (defer) HIPCHK(hipStreamWaitEvent(h->side[hope_env::RS_SIDE], h->ev_fork, 0));
     }
     bool joined_on_caller[2] = {false, false}, post_on_rs[2] = {false, false};
+    hipStream_t obs_stream[2] = {nullptr, nullptr};
+    // every chain's motion launch is followed by its ev_step record: those two events cover the pool's readers (the pool upload waits
+    // for them instead of a per-step record on the caller's stream)
+    h->last_via_steps = false;
     for (int i = 0; i < n_chain; i++) {
         const Chain& ch = chains[i];
         const int c = ch.c;
@@ -1142,7 +1149,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // 8 192 scenes 0.205 vs 0.188 ms -- the search chain is the longer one there; HOPE_POST_SEARCH=0 / 1 forces either)
         static const int post_on_search = getenv("HOPE_POST_SEARCH") ? atoi(getenv("HOPE_POST_SEARCH")) : -1;
         const bool post_rs = pipe && want_rs && (post_on_search < 0 ? split : post_on_search != 0);
-        if (i < 2) { joined_on_caller[i] = on_caller; post_on_rs[i] = post_rs; }
+        if (i < 2) { joined_on_caller[i] = on_caller; post_on_rs[i] = post_rs; obs_stream[i] = so; }
         hipStream_t sk = pipe ? so : sc;                        // the stream of the kinematics and the motion launch
         if (pipe && !on_caller) HIPCHK(hipStreamWaitEvent(sk, h->ev_fork, 0));
         p.tile_cap = (c == 0 && n_cls == 2) ? SMALL_TILE : h->max_obst;
@@ -1176,7 +1183,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         else if (fuse_kin) launch_env_step<0, true>(of64, af64, grid, block, lds, sk, p);
         else launch_env_step<0>(of64, af64, grid, block, lds, sk, p);
         if (tm) tm->end(sk);
-        if (fork && n_chain == 2 && (split || pipe || (stages & HOPE_STAGE_IMG))) HIPCHK(hipEventRecord(h->ev_step[i], sk));   // poses final
+        if (fork && n_chain == 2 && (split || pipe || (stages & HOPE_STAGE_IMG))) { HIPCHK(hipEventRecord(h->ev_step[i], sk)); h->last_via_steps = true; }   // poses final
         if (split && !pipe) HIPCHK(hipStreamWaitEvent(so, h->ev_step[i], 0));
         // k_post BEHIND the observation half on that stream: nothing waits for its outputs before the join, the observation is the
         // long launch (0.675 -> 0.669 ms; HOPE_POST_LAST=0: the round-3 order)
@@ -1288,9 +1295,22 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         } else
             for (int i = 1; i < n_streams; i++) { HIPCHK(hipEventRecord(h->ev_join[i], h->side[i])); HIPCHK(hipStreamWaitEvent(s, h->ev_join[i], 0)); }
         if ((stages & HOPE_STAGE_IMG) && n_chain == 2) HIPCHK(hipStreamWaitEvent(s, h->ev_join[2], 0));
-        if (split || pipe1) for (int i = 0; i < 2; i++) {
-            if (!joined_on_caller[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
-            if (post_on_rs[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_post[i], 0));
+        if (split || pipe1) {
+            // Round 6: every event the caller's stream waits for or records is a packet in ITS queue, in front of the next step's
+            // kinematics -- the head of the step's critical cycle: three waits + two records made a 50 us hole behind the observation
+            // launch (profiles/r05_step_timeline_pipelined.txt).  With one chain on the caller's stream the OTHER chain's observation
+            // stream -- it has slack -- waits for the two k_post launches and records ONE event for the caller (HOPE_JOIN_COLLECT=0: the
+            // round-5 joins).
+            static const bool collect_on = !(getenv("HOPE_JOIN_COLLECT") && atoi(getenv("HOPE_JOIN_COLLECT")) == 0);
+            if (collect_on && h->ev_collect && n_chain == 2 && joined_on_caller[0] != joined_on_caller[1]) {
+                const int o = joined_on_caller[0] ? 1 : 0;
+                for (int i = 0; i < 2; i++) if (post_on_rs[i]) HIPCHK(hipStreamWaitEvent(obs_stream[o], h->ev_post[i], 0));
+                HIPCHK(hipEventRecord(h->ev_collect, obs_stream[o]));
+                HIPCHK(hipStreamWaitEvent(s, h->ev_collect, 0));
+            } else for (int i = 0; i < 2; i++) {
+                if (!joined_on_caller[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_join[3 + i], 0));
+                if (post_on_rs[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_post[i], 0));
+            }
         }
     }
     return HOPE_OK;
@@ -1340,7 +1360,7 @@ static int launch_step(hope_env_t* h, const void* actions, const uint8_t* active
     { int rcc = sync_cold(h, s); if (rcc != HOPE_OK) return rcc; }
     struct LastStep {                                       // (the next pool upload must not overwrite a set this step still reads)
         hope_env_t* h; hipStream_t s;
-        ~LastStep() { if (h->pactive >= 0 && h->ev_last_step) hipEventRecord(h->ev_last_step, s); }
+        ~LastStep() { if (h->pactive >= 0 && h->ev_last_step && !h->last_via_steps) hipEventRecord(h->ev_last_step, s); }
     } last_step{h, s};
     if (prof && h->pending.size() > 4096) { int rc = drain_events(h); if (rc) return rc; }
     EventTimer timer(h);
@@ -1546,7 +1566,10 @@ static int commit_pool_impl(hope_env_t* h, int n_pool, bool relaxed) {
     }
     hipStream_t us = h->pool_stream;
     // the target set was the active one until the previous swap: steps enqueued before that swap may still be reading it
-    if (h->pactive >= 0) HIPCHK(hipStreamWaitEvent(us, h->ev_last_step, 0));
+    if (h->pactive >= 0) {
+        HIPCHK(hipStreamWaitEvent(us, h->ev_last_step, 0));
+        if (h->last_via_steps) for (int i = 0; i < 2; i++) HIPCHK(hipStreamWaitEvent(us, h->ev_step[i], 0));   // (the motion launches of the last step)
+    }
     const size_t P = (size_t)n_pool;
     char* dv = (char*)h->pstage_dev;
     {   // only the used prefix of every entry's obstacle tile travels (a 2-D copy: one row per entry): generated lots hold ~7 obstacles of
