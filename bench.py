@@ -652,13 +652,14 @@ def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's
         nn = n * rep
         if omp and can_set:
             O.lib(True).orc_set_num_threads(nt)
-        orc = O.BatchOracle(nn, args.max_obst, omp=omp)
+        orc = O.BatchOracle(nn, args.max_obst, omp=omp, track_traj=False)     # (the trajectory list is a serial Python loop over the scenes)
         tl = lambda x: np.concatenate([x] * rep, axis=0)  # noqa: E731
+        acts_r = [tl(a) for a in acts]                # (outside the timed region: with 128 threads the C call takes ~0.1 s per step)
         orc.set_scenes(np.arange(nn), tl(start), tl(dest), tl(bbox), tl(verts), tl(nvert), tl(nob))
         orc.reset_obs(with_rs=with_rs)
         t0 = time.perf_counter()
-        for a in acts:
-            o = orc.step(tl(a), with_rs=with_rs)
+        for a in acts_r:
+            o = orc.step(a, with_rs=with_rs)
             done = o['status'] != 1
             if done.any():
                 ids = np.nonzero(done)[0]

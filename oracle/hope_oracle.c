@@ -87,6 +87,8 @@ static double g_boxes[NACT][NITER][4][2];
 static double g_hull_base[NBEAM];
 static double g_beam_a[NBEAM], g_beam_b[NBEAM];
 static double *g_dist_star = 0; /* [NL][NACT][NITER] */
+static double g_ds_max[NL];      /* max over (a, k) of g_dist_star[l]: a beam whose scan value reaches it restricts no action */
+static const double *g_ds_max_of = 0; /* the table g_ds_max was computed from */
 
 /* configs.py:108-115: np.arange(0.75, -(0.75+0.075), -0.075) -> start + i*step, 21 values */
 static void build_actions(void) {
@@ -214,6 +216,15 @@ static void build_dist_star(void) {
     free(coarse);
 }
 
+static void refresh_ds_max(void) {
+    for (int l = 0; l < NL; l++) {
+        double m = -INFINITY;
+        for (int q = 0; q < NACT * NITER; q++) m = fmax(m, g_dist_star[(size_t)l * NACT * NITER + q]);
+        g_ds_max[l] = m;
+    }
+    g_ds_max_of = g_dist_star;
+}
+
 /* action_mask.py:145-163 _linear_interpolate on the (120,42,10) table -> (1200,42,10).
  * coarse has room for NBEAM+1 rows (row NBEAM = circular copy of row 0). */
 static void upsample_dist_star(double *coarse) {
@@ -226,6 +237,7 @@ static void upsample_dist_star(double *coarse) {
         const double *x1 = coarse + (j / UPS + 1) * NACT * NITER;
         for (int q = 0; q < NACT * NITER; q++) g_dist_star[j * NACT * NITER + q] = x0[q] * w1 + x1[q] * w2;
     }
+    refresh_ds_max();
 }
 
 /* inject a coarse (120,42,10) table (e.g. the one captured from the reference) and upsample it */
@@ -266,7 +278,7 @@ void orc_set_tables(const double *hull_base, const double *beam_a, const double 
     if (hull_base) memcpy(g_hull_base, hull_base, sizeof(g_hull_base));
     if (beam_a) memcpy(g_beam_a, beam_a, sizeof(g_beam_a));
     if (beam_b) memcpy(g_beam_b, beam_b, sizeof(g_beam_b));
-    if (dist_star) memcpy(g_dist_star, dist_star, sizeof(double) * NL * NACT * NITER);
+    if (dist_star) { memcpy(g_dist_star, dist_star, sizeof(double) * NL * NACT * NITER); refresh_ds_max(); }
 }
 
 /* ===================================================================================== */
@@ -580,8 +592,15 @@ void orc_get_steps(const double *raw_scan, const double *hull_base, const double
         dist_obs[j] = lo[j / UPS] * w1 + lo[j / UPS + 1] * w2;
     }
     long step_len[NACT];
-    for (int a = 0; a < NACT; a++) step_len[a] = 1L << 30;
-    for (int l = 0; l < NL; l++)
+    /* np.min over the 1200 beams of max_step (:178): every beam contributes at most n_iter, so the minimum starts there; and a beam
+     * whose scan value is >= every entry of its 420-entry block has all step_save flags set (max_step = n_iter for all 42 actions)
+     * and cannot lower it -- its block is not read.  Same result, entry for entry; without the skip every scene-step streamed the
+     * whole 4 MB table, and the OpenMP batch loop (bench.py's all-core CPU baseline) stopped scaling at 32 threads on the 128-core
+     * host (profiles/r06_cpu_baseline_threads.txt). */
+    const double *ds_max = (dist_star == g_dist_star && g_ds_max_of == g_dist_star) ? g_ds_max : 0;
+    for (int a = 0; a < NACT; a++) step_len[a] = NITER;
+    for (int l = 0; l < NL; l++) {
+        if (ds_max && dist_obs[l] >= ds_max[l]) continue;
         for (int a = 0; a < NACT; a++) {
             const double *ds = dist_star + ((size_t)l * NACT + a) * NITER;
             int sum = 0, first0 = -1;
@@ -594,6 +613,7 @@ void orc_get_steps(const double *raw_scan, const double *hull_base, const double
             if (sum == NITER) max_step = NITER;
             if (max_step < step_len[a]) step_len[a] = max_step;
         }
+    }
     /* post_process */
     long fwd[NACT / 2], bwd[NACT / 2], f2[NACT / 2], b2[NACT / 2];
     for (int i = 0; i < NACT / 2; i++) { fwd[i] = step_len[i]; bwd[i] = step_len[NACT / 2 + i]; }
@@ -882,14 +902,46 @@ static void rs_interpolate(int ind, double l, int m, double maxc, double ox, dou
     dir[ind] = l > 0.0 ? 1 : -1;
 }
 
-/* :452-507 generate_local_course.  Returns the number of points kept; arrays malloc'ed. */
+/* Per-thread scratch for the Reeds-Shepp sample arrays (stack discipline: mark at entry, release at exit).  A search makes up to
+ * ~60 arrays of up to 13 k points; with malloc / free per array the OpenMP batch loop of bench.py's all-core CPU baseline spent its
+ * time in the allocator's locks on a 128-core host (10.5x on 128 threads).  Chunks are kept for the thread's life. */
+#define ARENA_CHUNKS 64
+static __thread struct { char *chunk[ARENA_CHUNKS]; size_t cap[ARENA_CHUNKS]; int cur; size_t used; } g_arena;
+typedef struct { int cur; size_t used; } arena_mark_t;
+static arena_mark_t arena_mark(void) { arena_mark_t m = {g_arena.cur, g_arena.used}; return m; }
+static void arena_release(arena_mark_t m) { g_arena.cur = m.cur; g_arena.used = m.used; }
+static void *arena_alloc(size_t bytes, int zero) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    for (;;) {
+        int c = g_arena.cur;
+        if (g_arena.chunk[c] && g_arena.used + bytes <= g_arena.cap[c]) {
+            void *q = g_arena.chunk[c] + g_arena.used;
+            g_arena.used += bytes;
+            if (zero) memset(q, 0, bytes);
+            return q;
+        }
+        if (g_arena.chunk[c]) {
+            if (c + 1 >= ARENA_CHUNKS) abort();                 /* (64 chunks of >= 1 MB: a search needs ~6 MB) */
+            g_arena.cur = ++c; g_arena.used = 0;
+        }
+        if (!g_arena.chunk[c] || g_arena.cap[c] < bytes) {      /* a fresh (or too small, unused) slot */
+            size_t cap = bytes > ((size_t)1 << 20) ? bytes : ((size_t)1 << 20);
+            free(g_arena.chunk[c]);
+            g_arena.chunk[c] = (char *)malloc(cap);
+            g_arena.cap[c] = cap;
+            g_arena.used = 0;
+        }
+    }
+}
+
+/* :452-507 generate_local_course.  Returns the number of points kept; arrays from the thread's arena. */
 static int rs_local_course(double L, const double *lengths, const int *mode, int nseg, double maxc,
                            double step_size, double **opx, double **opy, double **opyaw, int **odir) {
     int point_num = (int)(L / step_size) + nseg + 3;
-    double *px = (double *)calloc(point_num, sizeof(double));
-    double *py = (double *)calloc(point_num, sizeof(double));
-    double *pyaw = (double *)calloc(point_num, sizeof(double));
-    int *dir = (int *)calloc(point_num, sizeof(int));
+    double *px = (double *)arena_alloc(point_num * sizeof(double), 1);
+    double *py = (double *)arena_alloc(point_num * sizeof(double), 1);
+    double *pyaw = (double *)arena_alloc(point_num * sizeof(double), 1);
+    int *dir = (int *)arena_alloc(point_num * sizeof(int), 1);
     int ind = 1;
     dir[0] = lengths[0] > 0.0 ? 1 : -1;
     double d = lengths[0] > 0.0 ? step_size : -step_size;
@@ -923,9 +975,6 @@ typedef struct {
     int *dir;
 } rs_path;
 
-static void rs_free_paths(rs_path *p, int n) {
-    for (int i = 0; i < n; i++) { free(p[i].x); free(p[i].y); free(p[i].yaw); free(p[i].dir); }
-}
 
 /* :35-54 calc_all_paths */
 static int rs_calc_all_paths(const double *q0, const double *q1, double maxc, double step_size, rs_path *out) {
@@ -938,8 +987,8 @@ static int rs_calc_all_paths(const double *q0, const double *q1, double maxc, do
         int *ldir;
         int n = rs_local_course(p->w.L, p->w.len, p->w.ct, p->w.n, maxc, step_size * maxc, &lx, &ly, &lyaw, &ldir);
         p->npts = n;
-        p->x = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
-        p->y = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+        p->x = (double *)arena_alloc(sizeof(double) * (n > 0 ? n : 1), 0);
+        p->y = (double *)arena_alloc(sizeof(double) * (n > 0 ? n : 1), 0);
         p->yaw = lyaw;
         p->dir = ldir;
         for (int k = 0; k < n; k++) {
@@ -947,8 +996,6 @@ static int rs_calc_all_paths(const double *q0, const double *q1, double maxc, do
             p->y[k] = -hm_sin(-q0[2]) * lx[k] + hm_cos(-q0[2]) * ly[k] + q0[1];
             p->yaw[k] = pi_2_pi(lyaw[k] + q0[2]);
         }
-        free(lx);
-        free(ly);
         for (int k = 0; k < p->w.n; k++) p->w.len[k] = p->w.len[k] / maxc;
         p->w.L = p->w.L / maxc;
     }
@@ -960,6 +1007,7 @@ int orc_rs_all_paths(const double *q0, const double *q1, double maxc, double ste
                      int32_t *nseg, int32_t *ctypes, double *lengths, double *L, int32_t *npts,
                      double *first3, double *last3, double *sums) {
     rs_path P[RS_MAXP];
+    const arena_mark_t am_ = arena_mark();
     int n = rs_calc_all_paths(q0, q1, maxc, step_size, P);
     for (int i = 0; i < n && i < max_paths; i++) {
         nseg[i] = P[i].w.n;
@@ -980,7 +1028,8 @@ int orc_rs_all_paths(const double *q0, const double *q1, double maxc, double ste
         for (int k = 0; k < np_; k++) { sx += P[i].x[k]; sy += P[i].y[k]; sw += P[i].yaw[k]; sd += P[i].dir[k]; }
         sums[4 * i] = sx; sums[4 * i + 1] = sy; sums[4 * i + 2] = sw; sums[4 * i + 3] = sd;
     }
-    rs_free_paths(P, n);
+    (void)n;
+    arena_release(am_);
     return n;
 }
 
@@ -988,13 +1037,15 @@ int orc_rs_all_paths(const double *q0, const double *q1, double maxc, double ste
 int orc_rs_path_samples(const double *q0, const double *q1, double maxc, double step_size, int pi,
                         int cap, double *xyz) {
     rs_path P[RS_MAXP];
+    const arena_mark_t am_ = arena_mark();
     int n = rs_calc_all_paths(q0, q1, maxc, step_size, P);
     int np_ = -1;
     if (pi < n) {
         np_ = P[pi].npts;
         for (int k = 0; k < np_ && k < cap; k++) { xyz[3 * k] = P[pi].x[k]; xyz[3 * k + 1] = P[pi].y[k]; xyz[3 * k + 2] = P[pi].yaw[k]; }
     }
-    rs_free_paths(P, n);
+    (void)n;
+    arena_release(am_);
     return np_;
 }
 
@@ -1012,8 +1063,9 @@ int orc_is_traj_valid(const double *traj, int T, const double *verts, const int3
     }
     if (mnx < bbox[0] || mxx > bbox[1] || mny < bbox[2] || mxy > bbox[3]) return 0;
     /* hull edges per pose: (corner k -> corner k+1), car_coords1=coords[:4], car_coords2=coords[1:] */
-    double *vx1 = (double *)malloc(sizeof(double) * 4 * T), *vy1 = (double *)malloc(sizeof(double) * 4 * T);
-    double *vx2 = (double *)malloc(sizeof(double) * 4 * T), *vy2 = (double *)malloc(sizeof(double) * 4 * T);
+    const arena_mark_t vm_ = arena_mark();
+    double *vx1 = (double *)arena_alloc(sizeof(double) * 4 * T, 0), *vy1 = (double *)arena_alloc(sizeof(double) * 4 * T, 0);
+    double *vx2 = (double *)arena_alloc(sizeof(double) * 4 * T, 0), *vy2 = (double *)arena_alloc(sizeof(double) * 4 * T, 0);
     double x_max = -INFINITY, x_min = INFINITY, y_max = -INFINITY, y_min = INFINITY;
     for (int t = 0; t < T; t++) {
         double ct = hm_cos(traj[3 * t + 2]), st = hm_sin(traj[3 * t + 2]);
@@ -1065,7 +1117,7 @@ int orc_is_traj_valid(const double *traj, int T, const double *verts, const int3
             }
         }
     }
-    free(vx1); free(vy1); free(vx2); free(vy2);
+    arena_release(vm_);
     (void)n_edges;
     return collide ? 0 : 1;
 }
@@ -1113,6 +1165,7 @@ int orc_find_rs_path(const double *pose, const double *dest, const double *verts
      * value is a constant of the path, kept literal so that both math flavours and the kernels share it */
     const double radius = 0.3327130214085973;
     rs_path P[RS_MAXP];
+    const arena_mark_t am_ = arena_mark();
     int n = rs_calc_all_paths(pose, dest, radius, 0.1, P);
     int found = 0, ntested = 0;
     if (n > 0) {
@@ -1127,10 +1180,11 @@ int orc_find_rs_path(const double *pose, const double *dest, const double *verts
             if (min_path_len < 0) min_path_len = P[pi].w.L;
             if (P[pi].w.L > 1.6 * min_path_len && idx > 2) break;
             int T = P[pi].npts;
-            double *traj = (double *)malloc(sizeof(double) * 3 * (T > 0 ? T : 1));
+            const arena_mark_t tm_ = arena_mark();
+            double *traj = (double *)arena_alloc(sizeof(double) * 3 * (T > 0 ? T : 1), 0);
             for (int k = 0; k < T; k++) { traj[3 * k] = P[pi].x[k]; traj[3 * k + 1] = P[pi].y[k]; traj[3 * k + 2] = P[pi].yaw[k]; }
             int ok = orc_is_traj_valid(traj, T, verts, nvert, n_obst, bbox);
-            free(traj);
+            arena_release(tm_);
             ntested++;
             if (ok) {
                 found = 1;
@@ -1150,7 +1204,8 @@ int orc_find_rs_path(const double *pose, const double *dest, const double *verts
         *out_L = 0.0;
     }
     if (out_ntested) *out_ntested = ntested;
-    rs_free_paths(P, n);
+    (void)n;
+    arena_release(am_);
     return found;
 }
 

@@ -34,10 +34,10 @@ def use_libm(flag):
 
 
 def lib(omp=False):
-    key = 'omp' if omp else ('libm' if _flavour['libm'] else 'st')
+    key = ('libm_omp' if _flavour['libm'] else 'omp') if omp else ('libm' if _flavour['libm'] else 'st')
     if key not in _libs:
         build()
-        name = {'omp': 'libhope_oracle_omp.so', 'st': 'libhope_oracle.so', 'libm': 'libhope_oracle_libm.so'}[key]
+        name = {'omp': 'libhope_oracle_omp.so', 'st': 'libhope_oracle.so', 'libm': 'libhope_oracle_libm.so', 'libm_omp': 'libhope_oracle_libm_omp.so'}[key]
         L = C.CDLL(os.path.join(_HERE, '_build', name))
         L.orc_init()
         L.orc_quad_intersection_area.restype = C.c_double
@@ -271,8 +271,9 @@ class BatchOracle:
     """N independent scenes stepped by the C oracle (fixed stride of max_obst obstacles/scene).
     Mirrors the product's batch interface so parity tests can run both on identical inputs."""
 
-    def __init__(self, n, max_obst, omp=False):
+    def __init__(self, n, max_obst, omp=False, track_traj=True):
         self.n, self.max_obst = n, max_obst
+        self.track_traj = track_traj                  # False: no vehicle.trajectory bookkeeping (a Python loop over the scenes; bench.py's timed baseline)
         self.L = lib(omp)
         self.n_obst = np.zeros(n, np.int32)
         self.verts = np.zeros((n, max_obst, 4, 2))
@@ -287,7 +288,7 @@ class BatchOracle:
                         reward_info=np.zeros((n, 5)), reward=np.zeros(n), status=np.zeros(n, np.int32),
                         rs_found=np.zeros(n, np.int32), rs_ctypes=np.zeros((n, 5), np.int32),
                         rs_lengths=np.zeros((n, 5)), substeps=np.zeros(n, np.int32))
-        self.traj = [[] for _ in range(n)]        # vehicle.trajectory (vehicle.py:114,132-133,144,158), last 20 kept
+        self.traj = [[] for _ in range(n)] if track_traj else None        # vehicle.trajectory (vehicle.py:114,132-133,144,158), last 20 kept
 
     def set_scenes(self, ids, start, dest, bbox, verts, nvert, n_obst):
         ids = np.asarray(ids)
@@ -307,8 +308,9 @@ class BatchOracle:
         self.pose[ids] = self.start[ids]
         self.t[ids] = 0.0
         self.accum[ids] = 0.0
-        for i in ids:
-            self.traj[int(i)] = [self.start[int(i)].copy()]
+        if self.track_traj:
+            for i in ids:
+                self.traj[int(i)] = [self.start[int(i)].copy()]
 
     def _call(self, actions, with_rs):
         o = self.out
@@ -318,7 +320,7 @@ class BatchOracle:
                               _p(a), C.c_int(int(with_rs)), _p(o['lidar']), _p(o['mask']), _p(o['target']),
                               _p(o['reward_info']), _p(o['reward']), _p(o['status']), _p(o['rs_found']),
                               _p(o['rs_ctypes']), _p(o['rs_lengths']), _p(o['substeps']))
-        if actions is not None:
+        if actions is not None and self.track_traj:
             # car_parking_base.py:259-276: of the sub-step states only the last kept one stays in vehicle.trajectory
             for i in np.nonzero(o['substeps'] > 0)[0]:
                 tr = self.traj[int(i)]

@@ -592,86 +592,14 @@ def test_independent_math_libm_oracle():
     """The kernels and the default oracle share hope_math.h, so a wrong polynomial there would be wrong on both sides.
     This run compares the HIP path with the oracle's **glibc-libm** build (what Python's `math` gave the reference):
     every step starts from the GPU's state, discrete outputs must agree except for the two documented ill-conditioned
-    classes of the Reeds-Shepp search (tests/rs_illcond.py), continuous outputs to 1e-9."""
-    from hope_amd import ParkingBatch
-    from hope_amd.scenes import SceneSource, pack_scenes
-    from oracle import oracle as O
-    from rs_illcond import allowed_results
-    import copy
-    n, mo = 2048, 128
-    src = SceneSource(seed=91)
-    uniq = [src.draw() for _ in range(512)]
-    rng = np.random.default_rng(92)
-    scenes = []
-    for k in range(n):
-        s = copy.copy(uniq[k % len(uniq)])
-        if k % 2 == 0:
-            r, a = rng.uniform(0.5, 9.0), rng.uniform(0, 2 * np.pi)
-            s.start = np.array([s.dest[0] + r * np.cos(a), s.dest[1] + r * np.sin(a), s.dest[2] + rng.normal() * 0.6])
-        scenes.append(s)
-    env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64)
-    env.set_scenes(np.arange(n), scenes)
-    start, dest, bbox, verts, nob, nvert = pack_scenes(scenes, mo)
-    t = env.tables
-    O.use_libm(True)
-    try:
-        O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'], omp=False)
-        orc = O.BatchOracle(n, mo)
-        orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
-        env.reset_obs()
-        orc.reset_obs()
-        status_bad = excused = searches = 0
-        unexplained, mask_ties, rs_ties = [], [], []
-        worst = 0.0
-        for it in range(8):
-            pose, tt, acc = env.download_state()
-            orc.pose[:], orc.t[:], orc.accum[:] = pose, tt, acc          # same inputs for both sides, every step
-            act = rng.uniform(-1.2, 1.2, (n, 2))
-            env.step(torch.from_numpy(act).to(env.device))
-            o = orc.step(act)
-            torch.cuda.synchronize()
-            status_bad += int((env.status.cpu().numpy() != o['status']).sum())
-            for i in np.nonzero((env.action_mask.cpu().numpy() != o['mask']).any(axis=1))[0]:
-                # a tolerated mask difference must be a TIE: some table entry within rounding of the scan value it is compared with
-                # (action_mask.py:170-173: dist_star[l, a, k] <= d[l]), so that the last ulp of sin / cos decides the step count
-                x = np.clip(o['lidar'][i], 0, 10) + t['hull_base']
-                xx = np.concatenate([x, x[:1]])
-                j = np.arange(1200)
-                d = xx[j // 10] * (1 - (j % 10) / 10) + xx[j // 10 + 1] * ((j % 10) / 10)
-                mask_ties.append((it, int(i), float(np.abs(t['dist_star'] - d[:, None, None]).min())))
-            for name, key in (('lidar', 'lidar'), ('target', 'target'), ('reward', 'reward'), ('reward_info', 'reward_info')):
-                worst = max(worst, float(np.abs(getattr(env, name).cpu().numpy() - o[key]).max()))
-            worst = max(worst, float(np.abs(env.download_state()[0] - orc.pose).max()))
-            w = env.rs_word.cpu().numpy()
-            searches += int(((o['status'] == 1) & (np.hypot(*(orc.pose[:, :2] - dest[:, :2]).T) < 10)).sum())
-            for i in np.nonzero((w[:, 6] != o['rs_found']) | (w[:, :5] != o['rs_ctypes']).any(axis=1))[0]:
-                allowed = allowed_results(orc.pose[i], dest[i], verts[i, :nob[i]], nvert[i, :nob[i]], bbox[i])
-                g = tuple(int(c) for c in w[i, :5] if c >= 0)
-                r_ = tuple(int(c) for c in o['rs_ctypes'][i] if c >= 0)
-                if g in allowed and r_ in allowed:
-                    excused += 1
-                    # why it is ill-conditioned: the relative length gap of the two words (equal-length twins), or 'axis' when
-                    # the two sides differ in the luck of an exactly axis-aligned crossing (rs_illcond.py)
-                    r_all = O.rs_all_paths(orc.pose[i], dest[i], 0.3327130214085973)
-                    Ls = {tuple(int(c) for c in r_all['ctypes'][k][:r_all['nseg'][k]]): float(r_all['L'][k]) for k in range(r_all['n'])}
-                    gap = abs(Ls[g] - Ls[r_]) / max(Ls[g], 1.0) if (g in Ls and r_ in Ls) else None
-                    rs_ties.append((it, int(i), g, r_, 'twins' if (gap is not None and gap <= 1e-9) else 'axis', gap))
-                else:
-                    unexplained.append((it, int(i), g, r_))
-        print('libm oracle:', dict(status_bad=status_bad, worst=worst, searches=searches, excused=excused, unexplained=unexplained))
-        print('  tolerated mask differences (step, scene, distance of the nearest table entry to its scan value):', mask_ties)
-        print('  tolerated search differences (step, scene, GPU word, libm-oracle word, class, relative length gap):', rs_ties)
-        assert status_bad == 0 and not unexplained
-        # every tolerated difference is listed with the tie it sits on: a mask entry may differ only where a table entry equals the
-        # scan value to rounding (the last ulp of sin / cos decides), a search only inside one of the two ill-conditioned classes
-        assert all(dist <= 1e-12 for _, _, dist in mask_ties), mask_ties
-        assert len(mask_ties) <= 4
-        assert all(cls_ == 'axis' or gap <= 1e-9 for *_, cls_, gap in rs_ties), rs_ties
-        assert worst < 1e-9
-        assert searches > 3000 and excused <= max(3, searches // 500)
-    finally:
-        O.use_libm(False)
-    env.close()
+    classes of the Reeds-Shepp search (tests/rs_illcond.py), continuous outputs to 1e-9.  (tests/libm_compare.py; the same
+    comparison over 1e6 scene-steps: tools/libm_soak.py -> profiles/r06_libm_soak.txt.)"""
+    from libm_compare import run, check
+    r = run(n=2048, steps=8, seed=91, omp=False)
+    print('libm oracle:', {k: r[k] for k in ('status_bad', 'worst', 'searches', 'excused', 'unexplained')})
+    print('  tolerated mask differences (step, scene, distance of the nearest table entry to its scan value):', r['mask_ties'])
+    print('  tolerated search differences (step, scene, GPU word, libm-oracle word, class, relative length gap):', r['rs_ties'])
+    check(r, min_searches=3000)
 
 
 def test_scene_pool_turnover_matches_oracle_on_the_drawn_scenes():

@@ -114,3 +114,58 @@ def test_mask_step_fraction_is_the_ieee_quotient():
     torch.cuda.synchronize()
     dev, host = out.cpu().numpy(), x / 10.0
     assert (dev.view(np.int64) == host.view(np.int64)).all(), (dev, host)
+
+
+@pytest.mark.gpu
+def test_device_math_sweep_against_glibc_ten_million_arguments():
+    """hope_math.h sits on both sides of every tolerance-0.0 comparison (kernels and default oracle), so its
+    accuracy is checked on its own against glibc (numpy's float64 functions = what Python's `math` gave the reference) over 1e7
+    arguments per function evaluated ON THE DEVICE: the ranges the path reaches -- headings of the unwrapped Euler chain
+    (vehicle.py:92-93: |h| up to ~1e2 rad and beyond), the Reeds-Shepp solvers' angles, the reward's acos(cos(.)) fold
+    (car_parking_base.py:203-206), quotients next to +-1 for asin / acos, atan2 over all quadrants incl. tiny and axis-aligned
+    arguments, fmod by 2 pi (reeds_shepp.py:561-568 pi_2_pi), square roots over 600 binades -- asserting <= 3 ulp (sqrt and fmod:
+    bit-equal).  The observed maxima are printed for profiles/."""
+    torch = pytest.importorskip('torch')
+    from hope_amd import _lib as L
+    lib = L.load_library()
+    rng = np.random.default_rng(77)
+    N = 10_000_000
+    parts = [rng.uniform(-130, 130, N // 2), rng.uniform(-2 * math.pi, 2 * math.pi, N // 4), rng.normal(0, 1e3, N // 8),
+             np.ldexp(rng.uniform(-1, 1, N // 16), rng.integers(-40, 1, N // 16))]
+    h = np.concatenate(parts + [np.arange(N - sum(len(p_) for p_ in parts)) * (math.pi / 1024)])      # multiples of pi / 1024: the quadrant boundaries
+    unit = np.concatenate([rng.uniform(-1, 1, N // 2), 1 - np.ldexp(rng.uniform(0, 1, N // 4), rng.integers(-50, 0, N // 4)),
+                           -1 + np.ldexp(rng.uniform(0, 1, N // 4), rng.integers(-50, 0, N // 4))])
+    ya = np.concatenate([rng.normal(0, 5, N // 2), np.ldexp(rng.uniform(-1, 1, N // 4), rng.integers(-60, 10, N // 4)), np.zeros(N // 8), rng.normal(0, 5, N // 8)])
+    xa = np.concatenate([rng.normal(0, 5, N // 2), rng.normal(0, 5, N // 4), rng.normal(0, 5, N // 8), np.zeros(N // 8)])
+    pos = np.ldexp(rng.uniform(0.5, 1, N), rng.integers(-300, 300, N))
+    report = {}
+
+    def dev(fn, a, b=None):
+        ta = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        tb = torch.from_numpy(np.ascontiguousarray(b)).cuda() if b is not None else None
+        out = torch.empty_like(ta)
+        L.check(lib.hope_debug_math(FN[fn], ta.numel(), C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()) if tb is not None else None,
+                                    C.c_void_p(out.data_ptr()), None), 'hope_debug_math')
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    with np.errstate(all='ignore'):
+        for name, got, want, bound in (
+                ('sin', dev('sin', h), np.sin(h), 3), ('cos', dev('cos', h), np.cos(h), 3), ('tan(steer)', dev('tan', h[:N // 8] / 130 * 0.8), np.tan(h[:N // 8] / 130 * 0.8), 3),
+                ('asin', dev('asin', unit), np.arcsin(unit), 3), ('acos', dev('acos', unit), np.arccos(unit), 3),
+                ('atan2', dev('atan2', ya, xa), np.arctan2(ya, xa), 3), ('hypot', dev('hypot', ya, xa), np.hypot(ya, xa), 1),
+                ('tanh(t / 2000)', dev('tanh', np.abs(h[:N // 8]) / 1300), np.tanh(np.abs(h[:N // 8]) / 1300), 3)):
+            u = ulps(got, want)
+            u = u[np.isfinite(u)]
+            report[name] = float(u.max())
+            assert u.max() <= bound, (name, float(u.max()))
+        f = dev('fmod', h, np.full_like(h, 2 * math.pi))
+        assert np.array_equal(f, np.fmod(h, 2 * math.pi))
+        sq = dev('sqrt', pos)
+        assert np.array_equal(sq, np.sqrt(pos))
+        # the reward's fold acos(cos(d)) over heading differences of the unwrapped chain (composition error)
+        d = h[:N // 4]
+        fold = dev('acos', dev('cos', d))
+        u = np.abs(fold - np.arccos(np.cos(d)))
+        report['acos(cos(d)) abs'] = float(u.max())
+        assert u.max() < 1e-10          # (acos is ill-conditioned at +-1; the host build of the same source gives 1.8e-12)
+    print('device hope_math.h vs glibc, max ulp over 1e7 arguments (fmod, sqrt bit-equal):', report)
