@@ -642,10 +642,27 @@ def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's
     except AttributeError:
         usable = os.cpu_count() or 1
     omp_default = O.lib(True).orc_num_threads()      # what OpenMP picks by itself (OMP_NUM_THREADS / its own CPU count)
+    # the container's CPU-time quota (cgroup v2 cpu.max / v1 cfs quota): the GPU boxes of this pool show 256 CPUs and grant 16 CPUs'
+    # worth of time -- with one thread per visible CPU the scheduler throttles the team and the rate FALLS (32 threads 108 k env-steps/s,
+    # 128 threads 55 k: profiles/r06_cpu_baseline_threads.txt), which round 5 read as a scaling problem of the oracle
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota = None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            quota = q / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()) if q > 0 else None
+        except (OSError, ValueError):
+            quota = None
     can_set = hasattr(O.lib(True), 'orc_set_num_threads')
     # all-core figure: one OpenMP thread per CPU this process may run on AND libgomp's own default (on a 2-way SMT host the
     # default is the core count, and the hardware threads beyond it do not help this float64 code) -- the better one is reported
-    runs = [(False, 1)] + [(True, nt) for nt in (sorted({int(omp_default), int(usable)}) if can_set else [int(omp_default)])]
+    cand = {int(omp_default), int(usable)}
+    if quota:
+        cand |= {max(1, int(round(quota))), max(1, int(round(2 * quota)))}     # the quota's worth of threads, and twice that (SMT-like slack)
+        cand = {c for c in cand if c <= 8 * quota}                             # (far beyond the quota: throttled, slower, and minutes of wall time)
+    runs = [(False, 1)] + [(True, nt) for nt in (sorted(cand) if can_set else [int(omp_default)])]
     allcore = {}
     for omp, nt in runs:
         rep = 16 if omp else 1                       # the all-core runs get 16x the scenes to keep the threads busy
@@ -677,9 +694,10 @@ def cpu_baseline(args, uniq, stages):   # uniq: the packed arrays of the bench's
             'sample': f'first {n} scenes of the bench scene set x {args.cpu_steps} steps, same stages/actions, '
                       'oracle/hope_oracle.c (gcc -O2), 1 thread',
             'allcore_value': allcore[best], 'allcore_threads': best, 'allcore_runs': {str(k): v for k, v in allcore.items()},
-            'host_cores': cores, 'host_cpus_usable': usable, 'openmp_default_threads': omp_default,
-            'allcore_note': 'OpenMP over scenes (16x the sample), timed with libgomp\'s default thread count and with one thread per CPU '
-                            'this process may run on (sched_getaffinity); allcore_value is the better of the two (allcore_runs has both)'}
+            'host_cores': cores, 'host_cpus_usable': usable, 'host_cpu_quota': quota, 'openmp_default_threads': omp_default,
+            'allcore_note': 'OpenMP over scenes (16x the sample), timed with the container\'s CPU quota worth of threads and twice that (or, without a '
+                            'quota, libgomp\'s default and one thread per usable CPU); allcore_value is the best (allcore_runs has all); '
+                            'host_cpu_quota = CPUs\' worth of time the cgroup grants this container'}
 
 
 if __name__ == '__main__':

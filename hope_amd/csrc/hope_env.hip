@@ -302,6 +302,26 @@ __global__ void k_debug_math(int fn, int n, const double* a, const double* b, do
     out[i] = r;
 }
 
+// Calibration of the memory-side traffic counters (FETCH_SIZE / WRITE_SIZE) on THIS library's access widths: a grid-stride sweep
+// over a buffer far larger than the 256 MiB Infinity Cache, with a known byte count (tools/pmc_calib.py).  MODE: reads 0 = 16 B per
+// lane (the obstacle tile copies; the guide's calibrated case), 1 = 8 B per lane (kin / post / table rows), 2 = 4 B per lane, 3 = one
+// 8-byte word per 64-byte line (one lane per scene record); writes 4 = 16 B, 5 = 8 B, 6 = 4 B per lane (float32 observations),
+// 7 = one 8-byte word per 64-byte line.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_traffic_calib(size_t bytes, const char* src, char* dst, double* sink) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    if (MODE == 0) { const double2* q = (const double2*)src; for (size_t i = tid; i < bytes / 16; i += nth) { const double2 v = q[i]; acc += v.x + v.y; } }
+    if (MODE == 1) { const double* q = (const double*)src; for (size_t i = tid; i < bytes / 8; i += nth) acc += q[i]; }
+    if (MODE == 2) { const float* q = (const float*)src; for (size_t i = tid; i < bytes / 4; i += nth) acc += (double)q[i]; }
+    if (MODE == 3) { const double* q = (const double*)src; for (size_t i = tid; i < bytes / 64; i += nth) acc += q[8 * i]; }
+    if (MODE == 4) { double2* q = (double2*)dst; for (size_t i = tid; i < bytes / 16; i += nth) q[i] = make_double2((double)i, 1.0); }
+    if (MODE == 5) { double* q = (double*)dst; for (size_t i = tid; i < bytes / 8; i += nth) q[i] = (double)i; }
+    if (MODE == 6) { float* q = (float*)dst; for (size_t i = tid; i < bytes / 4; i += nth) q[i] = (float)i; }
+    if (MODE == 7) { double* q = (double*)dst; for (size_t i = tid; i < bytes / 64; i += nth) q[8 * i] = (double)i; }
+    if (MODE < 4 && acc == 1.2345e301) sink[0] = acc;       // (keeps the loads)
+}
+
 // episode restart: pose = start, t = 0, accum = 0 for masked scenes
 __global__ void k_restart(int n, const uint8_t* mask, const double* scene_c, double* state, int32_t* tstep, double* traj,
                           int32_t* traj_len, int32_t* traj_valid) {
@@ -1935,6 +1955,26 @@ int hope_debug_math(int fn, int n, const double* a, const double* b, double* out
     if (n < 0 || !a || !out) return fail(HOPE_EINVAL, "hope_debug_math: bad argument");
     if (n == 0) return HOPE_OK;
     hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, a, b, out);
+    HIPCHK(hipGetLastError());
+    return HOPE_OK;
+}
+
+int hope_debug_traffic(int mode, size_t bytes, void* buf, void* stream) {
+    if (mode < 0 || mode > 7 || !buf || bytes < 4096) return fail(HOPE_EINVAL, "hope_debug_traffic: bad argument");
+    const dim3 g(256 * 32), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    char* q = (char*)buf;
+    double* sink = (double*)buf;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_traffic_calib<0>), g, b, 0, s, bytes, q, q, sink); break;
+        case 1: hipLaunchKernelGGL((k_traffic_calib<1>), g, b, 0, s, bytes, q, q, sink); break;
+        case 2: hipLaunchKernelGGL((k_traffic_calib<2>), g, b, 0, s, bytes, q, q, sink); break;
+        case 3: hipLaunchKernelGGL((k_traffic_calib<3>), g, b, 0, s, bytes, q, q, sink); break;
+        case 4: hipLaunchKernelGGL((k_traffic_calib<4>), g, b, 0, s, bytes, q, q, sink); break;
+        case 5: hipLaunchKernelGGL((k_traffic_calib<5>), g, b, 0, s, bytes, q, q, sink); break;
+        case 6: hipLaunchKernelGGL((k_traffic_calib<6>), g, b, 0, s, bytes, q, q, sink); break;
+        default: hipLaunchKernelGGL((k_traffic_calib<7>), g, b, 0, s, bytes, q, q, sink); break;
+    }
     HIPCHK(hipGetLastError());
     return HOPE_OK;
 }

@@ -10,6 +10,7 @@
 // hope_amd/scenes.py (rings_intersect / rings_distance), restated.
 #include <math.h>
 #include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
@@ -253,11 +254,24 @@ int level_index(int level) { return level < 0 || level > 2 ? -1 : level; }
 // and 8 ranks x hardware_concurrency() threads would oversubscribe the host eightfold.
 int default_threads() {
     if (const char* e = getenv("HOPE_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    int n = 0;
     cpu_set_t set;
     CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return c; }
-    const int hc = (int)std::thread::hardware_concurrency();
-    return hc > 0 ? hc : 1;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    // ... and not more than twice the container's CPU-time quota (cgroup v2 cpu.max "quota period"): a box that shows 256 CPUs but
+    // grants 16 CPUs' worth of time throttles a wider team (round 6: the generator peaked at 32 threads, the oracle's OpenMP loop too)
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        double per = 0.0;
+        if (fscanf(f, "%31s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0.0) {
+            const int cap = (int)(2.0 * atof(q) / per + 0.5);
+            if (cap >= 1 && cap < n) n = cap;
+        }
+        fclose(f);
+    }
+    return n;
 }
 
 

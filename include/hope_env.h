@@ -339,6 +339,12 @@ int hope_env_upload_state(hope_env_t *h, const double *pose, const int32_t *t, c
  * from IEEE-exact operations only, so the results must equal the host evaluation bit for bit. */
 int hope_debug_math(int fn, int n, const double *a, const double *b, double *out, void *stream);
 
+/* Profiling hook: one sweep over `bytes` of the DEVICE buffer `buf` with a known byte count in one of the library's access widths --
+ * mode 0 / 1 / 2: reads of 16 / 8 / 4 bytes per lane, 3: one 8-byte word per 64-byte line; 4 / 5 / 6 / 7: the same as writes.  Run
+ * under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` it calibrates those counters (tools/pmc_calib.py; the MI355X guide calibrates the
+ * 16-byte read only).  `bytes` should exceed the 256 MiB Infinity Cache several times. */
+int hope_debug_traffic(int mode, size_t bytes, void *buf, void *stream);
+
 /* Cycle accounting of the Reeds-Shepp validation kernel: 16 counters accumulated by the instrumented build that the library
  * launches when the environment variable HOPE_RS_TIMING is set (hope_amd/csrc/hope_rs.hip lists the sections); zeros
  * otherwise.  Host-synchronous.  tools/rs_timing.py prints the breakdown. */

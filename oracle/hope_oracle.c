@@ -1409,7 +1409,7 @@ void orc_batch_step(int n, int max_obst, const int32_t *n_obst, const double *ve
                     int32_t *substeps) {
     orc_init();
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 2)
 #endif
     for (int i = 0; i < n; i++) {
         orc_scene s;

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Thread scaling of the CPU oracle's batch step (the C call only) on this host: NS scenes (env NS, default 16384) x 3 steps with
+1, 8, 32, 64, 128 OpenMP threads -> profiles/rNN_cpu_baseline_threads.txt"""
 import numpy as np, sys, time, os
 sys.path.insert(0,os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
 from hope_amd import tables as T
@@ -12,7 +15,7 @@ start,dest,bbox,verts,nob,nvert=pack_scenes(scenes,mo)
 O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:,0], beam_b=t['beam_ab'][:,1], dist_star=t['dist_star'], omp=True)
 O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:,0], beam_b=t['beam_ab'][:,1], dist_star=t['dist_star'], omp=False)
 rng=np.random.default_rng(0)
-for nt in (1,8,32,64,128):
+for nt in [int(x) for x in os.environ.get("NTS","1,8,32,64,128").split(",")]:
     O.lib(True).orc_set_num_threads(nt)
     orc=O.BatchOracle(n,mo,omp=True)
     orc.set_scenes(np.arange(n),start,dest,bbox,verts,nvert,nob)
