@@ -331,11 +331,14 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
         if (alane) {
             double v[MG][2];
             const int mp0 = ms[0], mp1 = ms[1];
+            // (table offsets as 32-bit BYTE offsets off the scalar table pointer: the 4 MB table needs 22 bits, and a 64-bit multiply-add per
+            // lane and load was a fifth of this stage's vector instructions)
+            const char* tabb = (const char*)p.tab;
 #pragma unroll
             for (int g = 0; g < MG; g++) {
-                const double* row = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + hl;
-                v[g][0] = (has[g] && mp0 > 0) ? row[(mp0 - 1) * NACT] : 0.0;
-                v[g][1] = (has[g] && mp1 > 0) ? row[(mp1 - 1) * NACT + HALF_ACT] : 0.0;
+                const unsigned rowo = (unsigned)(UPS * ib[g]) * (NITER * NACT * 8u) + (unsigned)hl * 8u;
+                v[g][0] = (has[g] && mp0 > 0) ? *(const double*)(tabb + (rowo + (unsigned)(mp0 - 1) * (NACT * 8u))) : 0.0;
+                v[g][1] = (has[g] && mp1 > 0) ? *(const double*)(tabb + (rowo + (unsigned)(mp1 - 1) * (NACT * 8u) + HALF_ACT * 8u)) : 0.0;
             }
 #pragma unroll
             for (int g = 0; g < MG; g++) {
@@ -347,24 +350,23 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
                         const int mprobe = d == 0 ? mp0 : mp1;
                         double bv = v[g][d];                      // boundary value: largest examined entry <= x
                         if (bv > xv) {
-                            const double* row = p.tab + (size_t)(UPS * ib[g]) * NITER * NACT + hl + d * HALF_ACT;
+                            const unsigned rowo = (unsigned)(UPS * ib[g]) * (NITER * NACT * 8u) + (unsigned)(hl + d * HALF_ACT) * 8u;
                             // walk down to the first entry <= x, four rows per trip; row ms - 1 is already known to exceed when nothing
                             // lowered ms since the probe
                             int c = ms[d] == mprobe ? ms[d] - 1 : ms[d];
                             bv = -INFINITY;
+                            // (round 6: no per-row compare-and-branch -- the table is monotone in k, so the rows that exceed x form a
+                            // prefix of the four loaded ones and their NUMBER is the step down; the boundary value is the next row)
                             while (c > 0) {
-                                const double b0 = row[(c - 1) * NACT];
-                                const double b1 = c > 1 ? row[(c - 2) * NACT] : -INFINITY;
-                                const double b2 = c > 2 ? row[(c - 3) * NACT] : -INFINITY;
-                                const double b3 = c > 3 ? row[(c - 4) * NACT] : -INFINITY;
-                                bv = b0; if (!(bv > xv)) break;
-                                if (--c == 0) break;
-                                bv = b1; if (!(bv > xv)) break;
-                                if (--c == 0) break;
-                                bv = b2; if (!(bv > xv)) break;
-                                if (--c == 0) break;
-                                bv = b3; if (!(bv > xv)) break;
-                                --c;
+                                const unsigned o0 = rowo + (unsigned)(c - 1) * (NACT * 8u);
+                                const double b0 = *(const double*)(tabb + o0);
+                                const double b1 = c > 1 ? *(const double*)(tabb + (o0 - NACT * 8u)) : -INFINITY;
+                                const double b2 = c > 2 ? *(const double*)(tabb + (o0 - 2 * NACT * 8u)) : -INFINITY;
+                                const double b3 = c > 3 ? *(const double*)(tabb + (o0 - 3 * NACT * 8u)) : -INFINITY;
+                                const int nf = (b0 > xv ? 1 : 0) + (b1 > xv ? 1 : 0) + (b2 > xv ? 1 : 0) + (b3 > xv ? 1 : 0);
+                                bv = nf == 0 ? b0 : (nf == 1 ? b1 : (nf == 2 ? b2 : (nf == 3 ? b3 : -INFINITY)));
+                                c -= nf;
+                                if (nf < 4) break;
                             }
                             if (c == 0) bv = -INFINITY;
                             ms[d] = c;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates every file under profiles/ on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r06'
 # Outputs land in gpurun_out/final/ (merged back by gpurun); copy them into profiles/ afterwards.
 # PMC counters are collected in their own passes, without any trace domain.  Every command runs under `timeout`.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
@@ -87,6 +87,18 @@ rm -rf /tmp/pp_valu
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pp_valu -- python $R/tools/pmc_stage_probe.py --mix mixed --scenes 16384 --seq $O/probe_seq.json > /dev/null 2>&1
 python $R/tools/pmc_stage_probe.py --seq $O/probe_seq.json --reduce $(find /tmp/pp_valu -name "*counter_collection.csv" | head -1) SQ_INSTS_VALU > $O/${TAG}_env_step_insts_by_stage.txt 2>&1
 rm -f $O/probe_seq.json
+# round 6: the observation launch by stage, pair kernel vs one-scene kernel, on the stationary episode population
+rm -rf /tmp/op
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d /tmp/op -- python $R/tools/obs_probe.py --seq $O/obs_probe_seq.json > /dev/null 2>&1
+python $R/tools/obs_probe.py --seq $O/obs_probe_seq.json --reduce /tmp/op > $O/${TAG}_obs_insts_by_stage.txt 2>&1
+rm -f $O/obs_probe_seq.json
+# calibration of FETCH_SIZE / WRITE_SIZE on the library's access widths
+rm -rf /tmp/cf /tmp/cw
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/cf -- python $R/tools/pmc_calib.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/cw -- python $R/tools/pmc_calib.py > /dev/null 2>&1
+python $R/tools/pmc_calib.py --reduce /tmp/cf /tmp/cw > $O/${TAG}_pmc_calibration.json 2>/dev/null
+# the independent-math soak (libm oracle under OpenMP) and the CPU oracle's thread scaling on this host
+timeout 1500 python $R/tools/libm_soak.py --scenes 8192 --steps 128 > $O/${TAG}_libm_soak.txt 2>&1
 # one line per bench-modes entry
 python - > $O/${TAG}_bench_modes_summary.txt <<P
 import json
