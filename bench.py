@@ -75,6 +75,11 @@ def parse():
     ap.add_argument('--cpu-scenes', type=int, default=2048)
     ap.add_argument('--cpu-steps', type=int, default=12)
     ap.add_argument('--seed', type=int, default=42)
+    ap.add_argument('--action-bank', type=int, default=256,
+                    help='pre-generated U[-1,1]^2 action tensors, cycled (resident in HBM before the timed region).  256 (default) is longer than an '
+                         'episode (<= 200 steps): every scene-step of an episode gets its own draw, as SURVEY 8(d) specifies.  Rounds 1-5 cycled 16: each '
+                         'scene then repeats a 16-step pattern with a net drift and the stationary population has twice as many vehicles pressed against '
+                         'obstacles (tools/mask_active_census.py, profiles/r06_mask_active_census.txt)')
     ap.add_argument('--rs-join', default='deferred', choices=['deferred', 'joined'],
                     help='deferred (HOPE_DEFER_RS): the caller\'s stream is ordered after the observation / reward outputs of a step; its '
                          'Reeds-Shepp outputs are ordered by a hope_env_wait_rs issued BEFORE the next step -- the next step REPLACES them '
@@ -198,7 +203,7 @@ def main():
 
     g = torch.Generator(device=dev)
     g.manual_seed(args.seed + rank)
-    act_bank = [torch.rand((N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
+    act_bank = [torch.rand((N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(max(1, args.action_bank))]
 
     defer = args.rs_join == 'deferred'
 
@@ -470,7 +475,7 @@ def main():
             'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'all': rank_ms},
             'host': {'cpus_this_rank': host_cpus, 'cpus_node': os.cpu_count(), 'generator_threads': L.load_library().hope_scenegen_default_threads(),
                      'pinned': world > 1 and os.environ.get('HOPE_NO_PIN') != '1'},
-            'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2, '
+            'config': {'workload': f'{N} scenes/GPU, {args.mix} scene mix, stages={args.stages}{"+img" if args.image else ""}, random actions U[-1,1]^2 per scene-step ({args.action_bank} pre-generated draws, cycled), '
                                    'auto-restart of finished episodes', 'scenes_per_gpu': N, 'preroll_steps': args.preroll if trainer is None else 0, 'mean_edges': float(edges.mean()), 'mean_edges_of': 'the maps resident after the pre-roll (hope_env_download_n_obst)',
                        'parallelism': f'scene-sharded x{world}, no data-path collective', 'obs_dtype': 'f32',
                        'overlap_tile_classes': bool(env.overlap),
@@ -527,7 +532,7 @@ def main():
             from hope_amd.policy import count_parameters
             result['metric'] = 'env+agent steps/sec (full CarParking step + HOPE transformer policy' + \
                 {'rollout': ', inference only)', 'sac': ' + SAC updates)', 'ppo': ' + PPO updates)'}[args.algo]
-            result['config']['workload'] = result['config']['workload'].replace('random actions U[-1,1]^2', 'actions from the policy / RS replay')
+            result['config']['workload'] = result['config']['workload'].replace(f'random actions U[-1,1]^2 per scene-step ({args.action_bank} pre-generated draws, cycled)', 'actions from the policy / RS replay')
             result['config'].update({'policy': 'HopeNet (MultiObsEmbedding shape), random init', 'algo': args.algo,
                                      'actor_params': count_parameters(trainer.agent.actor), 'use_img': bool(args.image), 'policy_fast': args.policy_fast,
                                      'policy_graph_replays': (getattr(trainer.agent, '_fast', None) or {}).get('replays'),

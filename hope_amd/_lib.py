@@ -20,7 +20,7 @@ ABI_VERSION = 8
 
 EXPORTS = ['hope_env_create', 'hope_env_destroy', 'hope_last_error', 'hope_abi_version', 'hope_env_upload_tables',
            'hope_env_set_scenes', 'hope_env_step', 'hope_env_wait_rs', 'hope_env_last_step', 'hope_env_wait_rs_step', 'hope_env_download_n_obst', 'hope_env_queue_check', 'hope_env_reset_obs', 'hope_env_download_state',
-           'hope_env_upload_state', 'hope_env_restart', 'hope_env_set_pool', 'hope_env_pool_staging', 'hope_env_commit_pool', 'hope_env_commit_pool_relaxed', 'hope_env_pool_staging_ready', 'hope_env_pool_generation', 'hope_env_redraw', 'hope_env_set_redraw_seed', 'hope_env_download_pool_index', 'hope_env_set_dlp_cases', 'hope_env_pool_overflow', 'hope_env_set_draw_class', 'hope_env_download_scenes', 'hope_env_download_pool_state', 'hope_env_restore_maps', 'hope_env_kernel_ms', 'hope_env_kernel_union_ms', 'hope_env_profile_kernels', 'hope_debug_math', 'hope_debug_traffic', 'hope_debug_rs_prof', 'hope_debug_rs_log', 'hope_debug_rs_filter_stats', 'hope_debug_rs_filter_dump', 'hope_debug_step_prof', 'hope_debug_census', 'hope_scenegen_generate', 'hope_scenegen_default_threads', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
+           'hope_env_upload_state', 'hope_env_restart', 'hope_env_set_pool', 'hope_env_pool_staging', 'hope_env_commit_pool', 'hope_env_commit_pool_relaxed', 'hope_env_pool_staging_ready', 'hope_env_pool_generation', 'hope_env_redraw', 'hope_env_set_redraw_seed', 'hope_env_download_pool_index', 'hope_env_set_dlp_cases', 'hope_env_pool_overflow', 'hope_env_set_draw_class', 'hope_env_download_scenes', 'hope_env_download_pool_state', 'hope_env_restore_maps', 'hope_env_kernel_ms', 'hope_env_kernel_union_ms', 'hope_env_profile_kernels', 'hope_debug_math', 'hope_debug_traffic', 'hope_debug_mask_lut', 'hope_debug_rs_prof', 'hope_debug_rs_log', 'hope_debug_rs_filter_stats', 'hope_debug_rs_filter_dump', 'hope_debug_step_prof', 'hope_debug_census', 'hope_scenegen_generate', 'hope_scenegen_default_threads', 'hope_env_num_scenes', 'hope_env_max_obstacles', 'hope_env_device_arch']
 
 
 class HopeError(RuntimeError):
@@ -94,6 +94,7 @@ def load_library():
     L.hope_env_profile_kernels.argtypes = [C.c_void_p, C.c_uint32]
     L.hope_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hope_debug_traffic.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.hope_debug_mask_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.hope_scenegen_generate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.hope_env_num_scenes.argtypes = [C.c_void_p]

@@ -46,6 +46,8 @@ struct hope_env {
     int32_t* tstep = nullptr;
     double* tab = nullptr;
     double* pmax = nullptr;
+    uint16_t* mask_lut = nullptr;   // count-interval table of the action mask's coarse beams (MASK_LUT_*, hope_step_kernel.h)
+    double* mask_bsc = nullptr;     // [NBEAM] bins per metre of every coarse beam's table
     double* hull_base = nullptr;
     double* beam_ab = nullptr;
     int32_t* rs_count = nullptr;
@@ -582,6 +584,8 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
     ALLOC(h->tstep, N * sizeof(int32_t));
     ALLOC(h->tab, (size_t)NL * NITER * NACT * sizeof(double));
     ALLOC(h->pmax, NL * sizeof(double));
+    ALLOC(h->mask_lut, MASK_LUT_BYTES);
+    ALLOC(h->mask_bsc, NBEAM * sizeof(double));
     ALLOC(h->hull_base, NBEAM * sizeof(double));
     ALLOC(h->beam_ab, 2 * NBEAM * sizeof(double));
     ALLOC(h->rs_count, 2 * hope_env::MAX_CHAINS * sizeof(int32_t));
@@ -839,7 +843,7 @@ static int destroy_impl(hope_env_t* h) {                   // (also the clean-up
     for (hipEvent_t e : {h->ev_pool_ready, h->ev_pool_copied, h->ev_last_step}) if (e) hipEventDestroy(e);
     for (void* q : {(void*)h->pstage.start, (void*)h->pstage.dest, (void*)h->pstage.bbox, (void*)h->pstage.verts, (void*)h->pstage.nobst, (void*)h->pstage.list}) if (q) hipHostFree(q);
     for (hipEvent_t e : h->free_events) hipEventDestroy(e);
-    void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->cs, h->tstep, h->tab, h->pmax,
+    void* ptrs[] = {h->obb, h->fverts, h->fbox, h->eflag, h->verts, h->n_obst, h->scene_c, h->state, h->cs, h->tstep, h->tab, h->pmax, h->mask_lut, h->mask_bsc,
                     h->hull_base, h->beam_ab, h->rs_count, h->rs_surv_count, h->rs_surv, h->rs_list, h->rs_in, h->rs_flag, h->kin, h->post, h->cls_list[0], h->cls_list[1], h->rs_rec, h->cur_pool, h->episode, h->pset[0].verts, h->pset[0].c, h->pset[0].nobst, h->pset[0].list[0], h->pset[0].list[1], h->pset[1].verts, h->pset[1].c, h->pset[1].nobst, h->pset[1].list[0], h->pset[1].list[1], h->pstage_dev, h->pool_overflow, h->slot_cls, h->active_snap, h->cold_dev, h->dlp_mem[0], h->dlp_mem[1], h->dlp_mem[2], h->dlp_mem[3], h->dlp_mem[4], h->dlp_mem[5], h->stage, h->traj, h->traj_len, h->traj_valid, h->layer_valid, h->bev_layer, h->bev_dyn, h->bev_list, h->bev_legacy, h->bev_scratch};
     for (void* q : ptrs)
         if (q) hipFree(q);
@@ -912,13 +916,46 @@ int hope_env_num_scenes(const hope_env_t* h) { return h ? h->n : HOPE_EINVAL; }
 int hope_env_max_obstacles(const hope_env_t* h) { return h ? h->max_obst : HOPE_EINVAL; }
 const char* hope_env_device_arch(const hope_env_t* h) { return h ? h->arch : ""; }
 
-int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double* hull_base, const double* beam_ab) {
-    if (!h || !dist_star || !hull_base || !beam_ab) return fail(HOPE_EINVAL, "hope_env_upload_tables: null argument");
-    DeviceGuard guard(h->device);
-    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
-    // device layout: prefix-max over k (first exceedance of a sequence == first exceedance of its running
-    // max: exact), transposed to [l][k][a] so that lane = action reads coalesced rows.
-    std::vector<double> tab((size_t)NL * NITER * NACT), pmax(NL);
+// Count-interval table of the action mask's coarse beams (round 6; read by k_obs_pair's mask stage).  The scan value x of coarse beam i
+// falls into bin b = floor((x - lo_i) scale_i), lo_i = hull_base_i - 1e-6 (x >= hull_base_i always); the MASK_LUT_NB bins reach to the
+// table's maximum at that beam + 4e-9.  Per (i, b, action): cnt_lo <= #{k : tab <= x - 1e-9} and #{k : tab <= x} <= cnt_hi for EVERY x
+// whose computed bin is b -- the bin's edges are widened by 1e-6 of a bin (the device evaluates b in float64: its rounding is ~1e-13 of
+// a bin) and by 2e-9 m (the tie band of the coarse decision is 1e-9 m).  cnt_lo == cnt_hi: the count is known and no table entry lies
+// within 1e-9 of x; otherwise the kernel looks at the float64 entries cnt_lo .. cnt_hi - 1 themselves.  tab: [NL][NITER][NACT] prefix-maxed.
+static void build_mask_lut(const std::vector<double>& tab, const std::vector<double>& pmax, const double* hull_base,
+                           std::vector<uint16_t>& lut, std::vector<double>& bsc) {
+    lut.assign((size_t)MASK_LUT_ROWS * MASK_LUT_ROW, (uint16_t)0xAAAA);       // padding lanes and the neutral last row: [10, 10]
+    bsc.assign(NBEAM, 0.0);
+    for (int i = 0; i < NBEAM; i++) {
+        const int l = UPS * i;
+        const double lo = hull_base[i] - 1e-6;
+        const double scale = (double)MASK_LUT_NB / (pmax[l] + 4e-9 - lo);
+        bsc[i] = scale;
+        for (int b = 0; b < MASK_LUT_NB; b++) {
+            const double e_lo = lo + ((double)b - 1e-6) / scale - 2e-9, e_hi = lo + ((double)b + 1.0 + 1e-6) / scale + 2e-9;
+            uint16_t* row = lut.data() + ((size_t)i * MASK_LUT_NB + b) * MASK_LUT_ROW;
+            for (int hl = 0; hl < NACT / 2; hl++) {
+                int c[2][2];
+                for (int d = 0; d < 2; d++) {
+                    const int a = hl + d * (NACT / 2);
+                    int cl = 0, ch = 0;
+                    for (int k = 0; k < NITER; k++) {
+                        const double t = tab[((size_t)l * NITER + k) * NACT + a];
+                        cl += t <= e_lo; ch += t <= e_hi;
+                    }
+                    c[d][0] = cl; c[d][1] = ch;
+                }
+                row[hl] = (uint16_t)(c[0][0] | c[0][1] << 4 | c[1][0] << 8 | c[1][1] << 12);
+            }
+        }
+    }
+}
+
+// device layout of the mask table: prefix-max over k (first exceedance of a sequence == first exceedance of its running max: exact),
+// transposed to [l][k][a] so that lane = action reads coalesced rows; pmax[l] = the maximum over (a, k)
+static void build_mask_tab(const double* dist_star, std::vector<double>& tab, std::vector<double>& pmax) {
+    tab.assign((size_t)NL * NITER * NACT, 0.0);
+    pmax.assign(NL, 0.0);
     for (int l = 0; l < NL; l++) {
         double pm = -INFINITY;
         for (int a = 0; a < NACT; a++) {
@@ -932,8 +969,34 @@ int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double*
         }
         pmax[l] = pm;
     }
+}
+
+int hope_debug_mask_lut(const double* dist_star, const double* hull_base, uint16_t* lut_out, double* scale_out) {
+    if (!dist_star || !hull_base || !lut_out || !scale_out) return fail(HOPE_EINVAL, "hope_debug_mask_lut: null argument");
+    std::vector<double> tab, pmax, bsc;
+    std::vector<uint16_t> lut;
+    build_mask_tab(dist_star, tab, pmax);
+    build_mask_lut(tab, pmax, hull_base, lut, bsc);
+    memcpy(lut_out, lut.data(), MASK_LUT_BYTES);
+    memcpy(scale_out, bsc.data(), NBEAM * sizeof(double));
+    return HOPE_OK;
+}
+
+int hope_env_upload_tables(hope_env_t* h, const double* dist_star, const double* hull_base, const double* beam_ab) {
+    if (!h || !dist_star || !hull_base || !beam_ab) return fail(HOPE_EINVAL, "hope_env_upload_tables: null argument");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(HOPE_EHIP, "hipSetDevice failed");
+    std::vector<double> tab, pmax;
+    build_mask_tab(dist_star, tab, pmax);
     HIPCHK(hipMemcpy(h->tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->pmax, pmax.data(), pmax.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<uint16_t> lut;
+        std::vector<double> bsc;
+        build_mask_lut(tab, pmax, hull_base, lut, bsc);
+        HIPCHK(hipMemcpy(h->mask_lut, lut.data(), MASK_LUT_BYTES, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->mask_bsc, bsc.data(), NBEAM * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(h->hull_base, hull_base, NBEAM * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->beam_ab, beam_ab, 2 * NBEAM * sizeof(double), hipMemcpyHostToDevice));
     h->have_tables = true;
@@ -1042,7 +1105,7 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
     p.hflags = h->traj ? STEP_HF_TRAJ : 0;
     p.verts = h->verts; p.obb = h->obb; p.eflag = h->eflag; p.n_obst = h->n_obst; p.scene_c = h->scene_c; p.state = h->state; p.cs = h->cs; p.tstep = h->tstep;
     p.active = active; p.active_out = active ? h->active_snap : nullptr; p.kin = h->kin; p.actions = actions; p.post = h->post;
-    p.tab = h->tab; p.pmax = h->pmax; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
+    p.tab = h->tab; p.pmax = h->pmax; p.mask_lut = h->mask_lut; p.mask_bsc = h->mask_bsc; p.hull_base = h->hull_base; p.beam_ab = h->beam_ab;
     p.lidar = out->lidar; p.action_mask = out->action_mask;
     p.cold = h->cold_dev + h->cold_idx;                     // (sync_cold ran on the caller's stream before any launch of this step)
     const uint8_t* active_rs = active ? h->active_snap : nullptr;   // what the Reeds-Shepp chain reads instead of the caller's mask

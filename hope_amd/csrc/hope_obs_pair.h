@@ -81,12 +81,12 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
     ssync();
     for (int i = hl; i < 4 * n_l; i += OP_HALF) ((double2*)tile)[i] = src[4 * klist[i >> 2] + (i & 3)];
     // requested now, used after the drain: this lane's four beams' hull ranges and table maxima
-    double base[4], pm[4];
+    double base[4], pm[4];                                        // (pm: the table's maximum at the beam, or with HOPE_MASK_LUT its bins per metre)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int bi = hl + OP_HALF * r;
         base[r] = bi < NBEAM ? p.hull_base[bi] : 0.0;
-        pm[r] = bi < NBEAM ? p.pmax[UPS * bi] : 0.0;
+        pm[r] = bi < NBEAM ? (HOPE_MASK_LUT ? p.mask_bsc[bi] : p.pmax[UPS * bi]) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) best[hl + OP_HALF * r] = 0x7ff0000000000000ull;              // +inf
@@ -294,7 +294,6 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
     // ---- action mask (action_mask.py:166-196; the coarse-beam decision of hope_step_kernel.h) ---------------------------------
     ssync();                                                      // every lane has read its best[] words: xs[] takes their place
     double* xs = (double*)best;                                   // lidar_obs = clip(raw,0,10) + base (:170); [NBEAM + 1]
-    uint8_t* alist = (uint8_t*)tile;                              // this half's active coarse beams (the tile is dead)
     double xv_own[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -303,6 +302,82 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
         if (bi < NBEAM) xs[bi] = xv_own[r];
     }
     if (hl == 0) xs[NBEAM] = xv_own[0];                           // circular (:158)
+    constexpr int HALF_ACT = NACT / 2;                            // 21 actions per direction
+    const bool alane = hl < HALF_ACT;
+    int ms[2] = {NITER, NITER};                                   // step counts of action hl (forward) and HALF_ACT + hl (backward)
+    bool tie = false;
+#if HOPE_MASK_LUT
+    // ---- round 6: the counts of a coarse beam come from the count-interval table (hope_env_upload_tables), one 2-byte load per (beam,
+    // lane) for both directions and all rows k, every beam's load independent of every other's -- the row probes above were a chain of
+    // dependent L2 round trips (probe at the current minimum, walk down, next group) and ~390 vector instructions per group of four
+    // beams.  cnt_lo <= count <= cnt_hi per (beam, action); the minimum over the beams is known when min cnt_lo == min cnt_hi, else
+    // the few (beam, action) pairs that can still lower it are decided on the float64 entries cnt_lo .. cnt_hi - 1 themselves, where
+    // an entry within 1e-9 of the scan raises `tie` (-> the exact 1200-beam evaluation) exactly as the row probes did.
+    uint32_t* alist = (uint32_t*)tile;                            // this half's active coarse beams: beam << 16 | table row (the tile is dead)
+    int n_act = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int bi = hl + OP_HALF * r;
+        const double q = (xv_own[r] - (base[r] - 1e-6)) * pm[r];  // bin of the scan value; beyond the last bin: every entry <= x - 1e-9
+        const bool c = live && bi < NBEAM && q < (double)MASK_LUT_NB;
+        const unsigned long long m = __ballot(c);
+        const unsigned hm = hw ? (unsigned)(m >> 32) : (unsigned)m;
+        if (c) alist[n_act + __popc(hm & ((1u << hl) - 1))] = (uint32_t)(bi << 16) | (uint32_t)(bi * MASK_LUT_NB + (int)q);
+        n_act += __popc(hm);
+    }
+    ssync();
+    const int na_max = max(__builtin_amdgcn_readlane(n_act, 0), __builtin_amdgcn_readlane(n_act, OP_HALF));
+    if (na_max > 0) {
+        constexpr uint32_t NONE = (uint32_t)(NBEAM * MASK_LUT_NB);        // the table's last row: [10, 10] for every action
+        const char* lutb = (const char*)p.mask_lut + 2 * hl;
+        unsigned mlo[2] = {NITER, NITER}, mhi[2] = {NITER, NITER};
+        constexpr int PG = 4;                                     // beams whose loads are in flight together
+        for (int k0 = 0; k0 < na_max; k0 += PG) {
+            unsigned v[PG];
+#pragma unroll
+            for (int g = 0; g < PG; g++) {
+                const uint32_t e = k0 + g < n_act ? alist[k0 + g] & 0xFFFFu : NONE;
+                v[g] = *(const uint16_t*)(lutb + e * (MASK_LUT_ROW * 2u));
+            }
+#pragma unroll
+            for (int g = 0; g < PG; g++) {
+                mlo[0] = min(mlo[0], v[g] & 15u); mhi[0] = min(mhi[0], (v[g] >> 4) & 15u);
+                mlo[1] = min(mlo[1], (v[g] >> 8) & 15u); mhi[1] = min(mhi[1], v[g] >> 12);
+            }
+        }
+        if (__any(mlo[0] < mhi[0] || mlo[1] < mhi[1])) {
+            // second visit: the (beam, action) pairs with cnt_lo < cnt_hi and cnt_lo below the minimum of the upper bounds
+            const char* tabb = (const char*)p.tab;
+            for (int k = 0; k < na_max; k++) {
+                const bool has = k < n_act;
+                const uint32_t ae = has ? alist[k] : NONE;
+                const unsigned v = *(const uint16_t*)(lutb + (ae & 0xFFFFu) * (MASK_LUT_ROW * 2u));
+                const unsigned lo0 = v & 15u, hi0 = (v >> 4) & 15u, lo1 = (v >> 8) & 15u, hi1 = v >> 12;
+                const bool n0 = lo0 < hi0 && lo0 < mhi[0], n1 = lo1 < hi1 && lo1 < mhi[1];
+                if (!__any(n0 || n1)) continue;
+                const int ib = (int)(ae >> 16);
+                const double xv = xs[has ? ib : 0];
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    if (d == 0 ? n0 : n1) {
+                        unsigned c = d == 0 ? lo0 : lo1;
+                        const unsigned lim = min(d == 0 ? hi0 : hi1, mhi[d]);
+                        const unsigned rowo = (unsigned)(UPS * ib) * (NITER * NACT * 8u) + (unsigned)(hl + d * HALF_ACT) * 8u;
+                        while (c < lim) {                         // (one entry almost always: a bin holds one table value)
+                            const double t = *(const double*)(tabb + (rowo + c * (NACT * 8u)));
+                            if (t > xv) break;
+                            if (t > xv - 1e-9) tie = true;
+                            c++;
+                        }
+                        mhi[d] = min(mhi[d], c);
+                    }
+                }
+            }
+        }
+        ms[0] = (int)mhi[0]; ms[1] = (int)mhi[1];
+    }
+#else
+    uint8_t* alist = (uint8_t*)tile;                              // this half's active coarse beams (the tile is dead)
     int n_act = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -315,10 +390,6 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
     }
     ssync();
     const int na_max = max(__builtin_amdgcn_readlane(n_act, 0), __builtin_amdgcn_readlane(n_act, OP_HALF));
-    constexpr int HALF_ACT = NACT / 2;                            // 21 actions per direction
-    const bool alane = hl < HALF_ACT;
-    int ms[2] = {NITER, NITER};                                   // step counts of action hl (forward) and HALF_ACT + hl (backward)
-    bool tie = false;
     constexpr int MG = HOPE_MASK_MG;
     for (int k0 = 0; k0 < na_max; k0 += MG) {
         int ib[MG];
@@ -377,6 +448,7 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
             }
         }
     }
+#endif
     {
         // a table entry within 1e-9 of the scan (6e-7 of the scene-steps): the exact 1200-beam evaluation for that scene, by the
         // whole wave in the one-scene kernel's layout (lane = action), from scratch -- the coarse beams are among the 1200

@@ -31,6 +31,9 @@
 #ifndef HOPE_STEP_SYNC_FULL
 #define HOPE_STEP_SYNC_FULL 0   // 1: every LDS synchronisation point of the step kernel is a __syncthreads() (rounds 1-5)
 #endif
+#ifndef HOPE_MASK_LUT
+#define HOPE_MASK_LUT 1         // 1: the mask stage of k_obs_pair reads the count-interval table (round 6); 0: the row probes of rounds 2-5
+#endif
 #ifndef HOPE_MASK_FRAC_TABLE
 #define HOPE_MASK_FRAC_TABLE 0  // 1: the mask's k / n_iter from a table in constant memory (round 5: a dependent load at the kernel's very end)
 #endif
@@ -212,6 +215,8 @@ struct StepParams {
                               //   with HOPE_DEFER_RS runs after the caller's stream has been released
     const double* tab;        // prefix-max mask table [NL][NITER][NACT]
     const double* pmax;       // [NL] max over (a,k) of tab
+    const uint16_t* mask_lut; // [MASK_LUT_ROWS][MASK_LUT_ROW] count intervals of the coarse beams by scan-value bin (hope_env_upload_tables)
+    const double* mask_bsc;   // [NBEAM] bins per metre
     const double* hull_base;  // [NBEAM]
     const double* beam_ab;    // [NBEAM][2]
     void* lidar;              // hope_step_out.lidar / .action_mask (the other outputs are written by k_post / the Reeds-Shepp kernels)
@@ -237,6 +242,11 @@ constexpr int POST_F_REWARD = 1, POST_F_TURNOVER = 2, POST_F_NEED_UA = 4;   // N
 __host__ __device__ inline size_t step_lds_bytes(int tile_cap) {
     return (size_t)(8 * tile_cap + LDS_SCRATCH_WORDS) * 8 + (size_t)((tile_cap + 3) & ~3) * 4 + (size_t)((tile_cap + 3) & ~3);   // + near / keep list + shape flags
 }
+// Count-interval table of the action mask (round 6): per coarse beam MASK_LUT_NB scan-value bins, per bin one row of 32 uint16 --
+// word hl < 21 = (cnt_lo, cnt_hi) of the forward action hl in bits 0-3 / 4-7 and of the backward action 21 + hl in bits 8-11 / 12-15;
+// the other words and the last row (the "no beam" entry of a probe group) read [10, 10].
+constexpr int MASK_LUT_NB = 128, MASK_LUT_ROW = 32, MASK_LUT_ROWS = NBEAM * MASK_LUT_NB + 1;
+constexpr size_t MASK_LUT_BYTES = (size_t)MASK_LUT_ROWS * MASK_LUT_ROW * sizeof(uint16_t);
 constexpr int SMALL_TILE = 32;   // scenes with <= 32 obstacles run in a launch with a 2 KB tile (higher occupancy)
 
 // GEOS Area::ofRingSigned over an open vertex list (ring closed implicitly); lane-0 code, LDS arrays
@@ -1437,7 +1447,9 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
             ST_T(5);
         }
     }
-    const double pm0 = p.pmax[UPS * i0], pm1 = has1 ? p.pmax[UPS * i1] : 0.0;   // for the mask stage: in flight during the drain
+    // for the mask stage, in flight during the drain: the table's maximum at the lane's beams, or (HOPE_MASK_LUT) their bins per metre
+    constexpr bool MLUT = HOPE_MASK_LUT && !TIMING;             // (the instrumented build keeps the row probes: its census counts their compares)
+    const double pm0 = MLUT ? p.mask_bsc[i0] : p.pmax[UPS * i0], pm1 = has1 ? (MLUT ? p.mask_bsc[i1] : p.pmax[UPS * i1]) : 0.0;
     if (qn > 0) drain();
     const double best0 = sqrt(__longlong_as_double((long long)best[i0]));                     // min of the roots = root of the min
     const double best1 = has1 ? sqrt(__longlong_as_double((long long)best[i1])) : INFINITY;
@@ -1478,6 +1490,71 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     // inside (x_i - 1e-9, x_i] raises `tie` -> exact evaluation.
     int mstep = NITER;
     bool tie = false;
+    if (MLUT) {
+        // ---- round 6: the count-interval table (hope_env_upload_tables; hope_obs_pair.h has the argument).  Lane = action: its byte of
+        // the beam's row holds cnt_lo | cnt_hi << 4 for all ten rows k; one independent 2-byte load per active beam instead of the
+        // dependent row probes; the float64 entries only where cnt_lo < cnt_hi can still lower the minimum.
+        const double q0 = (xs[i0] - (base0 - 1e-6)) * pm0, q1 = has1 ? (xs[i1] - (base1 - 1e-6)) * pm1 : (double)MASK_LUT_NB;
+        const bool c0 = q0 < (double)MASK_LUT_NB, c1 = has1 && q1 < (double)MASK_LUT_NB;
+        const int row0 = i0 * MASK_LUT_NB + (c0 ? (int)q0 : 0), row1 = i1 * MASK_LUT_NB + (c1 ? (int)q1 : 0);
+        const unsigned long long am[2] = {__ballot(c0), __ballot(c1)};
+        if (am[0] | am[1]) {
+            constexpr int NONE = NBEAM * MASK_LUT_NB;                     // the table's last row: [10, 10]
+            const int hl_ = lane < NACT / 2 ? lane : (lane < NACT ? lane - NACT / 2 : 31), sh_ = (lane >= NACT / 2 && lane < NACT) ? 8 : 0;
+            const char* lutb = (const char*)p.mask_lut + 2 * hl_;
+            unsigned mlo = NITER, mhi = NITER;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                unsigned long long m = am[half];
+                while (m) {
+                    constexpr int PG = 4;
+                    unsigned v[PG];
+#pragma unroll
+                    for (int g = 0; g < PG; g++) {
+                        int row = NONE;
+                        if (m) { const int l_ = __ffsll((long long)m) - 1; m &= m - 1; row = __builtin_amdgcn_readlane(half ? row1 : row0, l_); }
+                        v[g] = *(const uint16_t*)(lutb + (unsigned)row * (MASK_LUT_ROW * 2u));
+                    }
+#pragma unroll
+                    for (int g = 0; g < PG; g++) {
+                        const unsigned w = v[g] >> sh_;
+                        mlo = min(mlo, w & 15u); mhi = min(mhi, (w >> 4) & 15u);
+                    }
+                }
+            }
+            if (__any(mlo < mhi)) {
+                const char* tabb = (const char*)p.tab;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    unsigned long long m = am[half];
+                    while (m) {
+                        const int l_ = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int ib = 64 * half + l_;
+                        const int row = __builtin_amdgcn_readlane(half ? row1 : row0, l_);
+                        const unsigned w = (unsigned)*(const uint16_t*)(lutb + (unsigned)row * (MASK_LUT_ROW * 2u)) >> sh_;
+                        const unsigned lo = w & 15u, hi = (w >> 4) & 15u;
+                        const bool need = lo < hi && lo < mhi;
+                        if (!__any(need)) continue;
+                        const double xv = xs[ib];
+                        if (need) {
+                            unsigned c = lo;
+                            const unsigned lim = min(hi, mhi);
+                            const unsigned rowo = (unsigned)(UPS * ib) * (NITER * NACT * 8u) + (unsigned)(lane < NACT ? lane : 0) * 8u;
+                            while (c < lim) {
+                                const double t = *(const double*)(tabb + (rowo + c * (NACT * 8u)));
+                                if (t > xv) break;
+                                if (t > xv - 1e-9) tie = true;
+                                c++;
+                            }
+                            mhi = min(mhi, c);
+                        }
+                    }
+                }
+            }
+            mstep = (int)mhi;
+        }
+    } else
     {
         // lane-parallel activity test (one lane per coarse beam), then only the active rows are visited,
         // four at a time so that their probes are in flight together

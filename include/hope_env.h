@@ -339,6 +339,11 @@ int hope_env_upload_state(hope_env_t *h, const double *pose, const int32_t *t, c
  * from IEEE-exact operations only, so the results must equal the host evaluation bit for bit. */
 int hope_debug_math(int fn, int n, const double *a, const double *b, double *out, void *stream);
 
+/* Test hook (pure host code, no device needed): the count-interval table hope_env_upload_tables derives from dist_star / hull_base for
+ * the action-mask stage (hope_amd/csrc/hope_step_kernel.h MASK_LUT_*): lut_out [(120 * 128 + 1)][32] uint16, scale_out [120] bins per
+ * metre.  tests/test_mask_lut.py checks its bracketing property against the float64 table (action_mask.py:166-177). */
+int hope_debug_mask_lut(const double *dist_star, const double *hull_base, uint16_t *lut_out, double *scale_out);
+
 /* Profiling hook: one sweep over `bytes` of the DEVICE buffer `buf` with a known byte count in one of the library's access widths --
  * mode 0 / 1 / 2: reads of 16 / 8 / 4 bytes per lane, 3: one 8-byte word per 64-byte line; 4 / 5 / 6 / 7: the same as writes.  Run
  * under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` it calibrates those counters (tools/pmc_calib.py; the MI355X guide calibrates the

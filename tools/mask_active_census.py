@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scenes', type=int, default=65536)
     ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--bank', type=int, default=0, help='cycle through this many fixed action tensors (bench.py: 16) instead of fresh draws every step')
     args = ap.parse_args()
     import torch
     from hope_amd import ParkingBatch
@@ -30,9 +31,11 @@ def main():
     env.reset_obs()
     env.upload_state(t=np.random.default_rng(1).integers(1, 200, N))
     g = torch.Generator(device=env.device); g.manual_seed(0)
+    bank = [torch.rand((N, 2), generator=g, device=env.device) * 2 - 1 for _ in range(args.bank)]
     for i in range(args.steps):
-        a = torch.rand((N, 2), generator=g, device=env.device, dtype=torch.float64) * 2 - 1
+        a = bank[i % args.bank] if args.bank else torch.rand((N, 2), generator=g, device=env.device) * 2 - 1
         env.step(a, auto_reset=True, fresh=True)
+    print('actions:', f'a bank of {args.bank} tensors, cycled' if args.bank else 'fresh U[-1,1]^2 draws every step', '|', args.steps, 'steps,', N, 'scenes')
     torch.cuda.synchronize()
     lid = env.lidar.cpu().numpy()
     nob = env.n_obst_now()
