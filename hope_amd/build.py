@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 _ROOT = os.path.dirname(_HERE)
 SOURCES = ['hope_env.hip', 'hope_rs.hip', 'hope_bev.hip', 'hope_scenegen.cpp']
-HEADERS = ['hope_math.h', 'hope_dev.h', 'hope_internal.h', 'hope_step_kernel.h', 'hope_obs_pair.h', os.path.join(_ROOT, 'include', 'hope_env.h')]
+HEADERS = ['hope_math.h', 'hope_dev.h', 'hope_internal.h', 'hope_step_kernel.h', 'hope_obs_pair.h', 'hope_motion_pair.h', os.path.join(_ROOT, 'include', 'hope_env.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
          '-Wno-unused-value', '-pthread']
 

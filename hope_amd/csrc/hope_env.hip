@@ -16,6 +16,7 @@
 #include "hope_internal.h"
 #include "hope_step_kernel.h"
 #include "hope_obs_pair.h"
+#include "hope_motion_pair.h"
 
 using namespace hope;
 
@@ -1261,7 +1262,11 @@ static int enqueue_step(hope_env_t* h, const void* actions, const uint8_t* activ
         // launch rewrites
         if (pipe) HIPCHK(hipStreamWaitEvent(sk, h->ev_segs[i], 0));
         if (tm) tm->begin(HOPE_K_STEP, sk);
-        if (split) launch_env_step<1>(of64, af64, grid, block, lds, sk, p);
+        // small-tile class, moving step: two scenes per wave (hope_motion_pair.h; HOPE_MOTION_PAIR=0 or stage bit 0x8000: the one-scene kernel)
+        static const bool motion_pair = !(getenv("HOPE_MOTION_PAIR") && atoi(getenv("HOPE_MOTION_PAIR")) == 0);
+        if (split && motion_pair && c == 0 && n_cls == 2 && p.tile_cap == SMALL_TILE && (stages & HOPE_STAGE_MOTION) && has_action && !(stages & 0x8000))
+            hipLaunchKernelGGL(k_motion_pair, dim3((p.n_list + 1) / 2), block, MP_LDS_BYTES, sk, p);
+        else if (split) launch_env_step<1>(of64, af64, grid, block, lds, sk, p);
         else if (step_timing && !of64 && !af64) hipLaunchKernelGGL((k_env_step<float, float, true>), grid, block, lds, sk, p);
         else if (fuse_kin) launch_env_step<0, true>(of64, af64, grid, block, lds, sk, p);
         else launch_env_step<0>(of64, af64, grid, block, lds, sk, p);

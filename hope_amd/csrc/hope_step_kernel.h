@@ -727,16 +727,25 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
         // k_env_step (one wave per scene) this scalar test cost the whole wave ~40 instructions per pass of its sub-step loop.
         const double* sc = scene_c + (size_t)sc_ * SC_WORDS;
         const double dcx = sc[SC_DCEN], dcy = sc[SC_DCEN + 1], dcd = sc[SC_DCEN + 2], dsd = sc[SC_DCEN + 3];
+        double s0, c0;
+        hm_sincos(st[2], &s0, &c0);
         int bits = 0;
         for (int k = q; k < NUM_STEP; k += 4)
             if (arrival_possible(out[30 + k], out[40 + k], out[10 + k], out[20 + k], dcx, dcy, dcd, dsd)) bits |= 1 << k;
+        // bit NUM_STEP: the pose the step starts from (where a step blocked at its first sub-step stays; read by k_motion_pair)
+        if (q == 3 && arrival_possible(st[0], st[1], c0, s0, dcx, dcy, dcd, dsd)) bits |= 1 << NUM_STEP;
+        {   // bits 16 + k: the rear axle of pose k lies inside the map box (the OUTBOUND test of _check_status, car_parking_base.py:178-179,
+            // same comparisons on the same doubles); bit 16 + NUM_STEP: the start pose.  Read by k_motion_pair.
+            const double xmin = sc[SC_BBOX], xmax = sc[SC_BBOX + 1], ymin = sc[SC_BBOX + 2], ymax = sc[SC_BBOX + 3];
+            for (int k = q; k < NUM_STEP; k += 4)
+                if (!(out[30 + k] > xmax || out[30 + k] < xmin || out[40 + k] > ymax || out[40 + k] < ymin)) bits |= 1 << (16 + k);
+            if (q == 3 && !(st[0] > xmax || st[0] < xmin || st[1] > ymax || st[1] < ymin)) bits |= 1 << (16 + NUM_STEP);
+        }
         bits |= __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
         bits |= __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
         if (q == 0) { out[50] = __hiloint2double(0, bits); out[51] = 0.0; }
         // box around every hull of this step (start pose + ten poses): k_env_step's near list keeps the obstacles whose box
         // meets it -- far fewer than a disc about the start pose, so more sub-steps fit in one pass of its collision loop
-        double s0, c0;
-        hm_sincos(st[2], &s0, &c0);
         Box b = make_box(st[0], st[1], c0, s0);
         double bx0 = fmin(fmin(b.x[0], b.x[1]), fmin(b.x[2], b.x[3])), bx1 = fmax(fmax(b.x[0], b.x[1]), fmax(b.x[2], b.x[3]));
         double by0 = fmin(fmin(b.y[0], b.y[1]), fmin(b.y[2], b.y[3])), by1 = fmax(fmax(b.y[0], b.y[1]), fmax(b.y[2], b.y[3]));

@@ -1306,8 +1306,9 @@ def test_lidar_back_face_cull_changes_no_bit():
 
 @pytest.mark.parametrize('f64', [True, False])
 def test_two_scenes_per_wave_observation_equals_the_one_scene_kernel(f64):
-    """Round 6: the observation launch of the small-tile class runs TWO scenes per wavefront (k_obs_pair, hope_obs_pair.h).  Against
-    the one-scene kernel (stage bit 0x8000 selects it) every lidar value and every mask entry must be the same bit: an odd number
+    """Round 6: the motion and the observation launch of the small-tile class run TWO scenes per wavefront (k_motion_pair,
+    hope_motion_pair.h; k_obs_pair, hope_obs_pair.h).  Against the one-scene kernels (stage bit 0x8000 selects them) every output
+    and the episode state must be the same bit: an odd number
     of small-tile scenes (the last wave's second half is empty), lots of every level incl. Dragon-Lake lots that fit the small
     tile, episode turnover on new maps, a caller's `active` mask that silences one scene of many pairs, float64 and float32
     observations.  (The oracle comparisons of this file run the pair kernel wherever they use the two-launch form.)"""
@@ -1345,8 +1346,12 @@ def test_two_scenes_per_wave_observation_equals_the_one_scene_kernel(f64):
             for e in envs:
                 e.wait_rs()
             torch.cuda.synchronize()
-            for k in ('lidar', 'action_mask', 'status', 'pose', 'reward', 'rs_word'):
+            for k in ('lidar', 'action_mask', 'status', 'done', 'pose', 'reward', 'reward_info', 'target', 'rs_word', 'rs_lengths'):
                 assert torch.equal(getattr(envs[0], k), getattr(envs[1], k)), (f64, it, k)
+            if it % 6 == 5:                                   # the episode state the motion launch keeps: pose, t, accum_arrive_reward
+                for u, v in zip(envs[0].download_state(), envs[1].download_state()):
+                    assert np.array_equal(u, v), (f64, it)
+                assert np.array_equal(envs[0].n_obst_now(), envs[1].n_obst_now())
         lid = envs[0].lidar.cpu().numpy()
         assert small % 2 == 1
         assert masked > 5000 and float(lid.min()) < 1.0 and float(lid.max()) > 5.0

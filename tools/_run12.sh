@@ -1,7 +1,8 @@
 set -x
 cd $GRAFT_REPO_ROOT
+R=$PWD
 mkdir -p gpurun_out/r06
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dropin.py -m gpu -x -q 2>&1 | grep -v "^$" | tail -8 > gpurun_out/r06/gpu_tests_lut.txt
-tail -3 gpurun_out/r06/gpu_tests_lut.txt
-BENCH_ARGS="--action-bank 16" bash tools/exp_env_ab.sh 3 "nolut_bank16:HOPE_AMD_LIB=$PWD/hope_amd/libhope_env_nolut.so" "lut_bank16:" 2>&1 | tee gpurun_out/r06/ab_mask_lut.txt
-bash tools/exp_env_ab.sh 3 "nolut_fresh:HOPE_AMD_LIB=$PWD/hope_amd/libhope_env_nolut.so" "lut_fresh:" 2>&1 | tee -a gpurun_out/r06/ab_mask_lut.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/bench.py --steps 8 --warmup 8 --preroll 100 --refresh-every 0 --no-cpu-baseline --witness 0 --repeat-passes 0 > /dev/null 2>&1
+python $R/tools/timeline.py /tmp/tl --tail 60 > $R/gpurun_out/r06/step_timeline_pipelined.txt 2>&1
+cat $R/gpurun_out/r06/step_timeline_pipelined.txt
