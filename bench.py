@@ -436,9 +436,9 @@ def main():
                                          'floor_ms_per_bench_step': fl * nl * 1e3}
                     floor_s += fl * nl
                     insts += v * nl
-                # (k_obs_pair -- the small-tile class's observation launch, two scenes per wave -- is a launch of the step kernel to the
+                # (k_obs_pair / k_motion_pair -- the small-tile class's observation / motion launch, two scenes per wave -- are launches of the step kernel to the
                 # library's event timers: its floor is compared with k_env_step's event time together with k_env_step's own)
-                grp = lambda k: 'k_env_step' if k == 'k_obs_pair' else k  # noqa: E731
+                grp = lambda k: 'k_env_step' if k in ('k_obs_pair', 'k_motion_pair') else k  # noqa: E731
                 for kname in per_kernel:
                     fl_g = sum(q['floor_ms_per_bench_step'] for k2, q in per_kernel.items() if grp(k2) == grp(kname))
                     t_meas = per_step.get(grp(kname), 0.0)
@@ -497,9 +497,9 @@ def main():
                                                  'k_env_step launches overlap each other and the other class\'s kernels, so '
                                                  'per-launch durations include that sharing; from 16 384 scenes on k_env_step is '
                                                  'two launches per class (motion half, then the observation half on its own stream '
-                                                 'next to the Reeds-Shepp kernels); the small-tile class\'s observation half is the '
-                                                 'two-scenes-per-wave form k_obs_pair (its own row in rocprof\'s table; the library\'s event '
-                                                 'timers and this average count it as a launch of the step kernel: profiles/*_kernel_stats_top.txt '
+                                                 'next to the Reeds-Shepp kernels); the small-tile class\'s two halves are the '
+                                                 'two-scenes-per-wave forms k_motion_pair / k_obs_pair (their own rows in rocprof\'s table; the library\'s event '
+                                                 'timers and this average count them as launches of the step kernel: profiles/*_kernel_stats_top.txt '
                                                  'ends with the combined row)') if env.overlap else None,
                          # the same kernel per step CALL: all its launches' bytes over the time during which at least one of them
                          # ran (the union of the launch intervals) -- what the kernel sustains while its launches overlap

@@ -51,6 +51,8 @@ py $R/tools/bev_probe.py > $O/${TAG}_image_stage_times.txt
   echo "== HOPE_RS_DEBUG=0x20000 (no screen pass: round 4's validation kernel)"; HOPE_RS_DEBUG=0x20000 $T python $R/bench.py --refresh-every 0 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   echo "== HOPE_PIPE=0 (steps not pipelined: the round-3 launch structure with this round's kernels)"; HOPE_PIPE=0 $T python $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   for NS in 4096 8192 16384; do echo "== --scenes $NS HOPE_RS_DEBUG=0x20000 (no screen pass)"; HOPE_RS_DEBUG=0x20000 $T python $R/bench.py --scenes $NS --no-cpu-baseline --witness 0 --repeat-passes 2 --steps 40 --warmup 10 2>/dev/null | tail -1; done
+  echo "== --action-bank 16 (rounds 1-5: each scene repeats a 16-step action pattern)"; py $R/bench.py --action-bank 16 --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 | tail -1
+  echo "== HOPE_MOTION_PAIR=0 HOPE_OBS_PAIR=0 (one scene per wave in both launches of the small-tile class)"; HOPE_MOTION_PAIR=0 HOPE_OBS_PAIR=0 $T python $R/bench.py --no-cpu-baseline --steps 40 --warmup 10 --repeat-passes 2 --witness 0 2>/dev/null | tail -1
   echo "== the driver's exact form: --steps 20 --warmup 5"; py $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1
   echo "== the driver's exact form, second run"; py $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1
   echo "== the driver's exact form, third run"; py $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline | tail -1
@@ -92,6 +94,8 @@ rm -rf /tmp/op
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d /tmp/op -- python $R/tools/obs_probe.py --seq $O/obs_probe_seq.json > /dev/null 2>&1
 python $R/tools/obs_probe.py --seq $O/obs_probe_seq.json --reduce /tmp/op > $O/${TAG}_obs_insts_by_stage.txt 2>&1
 rm -f $O/obs_probe_seq.json
+# round 6: how many coarse beams the mask stage visits, by action source
+{ $T python $R/tools/mask_active_census.py; $T python $R/tools/mask_active_census.py --bank 16; } > $O/${TAG}_mask_active_census.txt 2>/dev/null
 # calibration of FETCH_SIZE / WRITE_SIZE on the library's access widths
 rm -rf /tmp/cf /tmp/cw
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/cf -- python $R/tools/pmc_calib.py > /dev/null 2>&1

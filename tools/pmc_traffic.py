@@ -19,10 +19,10 @@ def per_kernel(path, counter):
         if r['Counter_Name'] != counter or 'hope' not in r['Kernel_Name']:
             continue
         name = r['Kernel_Name']
-        for k in ('k_kinematics', 'k_env_step', 'k_obs_pair', 'k_post', 'k_rs_compact', 'k_rs_words', 'k_rs_segs', 'k_rs_validate', 'k_bev_image', 'k_bev_prep'):
+        for k in ('k_kinematics', 'k_env_step', 'k_obs_pair', 'k_motion_pair', 'k_post', 'k_rs_compact', 'k_rs_words', 'k_rs_segs', 'k_rs_validate', 'k_bev_image', 'k_bev_prep'):
             if k in name:
                 acc[k].append(float(r['Counter_Value']))
-                if k == 'k_obs_pair':                      # the small-tile class's observation launch (two scenes per wave): a launch of the
+                if k in ('k_obs_pair', 'k_motion_pair'):                      # the small-tile class's observation launch (two scenes per wave): a launch of the
                     acc['k_env_step'].append(float(r['Counter_Value']))   # step kernel for bench.py's per-launch average (4 launches per step)
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KERNELS = ('k_kinematics', 'k_env_step', 'k_obs_pair', 'k_post', 'k_rs_compact', 'k_rs_words', 'k_rs_segs', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_bev_static')
+KERNELS = ('k_kinematics', 'k_env_step', 'k_obs_pair', 'k_motion_pair', 'k_post', 'k_rs_compact', 'k_rs_words', 'k_rs_segs', 'k_rs_validate', 'k_bev_image', 'k_bev_prep', 'k_bev_static')
 
 
 def find(d, pat):
@@ -32,11 +32,11 @@ def kernel_stats(src_dir, out_csv, out_top):
             g.write(f"{r['Name'][:70]:70s} calls={int(r['Calls']):4d} avg_ns={float(r['AverageNs']):12.0f} "
                     f"max_ns={int(float(r['MaxNs'])):9d} pct={r['Percentage']}\n")
         # the launches bench.py's roofline averages over: every k_env_step instantiation + k_obs_pair (the small-tile class's observation launch)
-        st = [r for r in rows if 'k_env_step' in r['Name'] or 'k_obs_pair' in r['Name']]
+        st = [r for r in rows if 'k_env_step' in r['Name'] or 'k_obs_pair' in r['Name'] or 'k_motion_pair' in r['Name']]
         if st:
             calls = sum(int(r['Calls']) for r in st)
             tot = sum(float(r['TotalDurationNs']) for r in st) if 'TotalDurationNs' in st[0] else sum(float(r['AverageNs']) * int(r['Calls']) for r in st)
-            g.write(f"{'step kernel, all launches (k_env_step<..> + k_obs_pair)':70s} calls={calls:4d} avg_ns={tot / calls:12.0f}\n")
+            g.write(f"{'step kernel, all launches (k_env_step<..> + k_motion_pair + k_obs_pair)':70s} calls={calls:4d} avg_ns={tot / calls:12.0f}\n")
 
 
 def pmc(src_dir, counter, out_csv):
