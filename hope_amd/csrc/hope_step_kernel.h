@@ -659,6 +659,10 @@ __global__ __launch_bounds__(64) void k_kinematics(int n, const int32_t* scene_l
     __shared__ double buf[KIN_SCENES_PER_BLOCK * KIN_WORDS];
     __shared__ double terms[MINI_ITER][2 * KIN_SCENES_PER_BLOCK];   // one round's displacement terms: [micro-step][2 scene + (x | y)]
     __shared__ int sid[KIN_SCENES_PER_BLOCK];
+#ifdef HOPE_KIN_PAD                                      // A/B probe: extra LDS per block (does the kernel's LDS footprint matter in the pipelined step?)
+    __shared__ double kin_pad[HOPE_KIN_PAD];
+    if (n < 0) kin_pad[threadIdx.x] = 0.0, kin[0] = kin_pad[(threadIdx.x * 7) % HOPE_KIN_PAD];
+#endif
     const int lane = threadIdx.x, q = lane & 3, ls = lane >> 2;
     const int idx = blockIdx.x * KIN_SCENES_PER_BLOCK + ls;
     const int scene = idx < n ? (scene_list ? scene_list[idx] : idx) : -1;
