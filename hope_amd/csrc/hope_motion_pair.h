@@ -217,7 +217,8 @@ __global__ __launch_bounds__(64, HOPE_MP_OCC) void k_motion_pair(StepParams p) {
     const int g = hl >> lgS, e0 = hl & (S - 1);
     const int nch = E <= OP_HALF ? 1 : (E + OP_HALF - 1) / OP_HALF; // passes over the edges per sub-step (more than 8 near obstacles)
     const int nch_max = max(__builtin_amdgcn_readlane(nch, 0), __builtin_amdgcn_readlane(nch, OP_HALF));
-    int ev_k = NUM_STEP, k0 = 0;
+    // (a half with no near obstacle and no sub-step pose that can reach the dest box has nothing to walk: the step ends at the tenth pose)
+    int ev_k = NUM_STEP, k0 = (E == 0 && (apmask & ((1 << NUM_STEP) - 1)) == 0) ? NUM_STEP : 0;
     bool ev_arrive = false;
     double ua = 0.0;
     const double dest_area = start[3];
@@ -253,6 +254,9 @@ __global__ __launch_bounds__(64, HOPE_MP_OCC) void k_motion_pair(StepParams p) {
         // walk this pass's sub-steps in order
         const int gmax = max(__builtin_amdgcn_readlane(on ? G : 0, 0), __builtin_amdgcn_readlane(on ? G : 0, OP_HALF));
         const unsigned gm0 = S == 32 ? 0xFFFFFFFFu : ((1u << S) - 1u);
+        // (only when this pass holds an event candidate: a certain hit, or a pose the slab bound lets arrive)
+        const bool cand = on && (hacc != 0 || (((unsigned)apmask >> k0) & ((1u << G) - 1u)) != 0);
+        if (__any(cand))
         for (int gg = 0; gg < gmax; gg++) {
             const int kq = k0 + gg;
             const bool walk = on && gg < G && kq < NUM_STEP && ev_k == NUM_STEP;

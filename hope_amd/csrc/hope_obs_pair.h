@@ -495,6 +495,13 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
     // post_process (:186-196) per direction half: both ends -1, min filter (5, reflect), clip, /10
     double mo[2];
     bool nzl = false;
+    if (HOPE_MASK_LUT && na_max == 0) {
+        // no scene of the wave has an active beam (two thirds of the scenes): every count is NITER, the filter's result is known --
+        // NITER - 1 within two actions of either end of a direction half (the ends' decrement, spread by the 5-wide minimum), NITER elsewhere
+        const int mn = (hl <= 2 || hl >= HALF_ACT - 3) ? NITER - 1 : NITER;
+        mo[0] = mo[1] = HOPE_MASK_FRAC_TABLE ? MASK_STEP_FRACTION[mn] : mask_fraction(mn);
+        nzl = true;
+    } else
 #pragma unroll
     for (int d = 0; d < 2; d++) {
         int v = ms[d];

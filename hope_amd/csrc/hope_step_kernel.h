@@ -989,7 +989,9 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         const int S = n_near <= 1 ? 4 : (n_near <= 2 ? 8 : (n_near <= 4 ? 16 : (n_near <= 8 ? 32 : 64)));
         int ev_k = NUM_STEP;              // first sub-step with an event (NUM_STEP: none)
         bool ev_arrive = false;
-        if (S < WAVE) {
+        if (n_near == 0 && (apmask & ((1 << NUM_STEP) - 1)) == 0) {
+            // no obstacle near the step's hulls and no pose the slab bound lets arrive: the step ends at the tenth pose (round 6)
+        } else if (S < WAVE) {
             const int G = WAVE / S;
             const int g = lane / S, e = lane % S;
             const bool has_edge = e < 4 * n_near;
