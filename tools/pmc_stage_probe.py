@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def reduce(seq_path, csv_path, counter):
     seq = json.load(open(seq_path))
-    rows = [r for r in csv.DictReader(open(csv_path)) if r['Counter_Name'] == counter and 'k_env_step' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(csv_path)) if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in ('k_env_step', 'k_obs_pair', 'k_motion_pair'))]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     assert len(rows) == len(seq['launches']), (len(rows), len(seq['launches']))
     acc = collections.defaultdict(list)
