@@ -1504,7 +1504,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     // every lower entry is too and this row cannot push the lower bound below the exact count.  Any boundary value
     // inside (x_i - 1e-9, x_i] raises `tie` -> exact evaluation.
     int mstep = NITER;
-    bool tie = false;
+    bool tie = false, mask_trivial = false;
     if (MLUT) {
         // ---- round 6: the count-interval table (hope_env_upload_tables; hope_obs_pair.h has the argument).  Lane = action: its byte of
         // the beam's row holds cnt_lo | cnt_hi << 4 for all ten rows k; one independent 2-byte load per active beam instead of the
@@ -1513,6 +1513,7 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
         const bool c0 = q0 < (double)MASK_LUT_NB, c1 = has1 && q1 < (double)MASK_LUT_NB;
         const int row0 = i0 * MASK_LUT_NB + (c0 ? (int)q0 : 0), row1 = i1 * MASK_LUT_NB + (c1 ? (int)q1 : 0);
         const unsigned long long am[2] = {__ballot(c0), __ballot(c1)};
+        mask_trivial = !(am[0] | am[1]);                     // no active beam (two thirds of the scene-steps): every count is NITER
         if (am[0] | am[1]) {
             constexpr int NONE = NBEAM * MASK_LUT_NB;                     // the table's last row: [10, 10]
             const int hl_ = lane < NACT / 2 ? lane : (lane < NACT ? lane - NACT / 2 : 31), sh_ = (lane >= NACT / 2 && lane < NACT) ? 8 : 0;
@@ -1665,6 +1666,8 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
     const int hb_ = lane < half ? 0 : half;
     const int li = lane - hb_;
     int mn = v;
+    if (mask_trivial) mn = (li <= 2 || li >= half - 3) ? NITER - 1 : NITER;   // the filter's result for all-NITER counts: the ends' decrement, spread by the 5-wide minimum
+    else
 #pragma unroll
     for (int off = -2; off <= 2; off++) {
         int j = li + off;
