@@ -1414,3 +1414,66 @@ def test_single_class_batch_in_two_sub_chains_equals_the_single_chain(which):
     finally:
         del os.environ['HOPE_AUTO_CHAINS']
         del os.environ['HOPE_SPLIT_MIN']
+
+
+@pytest.mark.parametrize('form', ['two_launch_pair_kernels', 'one_launch'])
+def test_mask_exact_path_on_obstacles_that_touch_the_hull(form):
+    """Round 6: the mask stage reads the count-interval table; a table entry within 1e-9 of a scan value must still send the scene to
+    the exact 1200-beam evaluation (action_mask.py:166-177).  Such ties are structural -- an obstacle that reaches the hull clips the
+    scan to the hull range the table was built from -- but rare in a rollout (125 in 2 x 10^8 scene-steps), so this test makes them:
+    every scene gets an obstacle pushed onto / against its vehicle.  Masks (float64) must equal the oracle's on the reset observation
+    and on the steps after it, in the pair kernel of the two-launch form and in the one-scene kernel of the one-launch form, and the
+    premise is checked: hundreds of scenes have a coarse-beam scan within 1e-9 of a table entry."""
+    import os
+    from hope_amd import ParkingBatch
+    from hope_amd.scene_gen import mixed_arrays
+    from oracle import oracle as O
+    os.environ['HOPE_SPLIT_MIN'] = '1' if form == 'two_launch_pair_kernels' else '1000000000'
+    try:
+        n, mo = 3000, 128
+        start, dest, bbox, verts, nob, nvert = mixed_arrays(n, levels=('Normal', 'Complex', 'Extrem', 'dlp'), seed=71, max_obst=mo)
+        rng = np.random.default_rng(72)
+        mid = 0.5 * (3.76 - 0.93)
+        for k in range(n):
+            if nob[k] == 0:
+                continue
+            j = int(rng.integers(nob[k]))
+            c, s_ = np.cos(start[k, 2]), np.sin(start[k, 2])
+            # where the obstacle's centroid goes: anywhere from deep inside the hull to just beyond its outline
+            ahead, side = rng.uniform(-3.0, 3.0), rng.uniform(-1.6, 1.6)
+            tx = start[k, 0] + (mid + ahead) * c - side * s_
+            ty = start[k, 1] + (mid + ahead) * s_ + side * c
+            cen = verts[k, j].mean(axis=0)
+            verts[k, j] += np.array([tx, ty]) - cen
+        env = ParkingBatch(n, mo, obs_dtype=torch.float64, action_dtype=torch.float64, overlap=True)
+        env.set_scene_arrays(np.arange(n), start, dest, bbox, verts, nob)
+        orc = O.BatchOracle(n, mo, omp=True, track_traj=False)
+        orc.set_scenes(np.arange(n), start, dest, bbox, verts, nvert, nob)
+        t = env.tables
+        O.set_tables(hull_base=t['hull_base'], beam_a=t['beam_ab'][:, 0], beam_b=t['beam_ab'][:, 1], dist_star=t['dist_star'], omp=True)
+        tab = np.maximum.accumulate(t['dist_star'][::10], axis=2)            # coarse rows [120][42][10]
+        ties = 0
+
+        def check(o, tag):
+            nonlocal ties
+            torch.cuda.synchronize()
+            m = env.action_mask.cpu().numpy()
+            lid = env.lidar.cpu().numpy()
+            assert np.array_equal(lid, o['lidar']), tag
+            bad = np.nonzero((m != o['mask']).any(axis=1))[0]
+            assert len(bad) == 0, (tag, bad[:8], m[bad[:2]], o['mask'][bad[:2]])
+            x = np.clip(lid, 0, 10) + t['hull_base'][None]
+            near = np.abs(tab[None] - x[:, :, None, None]) <= 1e-9            # [n, 120, 42, 10]
+            ties += int(near.any(axis=(1, 2, 3)).sum())
+
+        env.reset_obs()
+        check(orc.reset_obs(with_rs=False), 'reset')
+        for it in range(4):
+            act = rng.uniform(-1, 1, (n, 2))
+            env.step(torch.from_numpy(act).to(env.device))
+            check(orc.step(act, with_rs=False), it)
+        print(f'mask exact path ({form}): scene-observations with a table entry within 1e-9 of a coarse-beam scan: {ties}')
+        assert ties > 300
+        env.close()
+    finally:
+        os.environ.pop('HOPE_SPLIT_MIN', None)
