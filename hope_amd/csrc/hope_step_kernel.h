@@ -234,7 +234,7 @@ struct StepParams {
 constexpr int LDS_TX = 0, LDS_SH = 0, LDS_X = 0, LDS_HB = 320, LDS_CB = 330, LDS_SB = 340, LDS_PX = 350,
               LDS_PY = 360, LDS_DBOX = 370, LDS_W2 = 378, LDS_KEEP = 388, LDS_SCRATCH_WORDS = 388,
               LDS_ROBUST = 96;   // [ROBUST_LDS_WORDS] in region A, behind sh[64] and the turnover's constant record [64..88)
-constexpr int KIN_WORDS = 56;   // h[10] cos[10] sin[10] x[10] y[10], [50] = int2(arrival-possible bits of the ten poses, 0), [51] pad,
+constexpr int KIN_WORDS = 56;   // h[10] cos[10] sin[10] x[10] y[10], [50] = int2(bits 0..9 arrival-possible of the ten poses, bit 10 of the start pose, bits 16..26 inside-the-map-box of the eleven; 0), [51] pad,
                                 // [52..55] = box (xmin, xmax, ymin, ymax) around the hulls of the start pose and the ten poses
 // k_env_step -> k_post record: previous pose, final pose of the finished step, overlap area, (status | t << 8 | flags << 24)
 constexpr int POST_WORDS = 8;
