@@ -172,7 +172,10 @@ int hope_abi_version(void);
 /* ---- tables: ActionMask.__init__ / LidarSimlator.__init__ products (host pointers, host-sync) -- */
 /* dist_star  [1200][42][10] float64, reference order (action_mask.py:114-143 `precompute`);
  * hull_base  [120]  range from the rear axle to the hull per beam (lidar_simulator.py:48-53);
- * beam_ab    [120][2]  (sin theta_i, -cos theta_i) of lidar_simulator.py:86-88. */
+ * beam_ab    [120][2]  (sin theta_i, -cos theta_i) of lidar_simulator.py:86-88.
+ * The library derives its device tables from them on the host: dist_star prefix-maxed over k and transposed, its per-beam maximum,
+ * and (round 6) the count-interval table of the mask stage -- per coarse beam 128 scan-value bins, per bin and action the interval that
+ * brackets ActionMask.get_steps' first-exceed count (action_mask.py:166-177) for every scan value of the bin (hope_debug_mask_lut). */
 int hope_env_upload_tables(hope_env_t *h, const double *dist_star, const double *hull_base,
                            const double *beam_ab);
 
