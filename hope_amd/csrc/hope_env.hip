@@ -684,7 +684,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         // HOPE_PRIO (experiment): stream priorities by ROLE -- 1: chains highest, observation / image lowest; 2: chains default,
-        // observation lowest; 3: chains highest, observation default
+        // observation lowest; 3: chains highest, observation default; 4: chains (the search streams of pipelined steps) lowest
         static const int prio_mode = getenv("HOPE_PRIO") ? atoi(getenv("HOPE_PRIO")) : 0;
         int perm[hope_env::MAX_CHAINS] = {0, 1, 6, 3, 2, 5, 4, 7};
         // Which library stream plays which role decides which roles share a HARDWARE queue (the runtime spreads streams over a few
@@ -726,6 +726,7 @@ int hope_env_create(hope_env_t** out, int n_scenes, int max_obstacles, int devic
             if (prio_mode == 1) prio = is_obs ? prio_lo : prio_hi;
             else if (prio_mode == 2) prio = is_obs ? prio_lo : 0;
             else if (prio_mode == 3) prio = is_chain ? prio_hi : 0;
+            else if (prio_mode == 4) prio = is_chain ? prio_lo : 0;      // round 6: the search streams lowest, everything else default
             HIPCHK(hipStreamCreateWithPriority(&created[c], hipStreamNonBlocking, prio));
             HIPCHK(hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
         }
