@@ -177,7 +177,11 @@ __global__ __launch_bounds__(64, HOPE_MP_OCC) void k_motion_pair(StepParams p) {
     const int n_obst = live ? min(p.n_obst[scene], OP_CAP) : 0;
     const double* kr = p.kin + (size_t)scene * KIN_WORDS;
     const double kv0 = kr[hl], kv1 = hl < KIN_WORDS - OP_HALF ? kr[OP_HALF + hl] : 0.0;
-    const float4 bb = (p.obb + (size_t)scene * p.max_obst)[hl];
+    // (the obstacle boxes of the first OP_EAGER slots with the first loads -- generated lots have at most 13 obstacles --, the others only
+    // for a scene that has them: 256 instead of 512 bytes per scene and launch)
+    const float4* obb_s = p.obb + (size_t)scene * p.max_obst;
+    float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (hl < OP_EAGER) bb = obb_s[hl];
     const double* sc = p.scene_c + (size_t)scene * SC_WORDS;
     const double dbv = hl < 8 ? sc[SC_DBOX + hl] : 0.0;
     double* st = p.state + (size_t)scene * ST_WORDS;
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(64, HOPE_MP_OCC) void k_motion_pair(StepParams p) {
     double* start = hb + MP_START;
     if (hl < 4) start[hl] = stv;
 
+    if (hl >= OP_EAGER && hl < n_obst) bb = obb_s[hl];            // (behind every other first load: this one waits for the count)
     kin[hl] = kv0;
     if (hl < KIN_WORDS - OP_HALF) kin[OP_HALF + hl] = kv1;
     if (hl < 8) dbox[hl] = dbv;

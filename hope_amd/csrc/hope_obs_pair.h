@@ -28,6 +28,7 @@ namespace hope {
 constexpr int OP_HALF = 32;                       // lanes per scene
 constexpr int OP_CAP = SMALL_TILE;                // obstacle slots per scene tile
 static_assert(OP_CAP == OP_HALF, "one lane per obstacle slot in the near-obstacle scan");
+constexpr int OP_EAGER = 16;                     // obstacle-box slots requested before the obstacle count is known
 constexpr int OP_LQ = 512;                        // (beam, edge) pair queue entries, shared by the two scenes
 // per-half LDS block (doubles): tile[8 * OP_CAP] | best[128] (u64; later xs[121]) | klist[OP_CAP] i32 | cfl[OP_CAP] u8
 constexpr int OP_TILE_W = 8 * OP_CAP, OP_BEST_W = 128, OP_KLIST_W = OP_CAP / 2, OP_CFL_W = OP_CAP / 8;
@@ -59,12 +60,17 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
     const double* st = p.state + (size_t)scene * ST_WORDS;
     const double x = st[0], y = st[1];
     const double ct = p.cs[2 * (size_t)scene], sn = p.cs[2 * (size_t)scene + 1];          // hm_sincos(h) as the motion launch computed it
-    const float4 bb = (p.obb + (size_t)scene * p.max_obst)[hl];
+    // (obstacle boxes: the first OP_EAGER slots with the first loads, the others only for a scene that has them -- generated lots have
+    // at most 13 obstacles: 256 instead of 512 bytes per scene and launch)
+    const float4* obb_s = p.obb + (size_t)scene * p.max_obst;
+    float4 bb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (hl < OP_EAGER) bb = obb_s[hl];
     const uint8_t gfl = (p.eflag + (size_t)scene * eflag_stride(p.max_obst))[hl];
     const double2* src = (const double2*)(p.verts + (size_t)scene * p.max_obst * 8);
 
     // ---- obstacles whose box comes within lidar_range of the sensor (a superset of the rings :69 keeps), compacted: tile slot k = the
     // k-th such obstacle of the scene (stage_near of the one-scene kernel, one lane per obstacle slot)
+    if (hl >= OP_EAGER && hl < n_obst) bb = obb_s[hl];            // (behind every other first load: this one waits for the count)
     const double lr = LIDAR_RANGE + 1e-6;
     const bool near = hl < n_obst && !((double)bb.x > x + lr || (double)bb.y < x - lr || (double)bb.z > y + lr || (double)bb.w < y - lr);
     int n_l;
