@@ -28,6 +28,10 @@ namespace hope {
 constexpr int OP_HALF = 32;                       // lanes per scene
 constexpr int OP_CAP = SMALL_TILE;                // obstacle slots per scene tile
 static_assert(OP_CAP == OP_HALF, "one lane per obstacle slot in the near-obstacle scan");
+#ifndef HOPE_PAIR_NARROW
+#define HOPE_PAIR_NARROW 6
+#endif
+static_assert(HOPE_PAIR_NARROW * 64 <= 512, "narrow edges of one pass must fit the pair queue");
 constexpr int OP_EAGER = 16;                     // obstacle-box slots requested before the obstacle count is known
 constexpr int OP_LQ = 512;                        // (beam, edge) pair queue entries, shared by the two scenes
 // per-half LDS block (doubles): tile[8 * OP_CAP] | best[128] (u64; later xs[121]) | klist[OP_CAP] i32 | cfl[OP_CAP] u8
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
                 const bool ring_ok = ((rb >> sh) & 0xF) == 0 && ((fb >> sh) & 0xF) != 0 && ((bb2 >> sh) & 0xF) != 0;
                 if (ring_ok && back && !(p.stages & 0x4000)) cnt = 0;          // (0x4000: A/B switch, no cull)
             }
-            constexpr int NARROW = 6;
+            constexpr int NARROW = HOPE_PAIR_NARROW;          // edges of at most this many beams are appended lane-parallel (A/B: 4 / 8 not faster)
             const int tag = (hw << 14) | (e << 7);
             const int cs = (cnt > 0 && cnt <= NARROW) ? cnt : 0;
             const int incl = wave_incl_scan_i(cs, lane);
