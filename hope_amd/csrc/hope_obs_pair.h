@@ -341,8 +341,26 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
         constexpr uint32_t NONE = (uint32_t)(NBEAM * MASK_LUT_NB);        // the table's last row: [10, 10] for every action
         const char* lutb = (const char*)p.mask_lut + 2 * hl;
         unsigned mlo[2] = {NITER, NITER}, mhi[2] = {NITER, NITER};
-        constexpr int PG = 4;                                     // beams whose loads are in flight together
-        for (int k0 = 0; k0 < na_max; k0 += PG) {
+        constexpr int PG = 8;                                     // beams whose loads are in flight together
+        // the first PG beams (all of them for nine waves out of ten): their table words stay in registers for the second visit --
+        // one round trip for the first visit, none for the second visit's words
+        unsigned pk[PG / 2];                                      // two 16-bit words per register
+        {
+            unsigned v0[PG];
+#pragma unroll
+            for (int g = 0; g < PG; g++) {
+                const uint32_t e = g < n_act ? alist[g] & 0xFFFFu : NONE;
+                v0[g] = *(const uint16_t*)(lutb + e * (MASK_LUT_ROW * 2u));
+            }
+#pragma unroll
+            for (int g = 0; g < PG; g++) {
+                mlo[0] = min(mlo[0], v0[g] & 15u); mhi[0] = min(mhi[0], (v0[g] >> 4) & 15u);
+                mlo[1] = min(mlo[1], (v0[g] >> 8) & 15u); mhi[1] = min(mhi[1], v0[g] >> 12);
+            }
+#pragma unroll
+            for (int g = 0; g < PG / 2; g++) pk[g] = v0[2 * g] | v0[2 * g + 1] << 16;
+        }
+        for (int k0 = PG; k0 < na_max; k0 += PG) {
             unsigned v[PG];
 #pragma unroll
             for (int g = 0; g < PG; g++) {
@@ -361,7 +379,12 @@ __global__ __launch_bounds__(64) void k_obs_pair(StepParams p) {
             for (int k = 0; k < na_max; k++) {
                 const bool has = k < n_act;
                 const uint32_t ae = has ? alist[k] : NONE;
-                const unsigned v = *(const uint16_t*)(lutb + (ae & 0xFFFFu) * (MASK_LUT_ROW * 2u));
+                unsigned v;
+                switch (k >> 1) {                                 // (wave-uniform)
+                    case 0: v = pk[0]; break; case 1: v = pk[1]; break; case 2: v = pk[2]; break; case 3: v = pk[3]; break;
+                    default: v = (unsigned)*(const uint16_t*)(lutb + (ae & 0xFFFFu) * (MASK_LUT_ROW * 2u)) << ((k & 1) << 4); break;
+                }
+                v = (v >> ((k & 1) << 4)) & 0xFFFFu;
                 const unsigned lo0 = v & 15u, hi0 = (v >> 4) & 15u, lo1 = (v >> 8) & 15u, hi1 = v >> 12;
                 const bool n0 = lo0 < hi0 && lo0 < mhi[0], n1 = lo1 < hi1 && lo1 < mhi[1];
                 if (!__any(n0 || n1)) continue;

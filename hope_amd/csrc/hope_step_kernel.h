@@ -1519,27 +1519,36 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
             const int hl_ = lane < NACT / 2 ? lane : (lane < NACT ? lane - NACT / 2 : 31), sh_ = (lane >= NACT / 2 && lane < NACT) ? 8 : 0;
             const char* lutb = (const char*)p.mask_lut + 2 * hl_;
             unsigned mlo = NITER, mhi = NITER;
+            constexpr int PG = 8;                                         // beams whose loads are in flight together
+            unsigned long long m0 = am[0], m1 = am[1];
+            auto pop_row = [&]() -> int {                                // the next active beam's table row (beams 0..63, then 64..119)
+                int row = NONE;
+                if (m0) { const int l_ = __ffsll((long long)m0) - 1; m0 &= m0 - 1; row = __builtin_amdgcn_readlane(row0, l_); }
+                else if (m1) { const int l_ = __ffsll((long long)m1) - 1; m1 &= m1 - 1; row = __builtin_amdgcn_readlane(row1, l_); }
+                return row;
+            };
+            // the first PG beams (all of them for nine waves out of ten): their table words stay in registers, two per register, for
+            // the second visit
+            unsigned pk[PG / 2];
+            {
+                unsigned v0[PG];
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                unsigned long long m = am[half];
-                while (m) {
-                    constexpr int PG = 4;
-                    unsigned v[PG];
+                for (int g = 0; g < PG; g++) v0[g] = (unsigned)*(const uint16_t*)(lutb + (unsigned)pop_row() * (MASK_LUT_ROW * 2u)) >> sh_ & 0xFFu;
 #pragma unroll
-                    for (int g = 0; g < PG; g++) {
-                        int row = NONE;
-                        if (m) { const int l_ = __ffsll((long long)m) - 1; m &= m - 1; row = __builtin_amdgcn_readlane(half ? row1 : row0, l_); }
-                        v[g] = *(const uint16_t*)(lutb + (unsigned)row * (MASK_LUT_ROW * 2u));
-                    }
+                for (int g = 0; g < PG; g++) { mlo = min(mlo, v0[g] & 15u); mhi = min(mhi, v0[g] >> 4); }
 #pragma unroll
-                    for (int g = 0; g < PG; g++) {
-                        const unsigned w = v[g] >> sh_;
-                        mlo = min(mlo, w & 15u); mhi = min(mhi, (w >> 4) & 15u);
-                    }
-                }
+                for (int g = 0; g < PG / 2; g++) pk[g] = v0[2 * g] | v0[2 * g + 1] << 16;
+            }
+            while (m0 | m1) {
+                unsigned v[PG];
+#pragma unroll
+                for (int g = 0; g < PG; g++) v[g] = (unsigned)*(const uint16_t*)(lutb + (unsigned)pop_row() * (MASK_LUT_ROW * 2u)) >> sh_ & 0xFFu;
+#pragma unroll
+                for (int g = 0; g < PG; g++) { mlo = min(mlo, v[g] & 15u); mhi = min(mhi, v[g] >> 4); }
             }
             if (__any(mlo < mhi)) {
                 const char* tabb = (const char*)p.tab;
+                int k = 0;                                               // position of the beam in the order of the first visit
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     unsigned long long m = am[half];
@@ -1547,9 +1556,17 @@ __global__ __launch_bounds__(64, (PART == 0 && !TIMING) ? HOPE_PART0_OCC : 4) vo
                         const int l_ = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const int ib = 64 * half + l_;
-                        const int row = __builtin_amdgcn_readlane(half ? row1 : row0, l_);
-                        const unsigned w = (unsigned)*(const uint16_t*)(lutb + (unsigned)row * (MASK_LUT_ROW * 2u)) >> sh_;
-                        const unsigned lo = w & 15u, hi = (w >> 4) & 15u;
+                        unsigned w;
+                        switch (k >> 1) {                                // (wave-uniform)
+                            case 0: w = pk[0]; break; case 1: w = pk[1]; break; case 2: w = pk[2]; break; case 3: w = pk[3]; break;
+                            default: {
+                                const int row = __builtin_amdgcn_readlane(half ? row1 : row0, l_);
+                                w = ((unsigned)*(const uint16_t*)(lutb + (unsigned)row * (MASK_LUT_ROW * 2u)) >> sh_ & 0xFFu) << ((k & 1) << 4);
+                            }
+                        }
+                        w = (w >> ((k & 1) << 4)) & 0xFFu;
+                        k++;
+                        const unsigned lo = w & 15u, hi = w >> 4;
                         const bool need = lo < hi && lo < mhi;
                         if (!__any(need)) continue;
                         const double xv = xs[ib];
