@@ -43,7 +43,7 @@ def main():
     o = orc.step(rng.uniform(-1, 1, (n, 2)), with_rs=True)
     maxc = 0.3327130214085973
     first_hit, caught = [], {}
-    combos = [(64, 1), (64, 4), (96, 3), (128, 4), (128, 6), (128, 8), (192, 9), (192, 12), (256, 8), (256, 12), (256, 16), (160, 10), (160, 5)]
+    combos = [(128, 32), (128, 16), (96, 24), (64, 16), (160, 32), (64, 1), (64, 4), (96, 3), (128, 4), (128, 6), (128, 8), (192, 9), (192, 12), (256, 8), (256, 12), (256, 16), (160, 10), (160, 5)]
     for c in combos:
         caught[c] = 0
     n_search = n_words = n_invalid = all_dead = {c: 0 for c in combos}
