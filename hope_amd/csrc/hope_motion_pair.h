@@ -146,11 +146,17 @@ __device__ __noinline__ void mp_turnover(const double* verts, const float4* obb,
     ssync();
 }
 
+#ifndef HOPE_MP_PRIO
+#define HOPE_MP_PRIO 0        // wave priority of k_motion_pair (2 / 3 measured: see DESIGN 9a)
+#endif
 #ifndef HOPE_MP_OCC
 #define HOPE_MP_OCC 4         // waves per SIMD k_motion_pair is compiled for
 #endif
 __global__ __launch_bounds__(64, HOPE_MP_OCC) void k_motion_pair(StepParams p) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+#if HOPE_MP_PRIO
+    __builtin_amdgcn_s_setprio(HOPE_MP_PRIO);               // (A/B: the launch shares its SIMDs with the validation kernel, which runs at priority 1)
+#endif
     const int lane = threadIdx.x, hw = lane >> 5, hl = lane & (OP_HALF - 1);
     const int n_pairs = (p.n_list + 1) >> 1;
     if ((int)blockIdx.x >= n_pairs) return;
